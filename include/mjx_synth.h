@@ -1,0 +1,142 @@
+/*
+ * mjx_synth.h — deterministic synthetic inputs for the masked-compose / effect hot path.
+ *
+ * Shared, header-only, integer-exact definition of the synthetic workload of SURVEY.md §8(d):
+ * the HIP generator kernels (libmodjpeg_amd/csrc/mjx_synth.hip) and the CPU generator used by
+ * the oracle / cpu_baseline (oracle/mjx_synth.c) both include this file, so the GPU batch and the
+ * CPU sample are bit-identical without ever crossing PCIe.
+ *
+ * Everything here is a pure function of (seed, image index, component, block, coefficient):
+ * counter-based splitmix64, no state, no floating-point transcendentals.  The only floating-point
+ * operations are int->float conversions and the alpha scaling `(float)((double)(float)a * K)`,
+ * which restates the typing of the reference's tile preparation (reference dropon.c:548-566):
+ * every operation is a single IEEE-754 rounding, identical on x86-64 and gfx950.
+ *
+ * Value model (what a decoder + tile preparation would hand to the hot path):
+ *   JCOEF      quantised coefficient = trunc(dequantised / q);  dequantised DC uniform in
+ *              [-1000,1000], AC two-sided exponential-like with scale 40/(1+u+v), |AC| <= 1000,
+ *              so coef*q never wraps int16 (libjpeg 8-bit JPEG range).
+ *   image tile integer-valued floats (a q==1 "quality 100" JPEG of the dropon, reference
+ *              dropon.c:476-485): DC in [-1016,1016], |AC| <= 255 decaying with frequency.
+ *   alpha tile integer alpha-DCT coefficient a(k,l) times the K constants of dropon.c:548-566,
+ *              DC already offset by +1024 (dropon.c:542), three sparsity regimes:
+ *                A1 uniform : only w[0][0], a00 = 2040 (opaque)               -> 1 nnz / block
+ *                A2 smooth  : a(k,l) != 0 only for k+l <= 3 (headline)        -> 10 nnz / block
+ *                A3 dense   : all 64 non-zero                                 -> 64 nnz / block
+ */
+#ifndef MJX_SYNTH_H_
+#define MJX_SYNTH_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MJX_HD __host__ __device__ static inline
+#else
+#define MJX_HD static inline
+#endif
+
+#define MJX_SEED_COEF  0x5EED0000ull
+#define MJX_SEED_TILE  0xD80F0000ull
+#define MJX_SEED_ALPHA 0xA19A0000ull
+
+#define MJX_ALPHA_UNIFORM 1 /* A1 */
+#define MJX_ALPHA_SMOOTH  2 /* A2 */
+#define MJX_ALPHA_DENSE   3 /* A3 */
+
+/* n-th output (n = idx) of the splitmix64 stream seeded with `seed`. */
+MJX_HD uint64_t mjx_hash64(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* per-(image, component) stream key */
+MJX_HD uint64_t mjx_stream(uint64_t base, uint64_t image, uint32_t comp) {
+    return mjx_hash64(base + image, 0x1000ull + comp);
+}
+
+MJX_HD int mjx_clz32(uint32_t x) {
+    int n = 0;
+    if(x == 0) return 32;
+    while((x & 0x80000000u) == 0) { x <<= 1; n++; }
+    return n;
+}
+
+/* integer ~Exp(1) variate scaled by 256: clz gives the geometric part, 8 bits interpolate */
+MJX_HD int mjx_exp256(uint64_t r) {
+    int g = mjx_clz32((uint32_t)r);
+    int f = (int)((r >> 32) & 0xFF);
+    return g * 177 + ((f * 177) >> 8);
+}
+
+/* dequantised coefficient value at frequency (v,u) */
+MJX_HD int mjx_synth_dequant_value(uint64_t r, int v, int u) {
+    if((v | u) == 0) {
+        return (int)(r % 2001ull) - 1000;
+    }
+    int scale = 40 / (1 + u + v);
+    int mag = (scale * mjx_exp256(r)) >> 8;
+    if(mag > 1000) mag = 1000;
+    return ((r >> 63) != 0) ? -mag : mag;
+}
+
+/* JCOEF of block `block` (linear index inside the component plane), coefficient j = v*8+u */
+MJX_HD int16_t mjx_synth_coef(uint64_t stream, uint64_t block, int j, uint16_t q) {
+    uint64_t r = mjx_hash64(stream, block * 64ull + (uint64_t)j);
+    int val = mjx_synth_dequant_value(r, j >> 3, j & 7);
+    return (int16_t)(val / (int)q); /* C truncation toward zero */
+}
+
+/* image tile value (integer-valued float) */
+MJX_HD float mjx_synth_tile(uint64_t stream, uint64_t block, int j) {
+    uint64_t r = mjx_hash64(stream, block * 64ull + (uint64_t)j);
+    int v = j >> 3, u = j & 7, val;
+    if(j == 0) {
+        val = (int)(r % 2033ull) - 1016;
+    }
+    else {
+        int scale = 96 / (1 + u + v);
+        int mag = (scale * mjx_exp256(r)) >> 8;
+        if(mag > 255) mag = 255;
+        val = ((r >> 63) != 0) ? -mag : mag;
+    }
+    return (float)val;
+}
+
+/* scaling constants of the reference's alpha tile preparation, same literal expressions
+ * (reference dropon.c:548-566); constant-folded in double by any IEEE compiler */
+#define MJX_K00 (0.3535534 * 0.3535534 / 1020.0)
+#define MJX_K0U (0.3535534 * 0.5 / 1020.0)
+#define MJX_KV0 (0.5 * 0.3535534 / 1020.0)
+#define MJX_KVU (0.5 * 0.5 / 1020.0)
+
+MJX_HD float mjx_alpha_scale(int a, int j) {
+    int v = j >> 3, u = j & 7;
+    double K = (v == 0) ? ((u == 0) ? MJX_K00 : MJX_K0U) : ((u == 0) ? MJX_KV0 : MJX_KVU);
+    return (float)((double)(float)a * K);
+}
+
+/* integer alpha-DCT coefficient (DC already +1024) for the given regime */
+MJX_HD int mjx_synth_alpha_int(uint64_t stream, uint64_t block, int j, int regime) {
+    uint64_t r = mjx_hash64(stream, block * 64ull + (uint64_t)j);
+    int v = j >> 3, u = j & 7;
+    if(regime == MJX_ALPHA_UNIFORM) {
+        return (j == 0) ? 2040 : 0;
+    }
+    if(j == 0) {
+        return (int)(r % 2041ull); /* [0,2040] */
+    }
+    if(regime == MJX_ALPHA_SMOOTH && (u + v) > 3) {
+        return 0;
+    }
+    int a = (int)(r % 401ull) - 200;
+    if(regime == MJX_ALPHA_DENSE && a == 0) a = 1;
+    return a;
+}
+
+MJX_HD float mjx_synth_alpha(uint64_t stream, uint64_t block, int j, int regime) {
+    return mjx_alpha_scale(mjx_synth_alpha_int(stream, block, j, regime), j);
+}
+
+#endif /* MJX_SYNTH_H_ */
