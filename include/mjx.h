@@ -1,0 +1,142 @@
+/*
+ * mjx.h — C ABI of the MI355X-native libmodjpeg hot path (libmjx_hip.so).
+ *
+ * This is the drop-in boundary below the libmodjpeg.h API: plain C, plain pointers and sizes, no
+ * libjpeg types, no torch types.  Everything the reference computes per 8x8 block inside
+ *
+ *      mj_compose_with_mask()   reference src/compose.c:237-342
+ *      mj_convolve()            reference src/convolve.c:29-1099
+ *      mj_effect_grayscale()    reference src/effect.c:28-68
+ *      mj_effect_pixelate()     reference src/effect.c:70-114
+ *      mj_effect_tint()         reference src/effect.c:116-183
+ *      mj_effect_luminance()    reference src/effect.c:185-222
+ *
+ * is done by hand-written gfx950 HIP kernels behind these entry points, bit-exact against the
+ * reference CPU path (JCOEF output identical on identical inputs).  The libjpeg-facing
+ * libmodjpeg.h shim (libmodjpeg_amd/host/, include/libmodjpeg.h) and the Python mirror
+ * (libmodjpeg_amd/api.py) are thin callers of this header.
+ *
+ * There is NO CPU fallback: without a usable HIP device every compute entry point returns
+ * MJX_ERR_NO_DEVICE (and says so on stderr once).
+ *
+ * Data layout (the reference's own):
+ *   JCOEF plane   int16_t[rows_total][blocks_per_row][64], one 8x8 block = 64 coefficients in
+ *                 natural (row-major, de-zigzagged) order, index v*8+u; this is libjpeg's
+ *                 JBLOCKROW layout (a component's virtual array row = blocks_per_row*128 bytes).
+ *   quant table   uint16_t[64], natural order (jpeg_component_info.quant_table->quantval).
+ *   tiles         float[rows*cols][64]: prepared dropon blocks (mj_compileddropon_t.image[c]
+ *                 .blocks[cols*l+k][i], reference libmodjpeg.h:86-97) made contiguous, tile row l,
+ *                 tile column k; alpha likewise (already scaled as reference dropon.c:542-566).
+ *   All device pointers must be 16-byte aligned.
+ *
+ * Threading: a plan may be run from one thread at a time; distinct plans are independent.  Each
+ * host thread works on the device selected by its last mjx_set_device() (hipSetDevice semantics).
+ */
+#ifndef MJX_H_
+#define MJX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJX_VERSION 100
+
+/* error codes (0 = success).  The libmodjpeg.h shim maps them onto MJ_ERR_* (INTEGRATION.md). */
+#define MJX_OK             0
+#define MJX_ERR_NO_DEVICE  1 /* no HIP device / HIP runtime failure */
+#define MJX_ERR_MEMORY     2 /* device or host allocation failed */
+#define MJX_ERR_NULL_DATA  3 /* NULL pointer where data is required (MJ_ERR_NULL_DATA) */
+#define MJX_ERR_BAD_ARG    4 /* misaligned pointer, negative size, q == 0, rect outside plane */
+#define MJX_ERR_LAUNCH     5 /* kernel launch or synchronisation failed */
+
+typedef void *mjx_stream_t; /* a hipStream_t, or NULL for the default stream */
+
+/* ---- device plumbing (so that C callers need no HIP headers) -------------------------- */
+int         mjx_device_count(void);                 /* number of HIP devices, 0 if none */
+int         mjx_set_device(int ordinal);            /* hipSetDevice for the calling thread */
+const char *mjx_error_string(int err);
+int         mjx_malloc(void **dev, size_t bytes);   /* hipMalloc, 256-byte aligned */
+int         mjx_free(void *dev);
+int         mjx_memcpy_h2d(void *dev, const void *host, size_t bytes, mjx_stream_t s);
+int         mjx_memcpy_d2h(void *host, const void *dev, size_t bytes, mjx_stream_t s);
+int         mjx_stream_synchronize(mjx_stream_t s);
+
+/* ---- masked compose: mj_compose_with_mask (reference compose.c:237) -------------------- */
+
+/* One rectangle of one component plane of one image: what one iteration of the component loop
+ * at reference compose.c:256-338 visits.  Tile block (l,k) is blended into plane block
+ * (row0+l, col0+k); row0/col0 are the reference's height_offset/width_offset
+ * (block_y*v_samp, block_x*h_samp, compose.c:264-265). */
+typedef struct mjx_rect_job {
+    int16_t     *coef;           /* DEVICE: component plane, updated in place */
+    const float *tile;           /* DEVICE: rows*cols prepared image blocks */
+    const float *alpha;          /* DEVICE: rows*cols prepared alpha blocks */
+    int32_t      blocks_per_row; /* plane row pitch in blocks (width_in_blocks of the array) */
+    int32_t      plane_rows;     /* plane height in blocks (bounds check only) */
+    int32_t      row0, col0;     /* top-left block of the rectangle inside the plane */
+    int32_t      rows, cols;     /* rectangle size in blocks == tile height/width in blocks */
+    int32_t      qtable;         /* index into the plan's quant tables */
+} mjx_rect_job_t;
+
+typedef struct mjx_compose_plan mjx_compose_plan_t;
+
+/* Build a device-resident launch plan for `njobs` rectangles (any mix of images/components).
+ * `jobs` and `qtables` (nq tables of 64 uint16, natural order) are HOST arrays, copied.
+ * Rectangles must not overlap each other inside one plan. */
+int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs,
+                            const uint16_t *qtables, int nq);
+void mjx_compose_plan_destroy(mjx_compose_plan_t *plan);
+/* total 8x8 blocks the plan composes per run */
+int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan);
+/* Enqueue one pass over all rectangles on `stream` (asynchronous; no host sync, no allocation:
+ * safe inside hipGraph capture). */
+int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream);
+
+/* Convenience for per-image callers (the libmodjpeg.h shim): HOST buffers in, composed HOST
+ * plane out.  plane = blocks_per_row*plane_rows blocks; only the rectangle's rows travel. */
+int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, int row0, int col0, int rows, int cols,
+                          const uint16_t *q, const float *tile, const float *alpha);
+
+/* ---- one (k,l) term: mj_convolve (reference convolve.c:29), test seam ------------------- */
+/* y[b][64] += V_k(H_l(x[b][64])) * w for b < nblocks; x, y DEVICE float arrays. */
+int mjx_convolve(const float *x, float *y, float w, int k, int l, int nblocks, mjx_stream_t stream);
+
+/* ---- per-block effects (reference effect.c) -------------------------------------------- */
+
+/* One component plane (true width_in_blocks x height_in_blocks inside a pitch of
+ * blocks_per_row): DC' = clamp((short)((short)(DC*q0) + value), -2047, 2047) / q0 —
+ * mj_effect_luminance on component 0, mj_effect_tint on components 1 and 2
+ * (reference effect.c:207-217, :143-153, :167-177). */
+typedef struct mjx_dc_job {
+    int16_t *coef; /* DEVICE */
+    int32_t  blocks_per_row, rows, cols;
+    int32_t  value;
+    uint16_t q0;
+    uint16_t reserved;
+} mjx_dc_job_t;
+
+/* all jobs in one launch (fused luminance + tint over a batch = one pass over the DCs) */
+int mjx_effect_dc(const mjx_dc_job_t *jobs /* HOST */, int njobs, mjx_stream_t stream);
+
+typedef struct mjx_dc_plan mjx_dc_plan_t;
+int  mjx_dc_plan_create(mjx_dc_plan_t **plan, const mjx_dc_job_t *jobs, int njobs);
+void mjx_dc_plan_destroy(mjx_dc_plan_t *plan);
+int  mjx_dc_plan_run(const mjx_dc_plan_t *plan, mjx_stream_t stream);
+
+/* zero whole blocks (mj_effect_grayscale on components >= 1, effect.c:44-65; keep_dc = 0) or
+ * coefficients 1..63 (mj_effect_pixelate, effect.c:82-111; keep_dc = 1) of rows x cols blocks */
+int mjx_effect_zero(int16_t *coef /* DEVICE */, int blocks_per_row, int rows, int cols, int keep_dc, mjx_stream_t stream);
+
+/* ---- synthetic workload generators (bench / test support; definition: mjx_synth.h) ------ */
+int mjx_synth_coef(int16_t *dst /* DEVICE */, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks,
+                   const uint16_t *q /* HOST[64] */, mjx_stream_t stream);
+int mjx_synth_tile(float *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, mjx_stream_t stream);
+int mjx_synth_alpha(float *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, int regime, mjx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJX_H_ */

@@ -1,0 +1,96 @@
+"""ctypes binding of the C ABI in include/mjx.h (libmjx_hip.so, hand-written gfx950 kernels).
+
+There is no Python or CPU implementation of the hot path in this package: if the shared library is
+missing, or no HIP device is usable, every call fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmjx_hip.so")
+
+MJX_OK = 0
+MJX_ERR_NO_DEVICE = 1
+MJX_ERR_MEMORY = 2
+MJX_ERR_NULL_DATA = 3
+MJX_ERR_BAD_ARG = 4
+MJX_ERR_LAUNCH = 5
+
+
+class MjxError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__(f"{where}: mjx error {code} ({error_string(code)})")
+
+
+class RectJob(ctypes.Structure):
+    """struct mjx_rect_job (include/mjx.h)"""
+    _fields_ = [("coef", ctypes.c_void_p), ("tile", ctypes.c_void_p), ("alpha", ctypes.c_void_p),
+                ("blocks_per_row", ctypes.c_int32), ("plane_rows", ctypes.c_int32),
+                ("row0", ctypes.c_int32), ("col0", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("qtable", ctypes.c_int32)]
+
+
+class DcJob(ctypes.Structure):
+    """struct mjx_dc_job (include/mjx.h)"""
+    _fields_ = [("coef", ctypes.c_void_p), ("blocks_per_row", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("value", ctypes.c_int32), ("q0", ctypes.c_uint16), ("reserved", ctypes.c_uint16)]
+
+
+# every symbol include/mjx.h declares: (name, restype, argtypes)
+_vp, _i, _sz, _u64, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint32
+SYMBOLS = [
+    ("mjx_device_count", _i, []),
+    ("mjx_set_device", _i, [_i]),
+    ("mjx_error_string", ctypes.c_char_p, [_i]),
+    ("mjx_malloc", _i, [ctypes.POINTER(_vp), _sz]),
+    ("mjx_free", _i, [_vp]),
+    ("mjx_memcpy_h2d", _i, [_vp, _vp, _sz, _vp]),
+    ("mjx_memcpy_d2h", _i, [_vp, _vp, _sz, _vp]),
+    ("mjx_stream_synchronize", _i, [_vp]),
+    ("mjx_compose_plan_create", _i, [ctypes.POINTER(_vp), ctypes.POINTER(RectJob), _i, _vp, _i]),
+    ("mjx_compose_plan_destroy", None, [_vp]),
+    ("mjx_compose_plan_blocks", ctypes.c_int64, [_vp]),
+    ("mjx_compose_run", _i, [_vp, _vp]),
+    ("mjx_compose_rect_host", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    ("mjx_convolve", _i, [_vp, _vp, ctypes.c_float, _i, _i, _i, _vp]),
+    ("mjx_effect_dc", _i, [ctypes.POINTER(DcJob), _i, _vp]),
+    ("mjx_dc_plan_create", _i, [ctypes.POINTER(_vp), ctypes.POINTER(DcJob), _i]),
+    ("mjx_dc_plan_destroy", None, [_vp]),
+    ("mjx_dc_plan_run", _i, [_vp, _vp]),
+    ("mjx_effect_zero", _i, [_vp, _i, _i, _i, _i, _vp]),
+    ("mjx_synth_coef", _i, [_vp, _u64, _u32, _u64, _sz, _vp, _vp]),
+    ("mjx_synth_tile", _i, [_vp, _u64, _u32, _u64, _sz, _vp]),
+    ("mjx_synth_alpha", _i, [_vp, _u64, _u32, _u64, _sz, _i, _vp]),
+]
+
+_lib = None
+
+
+def lib():
+    """The loaded libmjx_hip.so; raises if it has not been built (python -c 'import
+    __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build(); "
+                               "libmodjpeg_amd has no CPU fallback for the hot path")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def error_string(code):
+    try:
+        return lib().mjx_error_string(code).decode()
+    except Exception:
+        return "?"
+
+
+def check(code, where):
+    if code != MJX_OK:
+        raise MjxError(code, where)

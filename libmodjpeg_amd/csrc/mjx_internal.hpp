@@ -1,0 +1,66 @@
+// mjx_internal.hpp — shared declarations of libmjx_hip.so (not installed)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mjx.h"
+
+namespace mjx {
+
+// device-side job descriptor (built by mjx_compose_plan_create from mjx_rect_job_t)
+struct DevJob {
+    int16_t     *coef;
+    const float *tile;
+    const float *alpha;
+    int32_t      bpr, row0, col0, cols;
+    int32_t      nblocks; // rows*cols
+    int32_t      qidx;
+    float        inv_cols; // 1.0f/cols, for the row/column split of the linear tile index
+    int32_t      pad;
+};
+static_assert(sizeof(DevJob) == 56, "DevJob layout");
+
+// one workgroup's share: up to kChunkBlocks consecutive tile blocks of one job
+struct Chunk {
+    int32_t job;
+    int32_t first;
+};
+
+constexpr int kWaveBlocks = 8;     // one wavefront = 8 blocks x 8 lanes
+constexpr int kWavesPerGroup = 4;  // 256 threads
+constexpr int kOctetsPerWave = 4;
+constexpr int kChunkBlocks = kWaveBlocks * kWavesPerGroup * kOctetsPerWave; // 128
+
+struct DevDcJob {
+    int16_t *coef;
+    int32_t  bpr, rows, cols, value;
+    int32_t  q0;
+    float    rq0;
+};
+
+struct QTable {
+    uint16_t q[64];
+};
+
+// host helpers (mjx_runtime.hip)
+int   check_hip(hipError_t e, const char *what, int err_code);
+bool  ensure_device();
+float rq_of(unsigned q);
+
+#define MJX_HIP(call, code)                                    \
+    do {                                                       \
+        int _e = ::mjx::check_hip((call), #call, (code));      \
+        if(_e != MJX_OK) return _e;                            \
+    } while(0)
+
+// launchers implemented in the kernel translation units
+int launch_compose(const DevJob *jobs, const Chunk *chunks, int nchunks, const uint16_t *qtab, const float *rqtab, hipStream_t s);
+int launch_convolve(const float *x, float *y, float w, int k, int l, int nblocks, hipStream_t s);
+int launch_effect_dc(const DevDcJob *jobs, int njobs, int64_t max_blocks_per_job, hipStream_t s);
+int launch_effect_zero(int16_t *coef, int bpr, int rows, int cols, int keep_dc, hipStream_t s);
+int launch_synth_coef(int16_t *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, const QTable &q, hipStream_t s);
+int launch_synth_tile(float *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, hipStream_t s);
+int launch_synth_alpha(float *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, int regime, hipStream_t s);
+
+} // namespace mjx

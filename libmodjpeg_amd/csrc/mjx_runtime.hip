@@ -1,0 +1,397 @@
+// mjx_runtime.hip — host side of the C ABI declared in include/mjx.h: device plumbing, launch
+// plans (device-resident job descriptors and workgroup chunk tables) and the per-image host-buffer
+// convenience call used by the libmodjpeg.h shim.  No CPU compute path exists here by design:
+// without a HIP device every entry point fails with MJX_ERR_NO_DEVICE.
+#include "mjx_internal.hpp"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <new>
+#include <vector>
+
+namespace mjx {
+
+int check_hip(hipError_t e, const char *what, int err_code) {
+    if(e == hipSuccess) return MJX_OK;
+    fprintf(stderr, "libmjx_hip: %s failed: %s\n", what, hipGetErrorString(e));
+    return err_code;
+}
+
+bool ensure_device() {
+    static std::atomic<int> state{0}; // 0 unknown, 1 ok, -1 none
+    int                     s = state.load();
+    if(s == 0) {
+        int        n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        s = (e == hipSuccess && n > 0) ? 1 : -1;
+        if(s < 0) {
+            fprintf(stderr, "libmjx_hip: no usable HIP device (%s); this library has no CPU fallback\n",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        }
+        state.store(s);
+    }
+    return s > 0;
+}
+
+// smallest float >= 1/q (see requant() in mjx_block_math.hpp)
+float rq_of(unsigned q) {
+    const double r = 1.0 / (double)q;
+    float        f = (float)r;
+    if((double)f < r) f = nextafterf(f, INFINITY);
+    return f;
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+} // namespace mjx
+
+using namespace mjx;
+
+struct mjx_compose_plan {
+    DevJob   *d_jobs = nullptr;
+    Chunk    *d_chunks = nullptr;
+    uint16_t *d_q = nullptr;
+    float    *d_rq = nullptr;
+    int       nchunks = 0;
+    int       njobs = 0;
+    int64_t   blocks = 0;
+};
+
+struct mjx_dc_plan {
+    DevDcJob *d_jobs = nullptr;
+    int       njobs = 0;
+    int64_t   max_blocks = 0;
+};
+
+extern "C" {
+
+int mjx_device_count(void) {
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mjx_set_device(int ordinal) {
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    MJX_HIP(hipSetDevice(ordinal), MJX_ERR_NO_DEVICE);
+    return MJX_OK;
+}
+
+const char *mjx_error_string(int err) {
+    switch(err) {
+        case MJX_OK: return "ok";
+        case MJX_ERR_NO_DEVICE: return "no HIP device (no CPU fallback in this library)";
+        case MJX_ERR_MEMORY: return "out of memory";
+        case MJX_ERR_NULL_DATA: return "null data";
+        case MJX_ERR_BAD_ARG: return "bad argument";
+        case MJX_ERR_LAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+int mjx_malloc(void **dev, size_t bytes) {
+    if(dev == nullptr) return MJX_ERR_NULL_DATA;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    MJX_HIP(hipMalloc(dev, bytes ? bytes : 16), MJX_ERR_MEMORY);
+    return MJX_OK;
+}
+
+int mjx_free(void *dev) {
+    if(dev == nullptr) return MJX_OK;
+    MJX_HIP(hipFree(dev), MJX_ERR_MEMORY);
+    return MJX_OK;
+}
+
+int mjx_memcpy_h2d(void *dev, const void *host, size_t bytes, mjx_stream_t s) {
+    if(bytes == 0) return MJX_OK;
+    if(dev == nullptr || host == nullptr) return MJX_ERR_NULL_DATA;
+    MJX_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, (hipStream_t)s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipStreamSynchronize((hipStream_t)s), MJX_ERR_LAUNCH);
+    return MJX_OK;
+}
+
+int mjx_memcpy_d2h(void *host, const void *dev, size_t bytes, mjx_stream_t s) {
+    if(bytes == 0) return MJX_OK;
+    if(dev == nullptr || host == nullptr) return MJX_ERR_NULL_DATA;
+    MJX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipStreamSynchronize((hipStream_t)s), MJX_ERR_LAUNCH);
+    return MJX_OK;
+}
+
+int mjx_stream_synchronize(mjx_stream_t s) {
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    MJX_HIP(hipStreamSynchronize((hipStream_t)s), MJX_ERR_LAUNCH);
+    return MJX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// compose plans
+// ------------------------------------------------------------------------------------------
+void mjx_compose_plan_destroy(mjx_compose_plan_t *p) {
+    if(p == nullptr) return;
+    if(p->d_jobs) (void)hipFree(p->d_jobs);
+    if(p->d_chunks) (void)hipFree(p->d_chunks);
+    if(p->d_q) (void)hipFree(p->d_q);
+    if(p->d_rq) (void)hipFree(p->d_rq);
+    delete p;
+}
+
+int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq) {
+    if(plan == nullptr) return MJX_ERR_NULL_DATA;
+    *plan = nullptr;
+    if(njobs < 0 || nq < 0) return MJX_ERR_BAD_ARG;
+    if(njobs > 0 && (jobs == nullptr || qtables == nullptr || nq == 0)) return MJX_ERR_NULL_DATA;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+
+    // the reference divides by quantval (compose.c:327-336): q == 0 is a caller bug there (SIGFPE)
+    for(int i = 0; i < nq * 64; ++i) {
+        if(qtables[i] == 0) return MJX_ERR_BAD_ARG;
+    }
+
+    std::vector<DevJob> dj;
+    std::vector<Chunk>  ch;
+    int64_t             blocks = 0;
+    // rectangles of >= 2^24 blocks are split by rows so that the kernel's float row/column split
+    // of the linear tile index stays exact
+    const int64_t kMaxJobBlocks = (1ll << 24) - 1;
+
+    for(int i = 0; i < njobs; ++i) {
+        const mjx_rect_job_t &j = jobs[i];
+        if(j.rows < 0 || j.cols < 0) return MJX_ERR_BAD_ARG;
+        if(j.rows == 0 || j.cols == 0) continue;
+        if(j.coef == nullptr || j.tile == nullptr || j.alpha == nullptr) return MJX_ERR_NULL_DATA;
+        if(!aligned16(j.coef) || !aligned16(j.tile) || !aligned16(j.alpha)) return MJX_ERR_BAD_ARG;
+        if(j.qtable < 0 || j.qtable >= nq) return MJX_ERR_BAD_ARG;
+        if(j.row0 < 0 || j.col0 < 0 || j.blocks_per_row <= 0 || j.col0 + (int64_t)j.cols > j.blocks_per_row) return MJX_ERR_BAD_ARG;
+        if(j.plane_rows > 0 && j.row0 + (int64_t)j.rows > j.plane_rows) return MJX_ERR_BAD_ARG;
+        if(j.cols > kMaxJobBlocks) return MJX_ERR_BAD_ARG;
+
+        const int max_rows = (int)(kMaxJobBlocks / j.cols);
+        for(int r0 = 0; r0 < j.rows; r0 += max_rows) {
+            const int rows = (j.rows - r0 < max_rows) ? (j.rows - r0) : max_rows;
+            DevJob    d;
+            d.coef = j.coef;
+            d.tile = j.tile + (size_t)r0 * (size_t)j.cols * 64;
+            d.alpha = j.alpha + (size_t)r0 * (size_t)j.cols * 64;
+            d.bpr = j.blocks_per_row;
+            d.row0 = j.row0 + r0;
+            d.col0 = j.col0;
+            d.cols = j.cols;
+            d.nblocks = rows * j.cols;
+            d.qidx = j.qtable;
+            d.inv_cols = 1.0f / (float)j.cols;
+            d.pad = 0;
+            const int jid = (int)dj.size();
+            dj.push_back(d);
+            for(int f = 0; f < d.nblocks; f += kChunkBlocks) ch.push_back(Chunk{jid, f});
+            blocks += d.nblocks;
+        }
+    }
+
+    mjx_compose_plan *p = new(std::nothrow) mjx_compose_plan;
+    if(p == nullptr) return MJX_ERR_MEMORY;
+    p->njobs = (int)dj.size();
+    p->nchunks = (int)ch.size();
+    p->blocks = blocks;
+
+    std::vector<float> rq((size_t)nq * 64);
+    for(int i = 0; i < nq * 64; ++i) rq[(size_t)i] = rq_of(qtables[i]);
+
+    int err = MJX_OK;
+    do {
+        if(p->njobs == 0) break;
+        if((err = check_hip(hipMalloc((void **)&p->d_jobs, dj.size() * sizeof(DevJob)), "hipMalloc(jobs)", MJX_ERR_MEMORY))) break;
+        if((err = check_hip(hipMalloc((void **)&p->d_chunks, ch.size() * sizeof(Chunk)), "hipMalloc(chunks)", MJX_ERR_MEMORY))) break;
+        if((err = check_hip(hipMalloc((void **)&p->d_q, (size_t)nq * 64 * sizeof(uint16_t)), "hipMalloc(q)", MJX_ERR_MEMORY))) break;
+        if((err = check_hip(hipMalloc((void **)&p->d_rq, (size_t)nq * 64 * sizeof(float)), "hipMalloc(rq)", MJX_ERR_MEMORY))) break;
+        if((err = check_hip(hipMemcpy(p->d_jobs, dj.data(), dj.size() * sizeof(DevJob), hipMemcpyHostToDevice), "hipMemcpy(jobs)", MJX_ERR_LAUNCH))) break;
+        if((err = check_hip(hipMemcpy(p->d_chunks, ch.data(), ch.size() * sizeof(Chunk), hipMemcpyHostToDevice), "hipMemcpy(chunks)", MJX_ERR_LAUNCH))) break;
+        if((err = check_hip(hipMemcpy(p->d_q, qtables, (size_t)nq * 64 * sizeof(uint16_t), hipMemcpyHostToDevice), "hipMemcpy(q)", MJX_ERR_LAUNCH))) break;
+        if((err = check_hip(hipMemcpy(p->d_rq, rq.data(), (size_t)nq * 64 * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(rq)", MJX_ERR_LAUNCH))) break;
+    } while(0);
+    if(err != MJX_OK) {
+        mjx_compose_plan_destroy(p);
+        return err;
+    }
+    *plan = p;
+    return MJX_OK;
+}
+
+int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan) { return plan ? plan->blocks : 0; }
+
+int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
+    if(plan == nullptr) return MJX_ERR_NULL_DATA;
+    if(plan->nchunks == 0) return MJX_OK;
+    return launch_compose(plan->d_jobs, plan->d_chunks, plan->nchunks, plan->d_q, plan->d_rq, (hipStream_t)stream);
+}
+
+int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, int row0, int col0, int rows, int cols, const uint16_t *q,
+                          const float *tile, const float *alpha) {
+    if(plane == nullptr || q == nullptr || tile == nullptr || alpha == nullptr) return MJX_ERR_NULL_DATA;
+    if(rows < 0 || cols < 0 || row0 < 0 || col0 < 0 || blocks_per_row <= 0 || col0 + (int64_t)cols > blocks_per_row ||
+       row0 + (int64_t)rows > plane_rows)
+        return MJX_ERR_BAD_ARG;
+    if(rows == 0 || cols == 0) return MJX_OK;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+
+    // only the plane rows the rectangle touches travel over PCIe
+    const size_t coef_bytes = (size_t)rows * (size_t)blocks_per_row * 128;
+    const size_t tile_bytes = (size_t)rows * (size_t)cols * 256;
+    int16_t     *h_rows = plane + (size_t)row0 * (size_t)blocks_per_row * 64;
+    void        *d_coef = nullptr, *d_tile = nullptr, *d_alpha = nullptr;
+    int          err = MJX_OK;
+    mjx_compose_plan_t *plan = nullptr;
+
+    do {
+        if((err = mjx_malloc(&d_coef, coef_bytes))) break;
+        if((err = mjx_malloc(&d_tile, tile_bytes))) break;
+        if((err = mjx_malloc(&d_alpha, tile_bytes))) break;
+        if((err = mjx_memcpy_h2d(d_coef, h_rows, coef_bytes, nullptr))) break;
+        if((err = mjx_memcpy_h2d(d_tile, tile, tile_bytes, nullptr))) break;
+        if((err = mjx_memcpy_h2d(d_alpha, alpha, tile_bytes, nullptr))) break;
+        mjx_rect_job_t job;
+        job.coef = (int16_t *)d_coef;
+        job.tile = (const float *)d_tile;
+        job.alpha = (const float *)d_alpha;
+        job.blocks_per_row = blocks_per_row;
+        job.plane_rows = rows;
+        job.row0 = 0;
+        job.col0 = col0;
+        job.rows = rows;
+        job.cols = cols;
+        job.qtable = 0;
+        if((err = mjx_compose_plan_create(&plan, &job, 1, q, 1))) break;
+        if((err = mjx_compose_run(plan, nullptr))) break;
+        if((err = mjx_memcpy_d2h(h_rows, d_coef, coef_bytes, nullptr))) break;
+    } while(0);
+
+    mjx_compose_plan_destroy(plan);
+    (void)mjx_free(d_coef);
+    (void)mjx_free(d_tile);
+    (void)mjx_free(d_alpha);
+    return err;
+}
+
+int mjx_convolve(const float *x, float *y, float w, int k, int l, int nblocks, mjx_stream_t stream) {
+    if(x == nullptr || y == nullptr) return MJX_ERR_NULL_DATA;
+    if(k < 0 || k > 7 || l < 0 || l > 7 || nblocks < 0 || !aligned16(x) || !aligned16(y)) return MJX_ERR_BAD_ARG;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    return launch_convolve(x, y, w, k, l, nblocks, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// effects
+// ------------------------------------------------------------------------------------------
+static int build_dc_jobs(const mjx_dc_job_t *jobs, int njobs, std::vector<DevDcJob> &out, int64_t &max_blocks) {
+    max_blocks = 0;
+    for(int i = 0; i < njobs; ++i) {
+        const mjx_dc_job_t &j = jobs[i];
+        if(j.rows < 0 || j.cols < 0 || j.blocks_per_row < j.cols) return MJX_ERR_BAD_ARG;
+        if(j.rows == 0 || j.cols == 0) continue;
+        if(j.coef == nullptr) return MJX_ERR_NULL_DATA;
+        if(j.q0 == 0) return MJX_ERR_BAD_ARG;
+        if((int64_t)j.rows * j.cols > 0x7FFFFFFFll) return MJX_ERR_BAD_ARG;
+        DevDcJob d;
+        d.coef = j.coef;
+        d.bpr = j.blocks_per_row;
+        d.rows = j.rows;
+        d.cols = j.cols;
+        d.value = j.value;
+        d.q0 = j.q0;
+        d.rq0 = rq_of(j.q0);
+        out.push_back(d);
+        if((int64_t)j.rows * j.cols > max_blocks) max_blocks = (int64_t)j.rows * j.cols;
+    }
+    if(out.size() > 65535) return MJX_ERR_BAD_ARG; // grid.y limit; callers batch above that
+    return MJX_OK;
+}
+
+void mjx_dc_plan_destroy(mjx_dc_plan_t *p) {
+    if(p == nullptr) return;
+    if(p->d_jobs) (void)hipFree(p->d_jobs);
+    delete p;
+}
+
+int mjx_dc_plan_create(mjx_dc_plan_t **plan, const mjx_dc_job_t *jobs, int njobs) {
+    if(plan == nullptr) return MJX_ERR_NULL_DATA;
+    *plan = nullptr;
+    if(njobs < 0) return MJX_ERR_BAD_ARG;
+    if(njobs > 0 && jobs == nullptr) return MJX_ERR_NULL_DATA;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    std::vector<DevDcJob> dj;
+    int64_t               max_blocks = 0;
+    int                   err = build_dc_jobs(jobs, njobs, dj, max_blocks);
+    if(err != MJX_OK) return err;
+    mjx_dc_plan *p = new(std::nothrow) mjx_dc_plan;
+    if(p == nullptr) return MJX_ERR_MEMORY;
+    p->njobs = (int)dj.size();
+    p->max_blocks = max_blocks;
+    if(p->njobs > 0) {
+        err = check_hip(hipMalloc((void **)&p->d_jobs, dj.size() * sizeof(DevDcJob)), "hipMalloc(dc jobs)", MJX_ERR_MEMORY);
+        if(err == MJX_OK) err = check_hip(hipMemcpy(p->d_jobs, dj.data(), dj.size() * sizeof(DevDcJob), hipMemcpyHostToDevice), "hipMemcpy(dc jobs)", MJX_ERR_LAUNCH);
+        if(err != MJX_OK) {
+            mjx_dc_plan_destroy(p);
+            return err;
+        }
+    }
+    *plan = p;
+    return MJX_OK;
+}
+
+int mjx_dc_plan_run(const mjx_dc_plan_t *plan, mjx_stream_t stream) {
+    if(plan == nullptr) return MJX_ERR_NULL_DATA;
+    return launch_effect_dc(plan->d_jobs, plan->njobs, plan->max_blocks, (hipStream_t)stream);
+}
+
+int mjx_effect_dc(const mjx_dc_job_t *jobs, int njobs, mjx_stream_t stream) {
+    mjx_dc_plan_t *plan = nullptr;
+    int            err = mjx_dc_plan_create(&plan, jobs, njobs);
+    if(err != MJX_OK) return err;
+    err = mjx_dc_plan_run(plan, stream);
+    if(err == MJX_OK) err = check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize", MJX_ERR_LAUNCH);
+    mjx_dc_plan_destroy(plan);
+    return err;
+}
+
+int mjx_effect_zero(int16_t *coef, int blocks_per_row, int rows, int cols, int keep_dc, mjx_stream_t stream) {
+    if(rows < 0 || cols < 0 || blocks_per_row < cols) return MJX_ERR_BAD_ARG;
+    if(rows == 0 || cols == 0) return MJX_OK;
+    if(coef == nullptr) return MJX_ERR_NULL_DATA;
+    if(!aligned16(coef)) return MJX_ERR_BAD_ARG;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    return launch_effect_zero(coef, blocks_per_row, rows, cols, keep_dc ? 1 : 0, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic inputs
+// ------------------------------------------------------------------------------------------
+int mjx_synth_coef(int16_t *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, const uint16_t *q, mjx_stream_t stream) {
+    if(dst == nullptr || q == nullptr) return MJX_ERR_NULL_DATA;
+    if(!aligned16(dst)) return MJX_ERR_BAD_ARG;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    QTable t;
+    for(int i = 0; i < 64; ++i) {
+        if(q[i] == 0) return MJX_ERR_BAD_ARG;
+        t.q[i] = q[i];
+    }
+    return launch_synth_coef(dst, image, comp, first_block, nblocks, t, (hipStream_t)stream);
+}
+
+int mjx_synth_tile(float *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, mjx_stream_t stream) {
+    if(dst == nullptr) return MJX_ERR_NULL_DATA;
+    if(!aligned16(dst)) return MJX_ERR_BAD_ARG;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    return launch_synth_tile(dst, image, comp, first_block, nblocks, (hipStream_t)stream);
+}
+
+int mjx_synth_alpha(float *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, int regime, mjx_stream_t stream) {
+    if(dst == nullptr) return MJX_ERR_NULL_DATA;
+    if(!aligned16(dst) || regime < 1 || regime > 3) return MJX_ERR_BAD_ARG;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    return launch_synth_alpha(dst, image, comp, first_block, nblocks, regime, (hipStream_t)stream);
+}
+
+} // extern "C"
