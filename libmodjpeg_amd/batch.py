@@ -1,0 +1,210 @@
+"""Batches of independent images for the hot path: device-resident JCOEF planes, per-image
+prepared tiles, and the launch plans of include/mjx.h.
+
+An image batch is what `modjpeg-nginx`-style callers produce: many decoded JPEGs of one geometry,
+each composed with its own compiled dropon (the reference compiles tiles per mj_compose call,
+reference compose.c:155-157).  Images are independent, so a batch shards across GPUs by image
+index with no exchange step: rank r of G owns a contiguous range of image
+indices and nothing ever crosses xGMI.
+
+Synthetic contents follow include/mjx_synth.h and are generated on the device.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import DcJob, RectJob, check, lib
+
+_BASE_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+                       14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                       49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99])
+_BASE_CHROMA = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99,
+                         47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32)
+
+
+def quant_table(chroma, quality=85):
+    """JPEG Annex K table in natural order with libjpeg's quality scaling (baseline clamp)."""
+    scale = 5000 // quality if quality < 50 else 200 - 2 * quality
+    base = _BASE_CHROMA if chroma else _BASE_LUMA
+    return np.clip((base * scale + 50) // 100, 1, 255).astype(np.uint16)
+
+
+def shard_range(n_items, rank, world):
+    """contiguous shard [lo, hi) of rank `rank` out of `world` (image i -> rank floor(i*world/n))"""
+    lo = -(-n_items * rank // world)
+    hi = -(-n_items * (rank + 1) // world)
+    return lo, hi
+
+
+class Geometry420:
+    """block geometry of a 4:2:0 YCbCr JPEG as libjpeg lays its coefficient arrays out
+    (interleaved scan: every component array is padded to whole MCUs)"""
+
+    def __init__(self, width, height):
+        self.width, self.height = width, height
+        self.mcus_x = -(-width // 16)
+        self.mcus_y = -(-height // 16)
+        self.samp = [(2, 2), (1, 1), (1, 1)]
+        # true size (jpeg_component_info.width_in_blocks/height_in_blocks) and padded array size
+        # jdmaster/jdinput: ceil(image_dim * samp / (max_samp * 8))
+        self.true_dims = [(-(-width // 8), -(-height // 8))] + [(-(-width // 16), -(-height // 16))] * 2
+        self.array_dims = [(self.mcus_x * h, self.mcus_y * v) for h, v in self.samp]  # (blocks per row, rows)
+
+    def blocks_per_image(self):
+        return sum(w * h for w, h in self.array_dims)
+
+
+class ComposeBatch:
+    """`n` images (global indices image0 .. image0+n-1) of one geometry, one dropon rectangle per
+    image at MCU (mcu_x, mcu_y) of dropon_w x dropon_h pixels (multiples of 16), per-image tiles."""
+
+    def __init__(self, n, width, height, dropon_w, dropon_h, mcu_x, mcu_y, regime, image0=0, quality=85, device=None):
+        assert dropon_w % 16 == 0 and dropon_h % 16 == 0
+        self.n, self.image0, self.regime = n, image0, regime
+        self.geo = Geometry420(width, height)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.quant = [quant_table(False, quality), quant_table(True, quality), quant_table(True, quality)]
+        self.rect = []  # per component (row0, col0, rows, cols)
+        for (h, v) in self.geo.samp:
+            self.rect.append((mcu_y * v, mcu_x * h, dropon_h // 16 * v, dropon_w // 16 * h))
+        for c, (row0, col0, rows, cols) in enumerate(self.rect):
+            bpr, prow = self.geo.array_dims[c]
+            assert row0 + rows <= prow and col0 + cols <= bpr, "dropon rectangle outside the image"
+        self.coef = [torch.empty((n, prow, bpr, 64), dtype=torch.int16, device=self.device) for bpr, prow in self.geo.array_dims]
+        self.tile = [torch.empty((n, rows * cols, 64), dtype=torch.float32, device=self.device) for (_, _, rows, cols) in self.rect]
+        self.alpha = [torch.empty((n, rows * cols, 64), dtype=torch.float32, device=self.device) for (_, _, rows, cols) in self.rect]
+        self.plan = ctypes.c_void_p()
+        self.blocks_per_image = sum(r[2] * r[3] for r in self.rect)
+
+    # ---- contents -------------------------------------------------------------------------
+    def fill_synthetic(self):
+        L = lib()
+        vp = ctypes.c_void_p
+        s = vp(torch.cuda.current_stream().cuda_stream)
+        for c in range(3):
+            bpr, prow = self.geo.array_dims[c]
+            pblocks = bpr * prow
+            tblocks = self.rect[c][2] * self.rect[c][3]
+            q = self.quant[c]
+            qp = q.ctypes.data_as(vp)
+            cbase, cstep = self.coef[c].data_ptr(), pblocks * 128
+            tbase, abase, tstep = self.tile[c].data_ptr(), self.alpha[c].data_ptr(), tblocks * 256
+            for i in range(self.n):
+                g = self.image0 + i
+                check(L.mjx_synth_coef(vp(cbase + i * cstep), g, c, 0, pblocks, qp, s), "mjx_synth_coef")
+                check(L.mjx_synth_tile(vp(tbase + i * tstep), g, c, 0, tblocks, s), "mjx_synth_tile")
+                check(L.mjx_synth_alpha(vp(abase + i * tstep), g, c, 0, tblocks, self.regime, s), "mjx_synth_alpha")
+        torch.cuda.current_stream().synchronize()
+
+    # ---- launch plan ------------------------------------------------------------------------
+    def build_plan(self):
+        jobs = (RectJob * (3 * self.n))()
+        j = 0
+        for i in range(self.n):
+            for c in range(3):
+                bpr, prow = self.geo.array_dims[c]
+                row0, col0, rows, cols = self.rect[c]
+                jobs[j] = RectJob(self.coef[c][i].data_ptr(), self.tile[c][i].data_ptr(), self.alpha[c][i].data_ptr(),
+                                  bpr, prow, row0, col0, rows, cols, c)
+                j += 1
+        qt = np.ascontiguousarray(np.stack(self.quant))
+        self.destroy_plan()
+        check(lib().mjx_compose_plan_create(ctypes.byref(self.plan), jobs, 3 * self.n, qt.ctypes.data_as(ctypes.c_void_p), 3), "mjx_compose_plan_create")
+        assert lib().mjx_compose_plan_blocks(self.plan) == self.n * self.blocks_per_image
+        return self
+
+    def run(self):
+        """one pass of mj_compose_with_mask over every image of the batch (asynchronous)"""
+        check(lib().mjx_compose_run(self.plan, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "mjx_compose_run")
+
+    def destroy_plan(self):
+        if self.plan:
+            lib().mjx_compose_plan_destroy(self.plan)
+            self.plan = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy_plan()
+        except Exception:
+            pass
+
+    # ---- inspection -------------------------------------------------------------------------
+    def rect_numpy(self, i, c):
+        row0, col0, rows, cols = self.rect[c]
+        return self.coef[c][i, row0:row0 + rows, col0:col0 + cols].cpu().numpy()
+
+    def total_blocks(self):
+        return self.n * self.blocks_per_image
+
+
+class EffectBatch:
+    """`n` 4:2:0 images for the DC effects: mj_effect_luminance(value) followed by
+    mj_effect_tint(cb, cr) over every image (reference effect.c:185, :116).  `fused=True`
+    applies the three channel updates in one launch (one pass over the DCs); `fused=False` issues
+    the reference's two calls as two launches."""
+
+    def __init__(self, n, width, height, image0=0, quality=85, device=None):
+        self.n, self.image0 = n, image0
+        self.geo = Geometry420(width, height)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.quant = [quant_table(False, quality), quant_table(True, quality), quant_table(True, quality)]
+        self.coef = [torch.empty((n, prow, bpr, 64), dtype=torch.int16, device=self.device) for bpr, prow in self.geo.array_dims]
+        self.plans = []
+
+    def fill_synthetic(self):
+        L = lib()
+        vp = ctypes.c_void_p
+        s = vp(torch.cuda.current_stream().cuda_stream)
+        for c in range(3):
+            bpr, prow = self.geo.array_dims[c]
+            pblocks = bpr * prow
+            qp = self.quant[c].ctypes.data_as(vp)
+            base, step = self.coef[c].data_ptr(), pblocks * 128
+            for i in range(self.n):
+                check(L.mjx_synth_coef(vp(base + i * step), self.image0 + i, c, 0, pblocks, qp, s), "mjx_synth_coef")
+        torch.cuda.current_stream().synchronize()
+
+    def dc_blocks_per_image(self):
+        return sum(w * h for w, h in self.geo.true_dims)
+
+    def build_plans(self, lum, cb, cr, fused=True):
+        """the effects walk the TRUE width_in_blocks x height_in_blocks of each component
+        (effect.c:201-204), not the MCU-padded array"""
+        self.destroy_plans()
+        groups = [[(0, lum), (1, cb), (2, cr)]] if fused else [[(0, lum)], [(1, cb), (2, cr)]]
+        for grp in groups:
+            jobs = []
+            for c, value in grp:
+                if c > 0 and value == 0:
+                    continue  # effect.c:134/:158
+                bpr, prow = self.geo.array_dims[c]
+                tw, th = self.geo.true_dims[c]
+                base, step = self.coef[c].data_ptr(), bpr * prow * 128
+                q0 = int(self.quant[c][0])
+                for i in range(self.n):
+                    jobs.append(DcJob(base + i * step, bpr, th, tw, value, q0, 0))
+            # grid.y limit: 65535 jobs per launch
+            for lo in range(0, len(jobs), 65535):
+                part = jobs[lo:lo + 65535]
+                arr = (DcJob * len(part))(*part)
+                plan = ctypes.c_void_p()
+                check(lib().mjx_dc_plan_create(ctypes.byref(plan), arr, len(part)), "mjx_dc_plan_create")
+                self.plans.append(plan)
+        return self
+
+    def run(self):
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for p in self.plans:
+            check(lib().mjx_dc_plan_run(p, s), "mjx_dc_plan_run")
+
+    def destroy_plans(self):
+        for p in self.plans:
+            lib().mjx_dc_plan_destroy(p)
+        self.plans = []
+
+    def __del__(self):
+        try:
+            self.destroy_plans()
+        except Exception:
+            pass
