@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmjx_hip.so")
+LIB_PATH = os.environ.get("MJX_HIP_LIB") or os.path.join(_HERE, "libmjx_hip.so")  # override: kernel A/B experiments
 
 MJX_OK = 0
 MJX_ERR_NO_DEVICE = 1

@@ -114,6 +114,23 @@ template <int K, int V> MJX_DEV float vstage_elem(float y, const float (&z)[8], 
     }
 }
 
+// Term (k,l) = (0,0) is the first term of the reference's accumulation order, so it meets
+// y == +0.0f exactly: (float)((double)0 + (2.0*z)*w) is the exactly representable product
+// 2*z*w rounded once to float, i.e. fmaf(z, 2w, +0.0f) (the +0 addend also reproduces the +0
+// the reference gets from 0.0 + (-0.0)).  One f32 instruction per element instead of
+// cvt, cvt, fma_f64, cvt.
+MJX_DEV void vstage_first(float (&y)[8], const float (&z)[8], float w) {
+    const float w2 = w + w; // exact (overflow to inf only where the double path also ends at inf)
+    y[0] = __builtin_fmaf(z[0], w2, 0.0f);
+    y[1] = __builtin_fmaf(z[1], w2, 0.0f);
+    y[2] = __builtin_fmaf(z[2], w2, 0.0f);
+    y[3] = __builtin_fmaf(z[3], w2, 0.0f);
+    y[4] = __builtin_fmaf(z[4], w2, 0.0f);
+    y[5] = __builtin_fmaf(z[5], w2, 0.0f);
+    y[6] = __builtin_fmaf(z[6], w2, 0.0f);
+    y[7] = __builtin_fmaf(z[7], w2, 0.0f);
+}
+
 template <int K> MJX_DEV void vstage(float (&y)[8], const float (&z)[8], double sz0, float w) {
     const double wd = (double)w;
     const double w2d = wd + wd; // 2.0 * (double)w, exact
@@ -133,7 +150,7 @@ template <int K> MJX_DEV void vstage(float (&y)[8], const float (&z)[8], double 
 MJX_DEV int wrap16(int v) { return (int)(short)(v & 0xFFFF); }
 
 // D: (short)(coef * q), coef int16, q uint16: |coef*q| < 2^31, 24-bit multiply is enough
-MJX_DEV int dequant(int coef, int q) { return wrap16(coef * q); }
+MJX_DEV int dequant(int coef, int q) { return wrap16(__mul24(coef, q)); }
 
 // `(int)f` as the x86-64 build of the reference evaluates it (cvttss2si): truncation toward
 // zero; NaN and every value outside [-2^31, 2^31) give 0x80000000.  v_cvt_i32_f32 saturates

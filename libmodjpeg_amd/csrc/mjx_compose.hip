@@ -26,6 +26,19 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MJX_MIN_WAVES
+#define MJX_MIN_WAVES 0
+#endif
+// non-temporal streaming accesses: every byte of the batch is touched once per pass
+#ifndef MJX_NT
+#define MJX_NT 1
+#endif
+// keep M_SQRT2*(double)z_l[0] of all eight l in registers (16 VGPRs) instead of recomputing it
+// (one cvt + one f64 mul) in each of the 56 terms with k >= 1
+#ifndef MJX_HOIST_SZ0
+#define MJX_HOIST_SZ0 0
+#endif
+
 namespace mjx {
 
 // padded LDS image of an octet: row stride 12 dwords, block stride 104 dwords.
@@ -80,17 +93,19 @@ constexpr unsigned long long kOnes = 0x0101010101010101ull; // bit 8b of every b
 //   cd[u]   dequantised coefficients (after step D), x[u] = tile - cd, al[u] = alpha row
 // returns Y in row layout
 // ------------------------------------------------------------------------------------------
-MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow)[8], float *imgA, float *imgZ, int b, int r) {
-    // alpha image for the per-(k,l) weight broadcast
-    lds_put_row(imgA, b, r, al);
-
+template <class WRow>
+MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow)[8], WRow &&weight_row, float *imgZ, int b, int r) {
     // which terms does this octet need?  bit (8b + k) of m[l] <=> alpha_b[k][l] != 0
     unsigned long long m[8];
     static_for<8>([&](auto L) { m[L] = __ballot(al[L] != 0.0f); });
 
-    // H stage in row layout, z_l moved to column layout through LDS
+    // H stage in row layout, z_l moved to column layout through LDS.  z_l of a column l that no
+    // block of the octet uses stays unwritten: it is only ever read under `w != 0`, which implies
+    // the ballot bit that made this branch run.
     float        z[8][8];
+#if MJX_HOIST_SZ0
     double       sz0[8];
+#endif
     const double sx0 = kSqrt2 * (double)x[0];
     static_for<8>([&](auto L) {
         if(m[L] != 0ull) {
@@ -100,28 +115,35 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
             wave_sync();
             lds_get_col(imgZ, b, r, z[L]);
             wave_sync();
+#if MJX_HOIST_SZ0
             sz0[L] = kSqrt2 * (double)z[L][0];
-        }
-        else {
-            static_for<8>([&](auto V) { z[L][V] = 0.0f; });
-            sz0[L] = 0.0;
+#endif
         }
     });
 
-    // V stage in column layout: k outer, l inner, as reference compose.c:303-312
+    // V stage in column layout: k outer, l inner, as reference compose.c:303-312.  Rows of alpha
+    // that are zero in every block of the octet are skipped as a whole (scalar test); inside a row
+    // each term is guarded per block by `w != 0` (convolve.c:32) and the compiler's execz skip.
+    unsigned long long any = 0ull;
+    static_for<8>([&](auto L) { any |= m[L]; });
     float y[8];
     static_for<8>([&](auto V) { y[V] = 0.0f; });
     static_for<8>([&](auto K) {
-        unsigned long long any_k = 0ull;
-        static_for<8>([&](auto L) { any_k |= m[L]; });
-        if((any_k & (kOnes << K)) != 0ull) {
+        if((any & (kOnes << K)) != 0ull) {
             float wk[8];
-            lds_get_row(imgA, b, K, wk); // alpha_b[K][0..7], broadcast inside the block
+            weight_row(K, wk); // alpha_b[K][0..7], broadcast inside the block
             static_for<8>([&](auto L) {
-                if((m[L] & (kOnes << K)) != 0ull) {
-                    const float w = wk[L];
-                    if(w != 0.0f) { // convolve.c:32, per block
+                const float w = wk[L];
+                if(w != 0.0f) {
+                    if constexpr(K == 0 && L == 0) {
+                        vstage_first(y, z[L], w);
+                    }
+                    else {
+#if MJX_HOIST_SZ0
                         vstage<K>(y, z[L], sz0[L], w);
+#else
+                        vstage<K>(y, z[L], K == 0 ? 0.0 : kSqrt2 * (double)z[L][0], w);
+#endif
                     }
                 }
             });
@@ -135,7 +157,41 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
     wave_sync();
 }
 
-__global__ __launch_bounds__(256) void compose_kernel(const DevJob *__restrict__ jobs, const Chunk *__restrict__ chunks,
+#if MJX_MIN_WAVES > 0
+#define MJX_COMPOSE_BOUNDS __launch_bounds__(256, MJX_MIN_WAVES)
+#else
+#define MJX_COMPOSE_BOUNDS __launch_bounds__(256)
+#endif
+
+// 16-byte streaming accesses; MJX_NT marks them non-temporal (each byte is touched once per pass)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float        f32x4 __attribute__((ext_vector_type(4)));
+MJX_DEV uint4 stream_load(const uint4 *p) {
+#if MJX_NT
+    u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+MJX_DEV float4 stream_load(const float4 *p) {
+#if MJX_NT
+    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+MJX_DEV void stream_store(uint4 *p, uint4 v) {
+#if MJX_NT
+    u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(p));
+#else
+    *p = v;
+#endif
+}
+
+__global__ MJX_COMPOSE_BOUNDS void compose_kernel(const DevJob *__restrict__ jobs, const Chunk *__restrict__ chunks,
                                                       const uint16_t *__restrict__ qtab, const float *__restrict__ rqtab) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerGroup * 2 * kImageDwords];
 
@@ -175,11 +231,11 @@ __global__ __launch_bounds__(256) void compose_kernel(const DevJob *__restrict__
         const float *tptr = job.tile + (size_t)nc * 64 + r * 8;
         const float *aptr = job.alpha + (size_t)nc * 64 + r * 8;
 
-        const uint4  c4 = *reinterpret_cast<const uint4 *>(cptr);
-        const float4 t_lo = reinterpret_cast<const float4 *>(tptr)[0];
-        const float4 t_hi = reinterpret_cast<const float4 *>(tptr)[1];
-        const float4 a_lo = reinterpret_cast<const float4 *>(aptr)[0];
-        const float4 a_hi = reinterpret_cast<const float4 *>(aptr)[1];
+        const uint4  c4 = stream_load(reinterpret_cast<const uint4 *>(cptr));
+        const float4 t_lo = stream_load(reinterpret_cast<const float4 *>(tptr));
+        const float4 t_hi = stream_load(reinterpret_cast<const float4 *>(tptr) + 1);
+        const float4 a_lo = stream_load(reinterpret_cast<const float4 *>(aptr));
+        const float4 a_hi = stream_load(reinterpret_cast<const float4 *>(aptr) + 1);
 
         const int   c[8] = {lo16s(c4.x), hi16s(c4.x), lo16s(c4.y), hi16s(c4.y), lo16s(c4.z), hi16s(c4.z), lo16s(c4.w), hi16s(c4.w)};
         const float t[8] = {t_lo.x, t_lo.y, t_lo.z, t_lo.w, t_hi.x, t_hi.y, t_hi.z, t_hi.w};
@@ -192,7 +248,8 @@ __global__ __launch_bounds__(256) void compose_kernel(const DevJob *__restrict__
             x[U] = t[U] - (float)cd[U];        // compose.c:289-298
         });
 
-        octet_blend(x, al, y, imgA, imgZ, b, r); // compose.c:300-312
+        lds_put_row(imgA, b, r, al); // alpha image for the per-(k,l) weight broadcast
+        octet_blend(x, al, y, [&](int K, float (&wk)[8]) { lds_get_row(imgA, b, K, wk); }, imgZ, b, r); // compose.c:300-312
 
         int o[8];
         static_for<8>([&](auto U) {
@@ -201,7 +258,7 @@ __global__ __launch_bounds__(256) void compose_kernel(const DevJob *__restrict__
         });
 
         if(valid) {
-            *reinterpret_cast<uint4 *>(cptr) = make_uint4(pack16(o[0], o[1]), pack16(o[2], o[3]), pack16(o[4], o[5]), pack16(o[6], o[7]));
+            stream_store(reinterpret_cast<uint4 *>(cptr), make_uint4(pack16(o[0], o[1]), pack16(o[2], o[3]), pack16(o[4], o[5]), pack16(o[6], o[7])));
         }
     }
 }
@@ -210,6 +267,315 @@ int launch_compose(const DevJob *jobs, const Chunk *chunks, int nchunks, const u
     if(nchunks <= 0) return MJX_OK;
     hipLaunchKernelGGL(compose_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, jobs, chunks, qtab, rqtab);
     return check_hip(hipGetLastError(), "compose_kernel launch", MJX_ERR_LAUNCH);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// compose kernel, version 2: per-wave software pipeline with LDS-DMA prefetch.
+//
+// A wave owns a *run* of consecutive octets of one job.  While it computes octet i, the 5 KiB of
+// octet i+1 (1 KiB JCOEF, 2 KiB tile, 2 KiB alpha) are already in flight from HBM straight into
+// wave-private LDS buffers by `global_load_lds_dwordx4` (no VGPR destination, so the prefetch
+// costs no registers and occupancy stays at 3 waves per SIMD).
+//
+// The kernel is VALU-issue bound for every mask that is not trivially sparse (rocprofv3:
+// ~80 % of the SIMD issue slots at 10 non-zero weights per block), and on gfx950 every VALU
+// instruction costs about the same issue time whatever its type (scripts/ubench/valu_rate.hip),
+// so the per-octet instruction count is what is optimised here:
+//   * JCOEF stays packed (2 x int16 per register): dequantisation is v_pk_mul_lo_u16, the
+//     `short += (int)Y` is v_pk_add_u16, only the float conversions touch single elements
+//   * per-lane addresses advance incrementally from octet to octet (tile column + plane block
+//     index); the float division only runs once per run and for a ragged last octet
+//   * `(int)Y` uses the saturating hardware conversion; its only difference to the reference's
+//     x86 conversion (Y >= 2^31) is detected per wave and sent down a slow path
+//
+// LDS-DMA writes LDS "wave-uniform base + 16*lane", the global SOURCE address is per lane:
+//   JCOEF piece  dest chunk = lane -> (block lane>>3, row lane&7): natural order, the per-block
+//                source address carries the rectangle -> plane mapping
+//   tile pieces  natural order (2 x 1 KiB; the second piece is the first + 1024 bytes on both
+//                sides, so it reuses the address registers with an immediate offset)
+//   alpha pieces natural order except that the 8 rows of block b are rotated by 2b rows, so the
+//                broadcast read of weight row k (8 lanes of a block read the same 32 bytes, 4
+//                blocks per ds_read_b128 lane group) falls on 4 different bank groups
+// vmcnt bookkeeping (VMEM ops retire in issue order): per octet 5 DMA pieces are issued, later
+// one JCOEF store; at the top of iteration i >= 1 the youngest outstanding op is store(i-1), so
+// `s_waitcnt vmcnt(1)` is exactly "the pieces of octet i have landed".  To keep that count exact
+// the store is unconditional (lanes past the end of the job duplicate the job's last block: same
+// address, same bytes) and the kernel must not spill (a scratch access is a VMEM op): build()
+// checks ScratchSize == 0.
+// ------------------------------------------------------------------------------------------
+#ifndef MJX_RUN_OCTETS
+#define MJX_RUN_OCTETS 16
+#endif
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void       lvoid_t;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short          s16x2 __attribute__((ext_vector_type(2)));
+
+#if MJX_NT
+#define MJX_NT_SFX " nt"
+#else
+#define MJX_NT_SFX ""
+#endif
+
+// LDS byte address of a __shared__ pointer, as a wave-uniform scalar
+MJX_DEV unsigned lds_addr(const float *p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lvoid_t *)p);
+}
+
+// LDS-DMA pieces.  Inline asm on purpose: hipcc (ROCm 7.2) tracks `__builtin_amdgcn_global_load_lds`
+// as a pending LDS write and then puts `s_waitcnt vmcnt(0)` in front of every later ds_read it
+// cannot prove disjoint (all of the blend's transposes), which would serialise the prefetch with
+// the compute it hides behind.  The asm form is invisible to the compiler's counters; the kernel
+// counts the pieces itself (wait_vmcnt) and has no compiler-visible VMEM load while pieces are in
+// flight.  M0 carries the LDS base; it is compiler-reserved, so it is saved/restored inside the
+// statement.
+//
+// one piece from a per-lane 64-bit address
+MJX_DEV void dma16(const void *src, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MJX_NT_SFX "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+}
+// two pieces 1024 bytes apart (global and LDS side) from scalar base + per-lane 32-bit offset
+MJX_DEV void dma16x2(const void *sbase, unsigned voff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2" MJX_NT_SFX "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024" MJX_NT_SFX "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
+
+typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+MJX_DEV void global_store16(void *p, uint4 v) {
+    u32x4 t = {v.x, v.y, v.z, v.w};
+#if MJX_NT
+    __builtin_nontemporal_store(t, (g_u32x4 *)p);
+#else
+    *(g_u32x4 *)p = t;
+#endif
+}
+
+// tile (row, column) of linear tile index nc; float estimate + exact fix-up (nblocks < 2^24)
+MJX_DEV void tile_rc(const DevJob &job, int nc, int &trow, int &tcol) {
+    trow = (int)((float)nc * job.inv_cols);
+    tcol = nc - __mul24(trow, job.cols);
+    if(tcol < 0) { trow -= 1; tcol += job.cols; }
+    if(tcol >= job.cols) { trow += 1; tcol -= job.cols; }
+}
+
+// per-lane addressing state of a run
+struct OctetAddr {
+    int      tcol;  // tile column of this lane's JCOEF block (lane>>3)
+    unsigned pblk;  // its block index inside the plane
+    unsigned toff;  // byte offset of this lane's tile chunk inside job.tile (alpha: aoff)
+    unsigned aoff;
+};
+
+// generic (slow) form: any octet, lanes past the end of the job clamp to its last block.
+// Issues the 5 pieces and leaves `a` describing this octet.
+MJX_DEV int16_t *dma_octet_generic(const DevJob &job, int n0, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
+    const int last = job.nblocks - 1;
+    int       nb = n0 + (lane >> 3);
+    nb = nb < last ? nb : last;
+    int trow;
+    tile_rc(job, nb, trow, a.tcol);
+    // plane block index < 2^31 (rows, pitch < 2^24 each: 24-bit multiply), byte offset in 64 bit
+    a.pblk = __umul24((unsigned)(job.row0 + trow), (unsigned)job.bpr) + (unsigned)(job.col0 + a.tcol);
+    int16_t *cptr = job.coef + (size_t)a.pblk * 64 + (lane & 7) * 8;
+    dma16(cptr, dC);
+    // tile / alpha: piece j holds blocks 4j .. 4j+3, 16 chunks of 16 B per block; alpha row
+    // position rp of block b holds source row (rp - 2b) & 7 (the same for b and b+4)
+    const int bq = lane >> 4, ch = lane & 15;
+    const int k_rot = ((ch >> 1) - 2 * bq) & 7;
+    a.toff = (unsigned)(n0 + bq) * 256u + (unsigned)ch * 16u;
+    a.aoff = (unsigned)(n0 + bq) * 256u + (unsigned)(k_rot * 32 + (ch & 1) * 16);
+    if(n0 + 7 <= last) {
+        dma16x2(job.tile, a.toff, dT);
+        dma16x2(job.alpha, a.aoff, dA);
+    }
+    else {
+        int n_lo = n0 + bq, n_hi = n0 + 4 + bq;
+        n_lo = n_lo < last ? n_lo : last;
+        n_hi = n_hi < last ? n_hi : last;
+        const unsigned t_in = (unsigned)ch * 16u, a_in = (unsigned)(k_rot * 32 + (ch & 1) * 16);
+        dma16(reinterpret_cast<const char *>(job.tile) + (size_t)n_lo * 256 + t_in, dT);
+        dma16(reinterpret_cast<const char *>(job.tile) + (size_t)n_hi * 256 + t_in, dT + 1024);
+        dma16(reinterpret_cast<const char *>(job.alpha) + (size_t)n_lo * 256 + a_in, dA);
+        dma16(reinterpret_cast<const char *>(job.alpha) + (size_t)n_hi * 256 + a_in, dA + 1024);
+    }
+    return cptr;
+}
+
+// fast form: the octet after the one described by `a`, which must be a full octet (no clamping)
+MJX_DEV int16_t *dma_octet_next(const DevJob &job, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
+    a.tcol += kWaveBlocks;
+    a.pblk += kWaveBlocks;
+    const unsigned row_skip = (unsigned)(job.bpr - job.cols);
+    while(a.tcol >= job.cols) { // at most once when the rectangle is >= 8 blocks wide
+        a.tcol -= job.cols;
+        a.pblk += row_skip;
+    }
+    int16_t *cptr = job.coef + (size_t)a.pblk * 64 + (lane & 7) * 8;
+    dma16(cptr, dC);
+    a.toff += kWaveBlocks * 256u;
+    a.aoff += kWaveBlocks * 256u;
+    dma16x2(job.tile, a.toff, dT);
+    dma16x2(job.alpha, a.aoff, dA);
+    return cptr;
+}
+
+template <int N> MJX_DEV void wait_vmcnt() {
+    if constexpr(N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+}
+
+MJX_DEV float s16_lo_to_f32(unsigned p) { return (float)(int)(short)(p & 0xFFFFu); }
+MJX_DEV float s16_hi_to_f32(unsigned p) { return (float)(((int)p) >> 16); }
+MJX_DEV unsigned pk_mul_lo_u16(unsigned a, unsigned b) {
+    u16x2 r = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(unsigned, r);
+}
+MJX_DEV unsigned pk_add_u16(unsigned a, unsigned b) {
+    u16x2 r = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(unsigned, r);
+}
+// saturating float -> int32 conversion of the hardware (NaN -> 0), no C++ UB attached
+MJX_DEV int cvt_i32_sat(float f) {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+
+// one octet: operands are in LDS (pC, pT, pA); prefetch of the next octet goes to (pC, pT, pAn)
+// NEXT: 0 = no next octet, 1 = next octet is full (fast addressing), 2 = runtime choice
+template <bool FIRST>
+MJX_DEV int16_t *octet_step(const DevJob &job, int n_next, bool has_next, int16_t *cptr, OctetAddr &addr, int lane, int b, int r, const float *qrow,
+                            float *pC, float *pT, float *pA, float *pAn, float *imgZ) {
+    wait_vmcnt<FIRST ? 0 : 1>();
+
+    const uint4  c4 = *reinterpret_cast<const uint4 *>(pC + lane * 4);
+    const float4 t_lo = *reinterpret_cast<const float4 *>(pT + lane * 8);
+    const float4 t_hi = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4);
+    const float *arow = pA + b * 64 + ((r + 2 * b) & 7) * 8;
+    const float4 a_lo = *reinterpret_cast<const float4 *>(arow);
+    const float4 a_hi = *reinterpret_cast<const float4 *>(arow + 4);
+    const uint4  q4 = *reinterpret_cast<const uint4 *>(qrow); // this lane's quant row, 8 x u16
+    // the JCOEF and tile buffers are about to be overwritten by the next octet's DMA
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    int16_t *cnext = cptr;
+    if(has_next) {
+        if(n_next + kWaveBlocks <= job.nblocks) cnext = dma_octet_next(job, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(pAn));
+        else cnext = dma_octet_generic(job, n_next, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(pAn));
+    }
+
+    // D: (short)(coef * q), two coefficients per register (compose.c:277-286)
+    const unsigned cd[4] = {pk_mul_lo_u16(c4.x, q4.x), pk_mul_lo_u16(c4.y, q4.y), pk_mul_lo_u16(c4.z, q4.z), pk_mul_lo_u16(c4.w, q4.w)};
+    const float    t[8] = {t_lo.x, t_lo.y, t_lo.z, t_lo.w, t_hi.x, t_hi.y, t_hi.z, t_hi.w};
+    const float    al[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
+    float          x[8], y[8];
+    static_for<4>([&](auto P) { // X = tile - (float)coef (compose.c:289-298)
+        x[2 * P] = t[2 * P] - s16_lo_to_f32(cd[P]);
+        x[2 * P + 1] = t[2 * P + 1] - s16_hi_to_f32(cd[P]);
+    });
+
+    octet_blend(x, al, y,
+                [&](int K, float (&wk)[8]) {
+                    const float *wrow = pA + b * 64 + ((K + 2 * b) & 7) * 8;
+                    const float4 lo = *reinterpret_cast<const float4 *>(wrow), hi = *reinterpret_cast<const float4 *>(wrow + 4);
+                    wk[0] = lo.x; wk[1] = lo.y; wk[2] = lo.z; wk[3] = lo.w; wk[4] = hi.x; wk[5] = hi.y; wk[6] = hi.z; wk[7] = hi.w;
+                },
+                imgZ, b, r); // compose.c:300-312
+
+    // A: coef = (short)(coef + (int)Y) (compose.c:315-324).  v_cvt_i32_f32 differs from the x86
+    // conversion of the reference only for Y >= 2^31 (0x7fffffff instead of 0x80000000; NaN and
+    // Y <= -2^31 agree in the low 16 bits), which the wave tests once with a max-reduction.
+    int         ti[8];
+    const float ymax = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
+    if(__builtin_expect(__any(!(ymax < 2147483648.0f)), 0)) {
+        static_for<8>([&](auto U) { ti[U] = f2i_x86(y[U]); });
+    }
+    else {
+        static_for<8>([&](auto U) { ti[U] = cvt_i32_sat(y[U]); });
+    }
+    const float4 rq_lo = *reinterpret_cast<const float4 *>(qrow + 4), rq_hi = *reinterpret_cast<const float4 *>(qrow + 8);
+    const float  rq[8] = {rq_lo.x, rq_lo.y, rq_lo.z, rq_lo.w, rq_hi.x, rq_hi.y, rq_hi.z, rq_hi.w};
+    unsigned     o[4];
+    static_for<4>([&](auto P) {
+        const unsigned s = pk_add_u16(cd[P], pack16(ti[2 * P], ti[2 * P + 1]));
+        // Q: (short)(coef / q) by the exact reciprocal product (compose.c:327-336)
+        const int q_lo = (int)(s16_lo_to_f32(s) * rq[2 * P]);
+        const int q_hi = (int)(s16_hi_to_f32(s) * rq[2 * P + 1]);
+        o[P] = pack16(q_lo, q_hi);
+    });
+    global_store16(cptr, make_uint4(o[0], o[1], o[2], o[3]));
+    return cnext;
+}
+
+#ifndef MJX_V2_MIN_WAVES
+#define MJX_V2_MIN_WAVES 3
+#endif
+__global__ __launch_bounds__(256, MJX_V2_MIN_WAVES) void compose_kernel_v2(const DevJob *__restrict__ jobs, const Run *__restrict__ runs, int nruns,
+                                                                          const uint16_t *__restrict__ qtab, const float *__restrict__ rqtab) {
+    __shared__ __attribute__((aligned(16))) float sC[kWavesPerGroup][256];
+    __shared__ __attribute__((aligned(16))) float sT[kWavesPerGroup][512];
+    __shared__ __attribute__((aligned(16))) float sA0[kWavesPerGroup][512];
+    __shared__ __attribute__((aligned(16))) float sA1[kWavesPerGroup][512];
+    __shared__ __attribute__((aligned(16))) float sZ[kWavesPerGroup][kImageDwords];
+    __shared__ __attribute__((aligned(16))) float sQ[kWavesPerGroup][8 * 12];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = lane >> 3, r = lane & 7;
+    const int ridx = blockIdx.x * kWavesPerGroup + wave;
+    if(ridx >= nruns) return; // wave-uniform; the kernel uses no workgroup barrier
+
+    const Run    run = runs[ridx];
+    const int    jidx = __builtin_amdgcn_readfirstlane(run.job);
+    const int    first = __builtin_amdgcn_readfirstlane(run.first);
+    const int    noct = __builtin_amdgcn_readfirstlane(run.noctets);
+    const DevJob job = jobs[jidx];
+
+    // Row r of the job's quant table (8 x u16) and of its reciprocals (8 x f32), staged in LDS as
+    // 12 dwords per row.  These are the only compiler-visible VMEM loads of the kernel; writing
+    // them to LDS makes the compiler retire them here, before the first DMA piece is issued.
+    float *qrow = sQ[wave] + r * 12;
+    {
+        const uint4  q4 = *reinterpret_cast<const uint4 *>(qtab + job.qidx * 64 + r * 8);
+        const float4 rq_lo = *reinterpret_cast<const float4 *>(rqtab + job.qidx * 64 + r * 8);
+        const float4 rq_hi = *reinterpret_cast<const float4 *>(rqtab + job.qidx * 64 + r * 8 + 4);
+        if(b == 0) {
+            *reinterpret_cast<uint4 *>(qrow) = q4;
+            *reinterpret_cast<float4 *>(qrow + 4) = rq_lo;
+            *reinterpret_cast<float4 *>(qrow + 8) = rq_hi;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+
+    float *pC = sC[wave], *pT = sT[wave], *pA0 = sA0[wave], *pA1 = sA1[wave], *imgZ = sZ[wave];
+
+    OctetAddr addr;
+    int16_t  *cptr = dma_octet_generic(job, first, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(pA0));
+    cptr = octet_step<true>(job, first + kWaveBlocks, noct > 1, cptr, addr, lane, b, r, qrow, pC, pT, pA0, pA1, imgZ);
+    // steady state, unrolled by two so that the alpha double buffer is addressed statically
+    int i = 1;
+#pragma unroll 1
+    for(; i + 1 < noct; i += 2) {
+        cptr = octet_step<false>(job, first + (i + 1) * kWaveBlocks, true, cptr, addr, lane, b, r, qrow, pC, pT, pA1, pA0, imgZ);
+        cptr = octet_step<false>(job, first + (i + 2) * kWaveBlocks, i + 2 < noct, cptr, addr, lane, b, r, qrow, pC, pT, pA0, pA1, imgZ);
+    }
+    if(i < noct) {
+        (void)octet_step<false>(job, 0, false, cptr, addr, lane, b, r, qrow, pC, pT, pA1, pA0, imgZ);
+    }
+}
+
+int launch_compose_v2(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, hipStream_t s) {
+    if(nruns <= 0) return MJX_OK;
+    const int groups = (nruns + kWavesPerGroup - 1) / kWavesPerGroup;
+    hipLaunchKernelGGL(compose_kernel_v2, dim3((unsigned)groups), dim3(256), 0, s, jobs, runs, nruns, qtab, rqtab);
+    return check_hip(hipGetLastError(), "compose_kernel_v2 launch", MJX_ERR_LAUNCH);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -280,3 +646,5 @@ int launch_convolve(const float *x, float *y, float w, int k, int l, int nblocks
 }
 
 } // namespace mjx
+
+int mjx::run_octets() { return MJX_RUN_OCTETS; }

@@ -27,6 +27,14 @@ struct Chunk {
     int32_t first;
 };
 
+// one wave's share in the pipelined kernel: up to MJX_RUN_OCTETS consecutive octets of one job
+struct Run {
+    int32_t job;
+    int32_t first;   // first tile block
+    int32_t noctets; // >= 1
+    int32_t pad;
+};
+
 constexpr int kWaveBlocks = 8;     // one wavefront = 8 blocks x 8 lanes
 constexpr int kWavesPerGroup = 4;  // 256 threads
 constexpr int kOctetsPerWave = 4;
@@ -56,6 +64,8 @@ float rq_of(unsigned q);
 
 // launchers implemented in the kernel translation units
 int launch_compose(const DevJob *jobs, const Chunk *chunks, int nchunks, const uint16_t *qtab, const float *rqtab, hipStream_t s);
+int launch_compose_v2(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, hipStream_t s);
+int run_octets();
 int launch_convolve(const float *x, float *y, float w, int k, int l, int nblocks, hipStream_t s);
 int launch_effect_dc(const DevDcJob *jobs, int njobs, int64_t max_blocks_per_job, hipStream_t s);
 int launch_effect_zero(int16_t *coef, int bpr, int rows, int cols, int keep_dc, hipStream_t s);

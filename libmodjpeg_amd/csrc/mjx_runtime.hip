@@ -53,6 +53,8 @@ using namespace mjx;
 struct mjx_compose_plan {
     DevJob   *d_jobs = nullptr;
     Chunk    *d_chunks = nullptr;
+    Run      *d_runs = nullptr;
+    int       nruns = 0;
     uint16_t *d_q = nullptr;
     float    *d_rq = nullptr;
     int       nchunks = 0;
@@ -134,6 +136,7 @@ void mjx_compose_plan_destroy(mjx_compose_plan_t *p) {
     if(p == nullptr) return;
     if(p->d_jobs) (void)hipFree(p->d_jobs);
     if(p->d_chunks) (void)hipFree(p->d_chunks);
+    if(p->d_runs) (void)hipFree(p->d_runs);
     if(p->d_q) (void)hipFree(p->d_q);
     if(p->d_rq) (void)hipFree(p->d_rq);
     delete p;
@@ -153,6 +156,8 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
 
     std::vector<DevJob> dj;
     std::vector<Chunk>  ch;
+    std::vector<Run>    runs;
+    const int           run_blocks = run_octets() * kWaveBlocks;
     int64_t             blocks = 0;
     // rectangles of >= 2^24 blocks are split by rows so that the kernel's float row/column split
     // of the linear tile index stays exact
@@ -187,6 +192,11 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
             const int jid = (int)dj.size();
             dj.push_back(d);
             for(int f = 0; f < d.nblocks; f += kChunkBlocks) ch.push_back(Chunk{jid, f});
+            for(int f = 0; f < d.nblocks; f += run_blocks) {
+                const int left = d.nblocks - f;
+                const int nb = left < run_blocks ? left : run_blocks;
+                runs.push_back(Run{jid, f, (nb + kWaveBlocks - 1) / kWaveBlocks, 0});
+            }
             blocks += d.nblocks;
         }
     }
@@ -195,6 +205,7 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
     if(p == nullptr) return MJX_ERR_MEMORY;
     p->njobs = (int)dj.size();
     p->nchunks = (int)ch.size();
+    p->nruns = (int)runs.size();
     p->blocks = blocks;
 
     std::vector<float> rq((size_t)nq * 64);
@@ -209,6 +220,8 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
         if((err = check_hip(hipMalloc((void **)&p->d_rq, (size_t)nq * 64 * sizeof(float)), "hipMalloc(rq)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMemcpy(p->d_jobs, dj.data(), dj.size() * sizeof(DevJob), hipMemcpyHostToDevice), "hipMemcpy(jobs)", MJX_ERR_LAUNCH))) break;
         if((err = check_hip(hipMemcpy(p->d_chunks, ch.data(), ch.size() * sizeof(Chunk), hipMemcpyHostToDevice), "hipMemcpy(chunks)", MJX_ERR_LAUNCH))) break;
+        if((err = check_hip(hipMalloc((void **)&p->d_runs, runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
+        if((err = check_hip(hipMemcpy(p->d_runs, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
         if((err = check_hip(hipMemcpy(p->d_q, qtables, (size_t)nq * 64 * sizeof(uint16_t), hipMemcpyHostToDevice), "hipMemcpy(q)", MJX_ERR_LAUNCH))) break;
         if((err = check_hip(hipMemcpy(p->d_rq, rq.data(), (size_t)nq * 64 * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(rq)", MJX_ERR_LAUNCH))) break;
     } while(0);
@@ -225,7 +238,11 @@ int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan) { return plan ? 
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
     if(plan->nchunks == 0) return MJX_OK;
+#if MJX_KERNEL_V1
     return launch_compose(plan->d_jobs, plan->d_chunks, plan->nchunks, plan->d_q, plan->d_rq, (hipStream_t)stream);
+#else
+    return launch_compose_v2(plan->d_jobs, plan->d_runs, plan->nruns, plan->d_q, plan->d_rq, (hipStream_t)stream);
+#endif
 }
 
 int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, int row0, int col0, int rows, int cols, const uint16_t *q,
