@@ -14,10 +14,11 @@
 // z_l = H_l(X) is computed once per l (not once per (k,l) as the reference does), moved from row
 // to column layout through a wave-private, bank-conflict-free padded LDS image (DS operations of
 // one wave execute in order, so no barrier is needed), and all eight z_l stay in registers.
-// Zero weights are skipped exactly like convolve.c:32: wave-uniform branches from ballots over
-// the alpha registers ("no block of this octet needs term (k,l)") plus a per-lane test.
+// Zero weights are skipped exactly like convolve.c:32: ballots over the alpha registers give
+// wave-uniform "no block of this octet uses column l / row k" tests, and each remaining term is
+// guarded per block by `w != 0` (an exec-masked branch that is skipped when no lane needs it).
 // No MFMA: there is no dense contraction here, the kernel is an HBM stream (768 B per block)
-// with a VALU side that depends on nnz(alpha).
+// with a VALU side that grows with nnz(alpha); see DESIGN.md for the measured balance.
 #include "mjx_block_math.hpp"
 #include "mjx_internal.hpp"
 
@@ -26,17 +27,9 @@
 
 #pragma clang fp contract(off)
 
-#ifndef MJX_MIN_WAVES
-#define MJX_MIN_WAVES 0
-#endif
 // non-temporal streaming accesses: every byte of the batch is touched once per pass
 #ifndef MJX_NT
 #define MJX_NT 1
-#endif
-// keep M_SQRT2*(double)z_l[0] of all eight l in registers (16 VGPRs) instead of recomputing it
-// (one cvt + one f64 mul) in each of the 56 terms with k >= 1
-#ifndef MJX_HOIST_SZ0
-#define MJX_HOIST_SZ0 0
 #endif
 
 namespace mjx {
@@ -80,10 +73,6 @@ MJX_DEV void lds_put_col(float *img, int b, int r, const float (&a)[8]) {
     static_for<8>([&](auto V) { p[V * kRowStride] = a[V]; });
 }
 
-MJX_DEV int lo16s(unsigned w) { return (int)(short)(w & 0xFFFFu); }
-MJX_DEV int hi16s(unsigned w) { return ((int)w) >> 16; }
-MJX_DEV int lo16u(unsigned w) { return (int)(w & 0xFFFFu); }
-MJX_DEV int hi16u(unsigned w) { return (int)(w >> 16); }
 MJX_DEV unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
 
 constexpr unsigned long long kOnes = 0x0101010101010101ull; // bit 8b of every block b
@@ -99,26 +88,21 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
     unsigned long long m[8];
     static_for<8>([&](auto L) { m[L] = __ballot(al[L] != 0.0f); });
 
-    // H stage in row layout, z_l moved to column layout through LDS.  z_l of a column l that no
-    // block of the octet uses stays unwritten: it is only ever read under `w != 0`, which implies
-    // the ballot bit that made this branch run.
+    // H stage in row layout, z_l moved to column layout through LDS.  z_l is computed only for
+    // columns l that some block of the octet uses, but read back unconditionally (stale LDS for an
+    // unused l is never consumed: its terms all have w == 0): the loads are then straight-line
+    // code, z[l] needs no merge copies (22 VGPRs less) and the round trips overlap.
     float        z[8][8];
-#if MJX_HOIST_SZ0
-    double       sz0[8];
-#endif
     const double sx0 = kSqrt2 * (double)x[0];
     static_for<8>([&](auto L) {
         if(m[L] != 0ull) {
             float zr[8];
             hstage<L>(x, sx0, zr);
             lds_put_row(imgZ, b, r, zr);
-            wave_sync();
-            lds_get_col(imgZ, b, r, z[L]);
-            wave_sync();
-#if MJX_HOIST_SZ0
-            sz0[L] = kSqrt2 * (double)z[L][0];
-#endif
         }
+        wave_sync();
+        lds_get_col(imgZ, b, r, z[L]);
+        wave_sync();
     });
 
     // V stage in column layout: k outer, l inner, as reference compose.c:303-312.  Rows of alpha
@@ -139,11 +123,9 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
                         vstage_first(y, z[L], w);
                     }
                     else {
-#if MJX_HOIST_SZ0
-                        vstage<K>(y, z[L], sz0[L], w);
-#else
+                        // M_SQRT2*(double)z_l[0] is recomputed per term (cvt + mul) rather than kept
+                        // for all eight l: 16 VGPRs would cost the third wave per SIMD
                         vstage<K>(y, z[L], K == 0 ? 0.0 : kSqrt2 * (double)z[L][0], w);
-#endif
                     }
                 }
             });
@@ -157,121 +139,10 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
     wave_sync();
 }
 
-#if MJX_MIN_WAVES > 0
-#define MJX_COMPOSE_BOUNDS __launch_bounds__(256, MJX_MIN_WAVES)
-#else
-#define MJX_COMPOSE_BOUNDS __launch_bounds__(256)
-#endif
-
-// 16-byte streaming accesses; MJX_NT marks them non-temporal (each byte is touched once per pass)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float        f32x4 __attribute__((ext_vector_type(4)));
-MJX_DEV uint4 stream_load(const uint4 *p) {
-#if MJX_NT
-    u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-MJX_DEV float4 stream_load(const float4 *p) {
-#if MJX_NT
-    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-MJX_DEV void stream_store(uint4 *p, uint4 v) {
-#if MJX_NT
-    u32x4 t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(p));
-#else
-    *p = v;
-#endif
-}
-
-__global__ MJX_COMPOSE_BOUNDS void compose_kernel(const DevJob *__restrict__ jobs, const Chunk *__restrict__ chunks,
-                                                      const uint16_t *__restrict__ qtab, const float *__restrict__ rqtab) {
-    __shared__ __attribute__((aligned(16))) float lds[kWavesPerGroup * 2 * kImageDwords];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = lane >> 3, r = lane & 7;
-    float    *imgA = lds + wave * 2 * kImageDwords;
-    float    *imgZ = imgA + kImageDwords;
-
-    const Chunk  ch = chunks[blockIdx.x];
-    const int    jidx = __builtin_amdgcn_readfirstlane(ch.job);
-    const int    first = __builtin_amdgcn_readfirstlane(ch.first);
-    const DevJob job = jobs[jidx];
-
-    // this lane's row of the quant table and of its reciprocals
-    const uint4  q4 = *reinterpret_cast<const uint4 *>(qtab + job.qidx * 64 + r * 8);
-    const float4 rq_lo = *reinterpret_cast<const float4 *>(rqtab + job.qidx * 64 + r * 8);
-    const float4 rq_hi = *reinterpret_cast<const float4 *>(rqtab + job.qidx * 64 + r * 8 + 4);
-    const int    q[8] = {lo16u(q4.x), hi16u(q4.x), lo16u(q4.y), hi16u(q4.y), lo16u(q4.z), hi16u(q4.z), lo16u(q4.w), hi16u(q4.w)};
-    const float  rq[8] = {rq_lo.x, rq_lo.y, rq_lo.z, rq_lo.w, rq_hi.x, rq_hi.y, rq_hi.z, rq_hi.w};
-
-#pragma unroll 1
-    for(int it = 0; it < kOctetsPerWave; ++it) {
-        const int n0 = first + (it * kWavesPerGroup + wave) * kWaveBlocks;
-        if(n0 >= job.nblocks) break; // wave-uniform
-        const int  n = n0 + b;
-        const bool valid = n < job.nblocks;
-        const int  nc = valid ? n : job.nblocks - 1;
-
-        // tile (row, column) of the linear index; float estimate + exact fix-up (nblocks < 2^24)
-        int trow = (int)((float)nc * job.inv_cols);
-        int tcol = nc - trow * job.cols;
-        if(tcol < 0) { trow -= 1; tcol += job.cols; }
-        if(tcol >= job.cols) { trow += 1; tcol -= job.cols; }
-
-        int16_t     *cptr = job.coef + ((size_t)(job.row0 + trow) * (size_t)job.bpr + (size_t)(job.col0 + tcol)) * 64 + r * 8;
-        const float *tptr = job.tile + (size_t)nc * 64 + r * 8;
-        const float *aptr = job.alpha + (size_t)nc * 64 + r * 8;
-
-        const uint4  c4 = stream_load(reinterpret_cast<const uint4 *>(cptr));
-        const float4 t_lo = stream_load(reinterpret_cast<const float4 *>(tptr));
-        const float4 t_hi = stream_load(reinterpret_cast<const float4 *>(tptr) + 1);
-        const float4 a_lo = stream_load(reinterpret_cast<const float4 *>(aptr));
-        const float4 a_hi = stream_load(reinterpret_cast<const float4 *>(aptr) + 1);
-
-        const int   c[8] = {lo16s(c4.x), hi16s(c4.x), lo16s(c4.y), hi16s(c4.y), lo16s(c4.z), hi16s(c4.z), lo16s(c4.w), hi16s(c4.w)};
-        const float t[8] = {t_lo.x, t_lo.y, t_lo.z, t_lo.w, t_hi.x, t_hi.y, t_hi.z, t_hi.w};
-        const float al[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
-
-        int   cd[8];
-        float x[8], y[8];
-        static_for<8>([&](auto U) {
-            cd[U] = dequant(c[U], q[U]);       // compose.c:277-286
-            x[U] = t[U] - (float)cd[U];        // compose.c:289-298
-        });
-
-        lds_put_row(imgA, b, r, al); // alpha image for the per-(k,l) weight broadcast
-        octet_blend(x, al, y, [&](int K, float (&wk)[8]) { lds_get_row(imgA, b, K, wk); }, imgZ, b, r); // compose.c:300-312
-
-        int o[8];
-        static_for<8>([&](auto U) {
-            const int s = add_trunc(cd[U], y[U]); // compose.c:315-324
-            o[U] = requant(s, rq[U]);             // compose.c:327-336
-        });
-
-        if(valid) {
-            stream_store(reinterpret_cast<uint4 *>(cptr), make_uint4(pack16(o[0], o[1]), pack16(o[2], o[3]), pack16(o[4], o[5]), pack16(o[6], o[7])));
-        }
-    }
-}
-
-int launch_compose(const DevJob *jobs, const Chunk *chunks, int nchunks, const uint16_t *qtab, const float *rqtab, hipStream_t s) {
-    if(nchunks <= 0) return MJX_OK;
-    hipLaunchKernelGGL(compose_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, jobs, chunks, qtab, rqtab);
-    return check_hip(hipGetLastError(), "compose_kernel launch", MJX_ERR_LAUNCH);
-}
-
 
 // ------------------------------------------------------------------------------------------
-// compose kernel, version 2: per-wave software pipeline with LDS-DMA prefetch.
+// compose kernel: per-wave software pipeline with LDS-DMA prefetch.
 //
 // A wave owns a *run* of consecutive octets of one job.  While it computes octet i, the 5 KiB of
 // octet i+1 (1 KiB JCOEF, 2 KiB tile, 2 KiB alpha) are already in flight from HBM straight into
@@ -514,10 +385,10 @@ MJX_DEV int16_t *octet_step(const DevJob &job, int n_next, bool has_next, int16_
     return cnext;
 }
 
-#ifndef MJX_V2_MIN_WAVES
-#define MJX_V2_MIN_WAVES 3
+#ifndef MJX_COMPOSE_MIN_WAVES
+#define MJX_COMPOSE_MIN_WAVES 3
 #endif
-__global__ __launch_bounds__(256, MJX_V2_MIN_WAVES) void compose_kernel_v2(const DevJob *__restrict__ jobs, const Run *__restrict__ runs, int nruns,
+__global__ __launch_bounds__(256, MJX_COMPOSE_MIN_WAVES) void compose_kernel(const DevJob *__restrict__ jobs, const Run *__restrict__ runs, int nruns,
                                                                           const uint16_t *__restrict__ qtab, const float *__restrict__ rqtab) {
     __shared__ __attribute__((aligned(16))) float sC[kWavesPerGroup][256];
     __shared__ __attribute__((aligned(16))) float sT[kWavesPerGroup][512];
@@ -571,11 +442,11 @@ __global__ __launch_bounds__(256, MJX_V2_MIN_WAVES) void compose_kernel_v2(const
     }
 }
 
-int launch_compose_v2(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, hipStream_t s) {
+int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
     const int groups = (nruns + kWavesPerGroup - 1) / kWavesPerGroup;
-    hipLaunchKernelGGL(compose_kernel_v2, dim3((unsigned)groups), dim3(256), 0, s, jobs, runs, nruns, qtab, rqtab);
-    return check_hip(hipGetLastError(), "compose_kernel_v2 launch", MJX_ERR_LAUNCH);
+    hipLaunchKernelGGL(compose_kernel, dim3((unsigned)groups), dim3(256), 0, s, jobs, runs, nruns, qtab, rqtab);
+    return check_hip(hipGetLastError(), "compose_kernel launch", MJX_ERR_LAUNCH);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -21,13 +21,7 @@ struct DevJob {
 };
 static_assert(sizeof(DevJob) == 56, "DevJob layout");
 
-// one workgroup's share: up to kChunkBlocks consecutive tile blocks of one job
-struct Chunk {
-    int32_t job;
-    int32_t first;
-};
-
-// one wave's share in the pipelined kernel: up to MJX_RUN_OCTETS consecutive octets of one job
+// one wave's share of a launch: up to MJX_RUN_OCTETS consecutive octets (8 blocks each) of one job
 struct Run {
     int32_t job;
     int32_t first;   // first tile block
@@ -37,8 +31,6 @@ struct Run {
 
 constexpr int kWaveBlocks = 8;     // one wavefront = 8 blocks x 8 lanes
 constexpr int kWavesPerGroup = 4;  // 256 threads
-constexpr int kOctetsPerWave = 4;
-constexpr int kChunkBlocks = kWaveBlocks * kWavesPerGroup * kOctetsPerWave; // 128
 
 struct DevDcJob {
     int16_t *coef;
@@ -63,8 +55,7 @@ float rq_of(unsigned q);
     } while(0)
 
 // launchers implemented in the kernel translation units
-int launch_compose(const DevJob *jobs, const Chunk *chunks, int nchunks, const uint16_t *qtab, const float *rqtab, hipStream_t s);
-int launch_compose_v2(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, hipStream_t s);
+int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, hipStream_t s);
 int run_octets();
 int launch_convolve(const float *x, float *y, float w, int k, int l, int nblocks, hipStream_t s);
 int launch_effect_dc(const DevDcJob *jobs, int njobs, int64_t max_blocks_per_job, hipStream_t s);

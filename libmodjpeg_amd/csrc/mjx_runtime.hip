@@ -1,5 +1,5 @@
 // mjx_runtime.hip — host side of the C ABI declared in include/mjx.h: device plumbing, launch
-// plans (device-resident job descriptors and workgroup chunk tables) and the per-image host-buffer
+// plans (device-resident job descriptors and per-wave run tables) and the per-image host-buffer
 // convenience call used by the libmodjpeg.h shim.  No CPU compute path exists here by design:
 // without a HIP device every entry point fails with MJX_ERR_NO_DEVICE.
 #include "mjx_internal.hpp"
@@ -52,12 +52,10 @@ using namespace mjx;
 
 struct mjx_compose_plan {
     DevJob   *d_jobs = nullptr;
-    Chunk    *d_chunks = nullptr;
     Run      *d_runs = nullptr;
     int       nruns = 0;
     uint16_t *d_q = nullptr;
     float    *d_rq = nullptr;
-    int       nchunks = 0;
     int       njobs = 0;
     int64_t   blocks = 0;
 };
@@ -135,7 +133,6 @@ int mjx_stream_synchronize(mjx_stream_t s) {
 void mjx_compose_plan_destroy(mjx_compose_plan_t *p) {
     if(p == nullptr) return;
     if(p->d_jobs) (void)hipFree(p->d_jobs);
-    if(p->d_chunks) (void)hipFree(p->d_chunks);
     if(p->d_runs) (void)hipFree(p->d_runs);
     if(p->d_q) (void)hipFree(p->d_q);
     if(p->d_rq) (void)hipFree(p->d_rq);
@@ -155,7 +152,6 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
     }
 
     std::vector<DevJob> dj;
-    std::vector<Chunk>  ch;
     std::vector<Run>    runs;
     const int           run_blocks = run_octets() * kWaveBlocks;
     int64_t             blocks = 0;
@@ -191,7 +187,6 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
             d.pad = 0;
             const int jid = (int)dj.size();
             dj.push_back(d);
-            for(int f = 0; f < d.nblocks; f += kChunkBlocks) ch.push_back(Chunk{jid, f});
             for(int f = 0; f < d.nblocks; f += run_blocks) {
                 const int left = d.nblocks - f;
                 const int nb = left < run_blocks ? left : run_blocks;
@@ -204,7 +199,6 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
     mjx_compose_plan *p = new(std::nothrow) mjx_compose_plan;
     if(p == nullptr) return MJX_ERR_MEMORY;
     p->njobs = (int)dj.size();
-    p->nchunks = (int)ch.size();
     p->nruns = (int)runs.size();
     p->blocks = blocks;
 
@@ -215,11 +209,9 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
     do {
         if(p->njobs == 0) break;
         if((err = check_hip(hipMalloc((void **)&p->d_jobs, dj.size() * sizeof(DevJob)), "hipMalloc(jobs)", MJX_ERR_MEMORY))) break;
-        if((err = check_hip(hipMalloc((void **)&p->d_chunks, ch.size() * sizeof(Chunk)), "hipMalloc(chunks)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMalloc((void **)&p->d_q, (size_t)nq * 64 * sizeof(uint16_t)), "hipMalloc(q)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMalloc((void **)&p->d_rq, (size_t)nq * 64 * sizeof(float)), "hipMalloc(rq)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMemcpy(p->d_jobs, dj.data(), dj.size() * sizeof(DevJob), hipMemcpyHostToDevice), "hipMemcpy(jobs)", MJX_ERR_LAUNCH))) break;
-        if((err = check_hip(hipMemcpy(p->d_chunks, ch.data(), ch.size() * sizeof(Chunk), hipMemcpyHostToDevice), "hipMemcpy(chunks)", MJX_ERR_LAUNCH))) break;
         if((err = check_hip(hipMalloc((void **)&p->d_runs, runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMemcpy(p->d_runs, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
         if((err = check_hip(hipMemcpy(p->d_q, qtables, (size_t)nq * 64 * sizeof(uint16_t), hipMemcpyHostToDevice), "hipMemcpy(q)", MJX_ERR_LAUNCH))) break;
@@ -237,12 +229,8 @@ int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan) { return plan ? 
 
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
-    if(plan->nchunks == 0) return MJX_OK;
-#if MJX_KERNEL_V1
-    return launch_compose(plan->d_jobs, plan->d_chunks, plan->nchunks, plan->d_q, plan->d_rq, (hipStream_t)stream);
-#else
-    return launch_compose_v2(plan->d_jobs, plan->d_runs, plan->nruns, plan->d_q, plan->d_rq, (hipStream_t)stream);
-#endif
+    if(plan->nruns == 0) return MJX_OK;
+    return launch_compose(plan->d_jobs, plan->d_runs, plan->nruns, plan->d_q, plan->d_rq, (hipStream_t)stream);
 }
 
 int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, int row0, int col0, int rows, int cols, const uint16_t *q,
