@@ -95,8 +95,22 @@ int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan);
  * safe inside hipGraph capture). */
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream);
 
-/* Convenience for per-image callers (the libmodjpeg.h shim): HOST buffers in, composed HOST
- * plane out.  plane = blocks_per_row*plane_rows blocks; only the rectangle's rows travel. */
+/* Per-image callers (the libmodjpeg.h shim) hold everything in HOST memory.  One call = one
+ * staging allocation, asynchronous H2D of every rectangle's plane rows and tiles, ONE launch over
+ * all rectangles, D2H of the rows.  `rows_ptr` points at the first plane row the rectangle touches
+ * (rows * blocks_per_row blocks, updated in place): only those rows travel over PCIe. */
+typedef struct mjx_host_rect {
+    int16_t        *rows_ptr;       /* HOST, in/out */
+    const float    *tile;           /* HOST, rows*cols blocks */
+    const float    *alpha;          /* HOST, rows*cols blocks */
+    const uint16_t *q;              /* HOST[64] */
+    int32_t         blocks_per_row; /* plane pitch in blocks */
+    int32_t         col0;           /* first block column of the rectangle */
+    int32_t         rows, cols;
+} mjx_host_rect_t;
+int mjx_compose_host(const mjx_host_rect_t *rects, int n);
+
+/* single rectangle given the whole plane (blocks_per_row * plane_rows blocks) */
 int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, int row0, int col0, int rows, int cols,
                           const uint16_t *q, const float *tile, const float *alpha);
 
@@ -129,6 +143,12 @@ int  mjx_dc_plan_run(const mjx_dc_plan_t *plan, mjx_stream_t stream);
 /* zero whole blocks (mj_effect_grayscale on components >= 1, effect.c:44-65; keep_dc = 0) or
  * coefficients 1..63 (mj_effect_pixelate, effect.c:82-111; keep_dc = 1) of rows x cols blocks */
 int mjx_effect_zero(int16_t *coef /* DEVICE */, int blocks_per_row, int rows, int cols, int keep_dc, mjx_stream_t stream);
+
+/* HOST-buffer forms of the effects and of the mj_convolve seam for per-image callers (H2D,
+ * kernel, D2H; synchronous) */
+int mjx_effect_dc_host(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value);
+int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc);
+int mjx_convolve_host(const float *x, float *y, float w, int k, int l, int nblocks);
 
 /* ---- synthetic workload generators (bench / test support; definition: mjx_synth.h) ------ */
 int mjx_synth_coef(int16_t *dst /* DEVICE */, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks,

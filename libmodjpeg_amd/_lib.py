@@ -31,6 +31,12 @@ class RectJob(ctypes.Structure):
                 ("qtable", ctypes.c_int32)]
 
 
+class HostRect(ctypes.Structure):
+    """struct mjx_host_rect (include/mjx.h)"""
+    _fields_ = [("rows_ptr", ctypes.c_void_p), ("tile", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("q", ctypes.c_void_p),
+                ("blocks_per_row", ctypes.c_int32), ("col0", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
+
+
 class DcJob(ctypes.Structure):
     """struct mjx_dc_job (include/mjx.h)"""
     _fields_ = [("coef", ctypes.c_void_p), ("blocks_per_row", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
@@ -52,7 +58,11 @@ SYMBOLS = [
     ("mjx_compose_plan_destroy", None, [_vp]),
     ("mjx_compose_plan_blocks", ctypes.c_int64, [_vp]),
     ("mjx_compose_run", _i, [_vp, _vp]),
+    ("mjx_compose_host", _i, [ctypes.POINTER(HostRect), _i]),
     ("mjx_compose_rect_host", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    ("mjx_effect_dc_host", _i, [_vp, _i, _i, _i, ctypes.c_uint16, _i]),
+    ("mjx_effect_zero_host", _i, [_vp, _i, _i, _i, _i]),
+    ("mjx_convolve_host", _i, [_vp, _vp, ctypes.c_float, _i, _i, _i]),
     ("mjx_convolve", _i, [_vp, _vp, ctypes.c_float, _i, _i, _i, _vp]),
     ("mjx_effect_dc", _i, [ctypes.POINTER(DcJob), _i, _vp]),
     ("mjx_dc_plan_create", _i, [ctypes.POINTER(_vp), ctypes.POINTER(DcJob), _i]),

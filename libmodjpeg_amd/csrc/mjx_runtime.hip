@@ -233,51 +233,102 @@ int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     return launch_compose(plan->d_jobs, plan->d_runs, plan->nruns, plan->d_q, plan->d_rq, (hipStream_t)stream);
 }
 
-int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, int row0, int col0, int rows, int cols, const uint16_t *q,
-                          const float *tile, const float *alpha) {
-    if(plane == nullptr || q == nullptr || tile == nullptr || alpha == nullptr) return MJX_ERR_NULL_DATA;
-    if(rows < 0 || cols < 0 || row0 < 0 || col0 < 0 || blocks_per_row <= 0 || col0 + (int64_t)cols > blocks_per_row ||
-       row0 + (int64_t)rows > plane_rows)
-        return MJX_ERR_BAD_ARG;
-    if(rows == 0 || cols == 0) return MJX_OK;
+// scoped device buffer for the host-buffer entry points
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if(p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) { return check_hip(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc(staging)", MJX_ERR_MEMORY); }
+};
+size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
+} // namespace
+
+int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
+    if(n < 0) return MJX_ERR_BAD_ARG;
+    if(n == 0) return MJX_OK;
+    if(rects == nullptr) return MJX_ERR_NULL_DATA;
+    size_t total = 0;
+    int    live = 0;
+    for(int i = 0; i < n; ++i) {
+        const mjx_host_rect_t &r = rects[i];
+        if(r.rows < 0 || r.cols < 0 || r.col0 < 0 || r.blocks_per_row <= 0 || r.col0 + (int64_t)r.cols > r.blocks_per_row) return MJX_ERR_BAD_ARG;
+        if(r.rows == 0 || r.cols == 0) continue;
+        if(r.rows_ptr == nullptr || r.tile == nullptr || r.alpha == nullptr || r.q == nullptr) return MJX_ERR_NULL_DATA;
+        total += round256((size_t)r.rows * r.blocks_per_row * 128) + 2 * round256((size_t)r.rows * r.cols * 256);
+        ++live;
+    }
+    if(live == 0) return MJX_OK;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
 
-    // only the plane rows the rectangle touches travel over PCIe
-    const size_t coef_bytes = (size_t)rows * (size_t)blocks_per_row * 128;
-    const size_t tile_bytes = (size_t)rows * (size_t)cols * 256;
-    int16_t     *h_rows = plane + (size_t)row0 * (size_t)blocks_per_row * 64;
-    void        *d_coef = nullptr, *d_tile = nullptr, *d_alpha = nullptr;
-    int          err = MJX_OK;
+    DevBuf buf;
+    int    err = buf.alloc(total);
+    if(err != MJX_OK) return err;
+
+    std::vector<mjx_rect_job_t> jobs;
+    std::vector<uint16_t>       qt;
+    std::vector<size_t>         coef_off;
+    char                       *base = static_cast<char *>(buf.p);
+    size_t                      off = 0;
+    hipStream_t                 s = nullptr;
+    for(int i = 0; i < n; ++i) {
+        const mjx_host_rect_t &r = rects[i];
+        if(r.rows == 0 || r.cols == 0) continue;
+        const size_t cb = (size_t)r.rows * r.blocks_per_row * 128, tb = (size_t)r.rows * r.cols * 256;
+        mjx_rect_job_t j;
+        j.coef = reinterpret_cast<int16_t *>(base + off);
+        coef_off.push_back(off);
+        MJX_HIP(hipMemcpyAsync(base + off, r.rows_ptr, cb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+        off += round256(cb);
+        j.tile = reinterpret_cast<const float *>(base + off);
+        MJX_HIP(hipMemcpyAsync(base + off, r.tile, tb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+        off += round256(tb);
+        j.alpha = reinterpret_cast<const float *>(base + off);
+        MJX_HIP(hipMemcpyAsync(base + off, r.alpha, tb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+        off += round256(tb);
+        j.blocks_per_row = r.blocks_per_row;
+        j.plane_rows = r.rows;
+        j.row0 = 0;
+        j.col0 = r.col0;
+        j.rows = r.rows;
+        j.cols = r.cols;
+        j.qtable = (int)jobs.size();
+        jobs.push_back(j);
+        qt.insert(qt.end(), r.q, r.q + 64);
+    }
+
     mjx_compose_plan_t *plan = nullptr;
-
-    do {
-        if((err = mjx_malloc(&d_coef, coef_bytes))) break;
-        if((err = mjx_malloc(&d_tile, tile_bytes))) break;
-        if((err = mjx_malloc(&d_alpha, tile_bytes))) break;
-        if((err = mjx_memcpy_h2d(d_coef, h_rows, coef_bytes, nullptr))) break;
-        if((err = mjx_memcpy_h2d(d_tile, tile, tile_bytes, nullptr))) break;
-        if((err = mjx_memcpy_h2d(d_alpha, alpha, tile_bytes, nullptr))) break;
-        mjx_rect_job_t job;
-        job.coef = (int16_t *)d_coef;
-        job.tile = (const float *)d_tile;
-        job.alpha = (const float *)d_alpha;
-        job.blocks_per_row = blocks_per_row;
-        job.plane_rows = rows;
-        job.row0 = 0;
-        job.col0 = col0;
-        job.rows = rows;
-        job.cols = cols;
-        job.qtable = 0;
-        if((err = mjx_compose_plan_create(&plan, &job, 1, q, 1))) break;
-        if((err = mjx_compose_run(plan, nullptr))) break;
-        if((err = mjx_memcpy_d2h(h_rows, d_coef, coef_bytes, nullptr))) break;
-    } while(0);
-
+    err = mjx_compose_plan_create(&plan, jobs.data(), (int)jobs.size(), qt.data(), (int)jobs.size());
+    if(err == MJX_OK) err = mjx_compose_run(plan, s);
+    if(err == MJX_OK) {
+        size_t k = 0;
+        for(int i = 0; i < n && err == MJX_OK; ++i) {
+            const mjx_host_rect_t &r = rects[i];
+            if(r.rows == 0 || r.cols == 0) continue;
+            err = check_hip(hipMemcpyAsync(r.rows_ptr, base + coef_off[k++], (size_t)r.rows * r.blocks_per_row * 128, hipMemcpyDeviceToHost, s),
+                            "hipMemcpyAsync(D2H)", MJX_ERR_LAUNCH);
+        }
+    }
+    const int serr = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
     mjx_compose_plan_destroy(plan);
-    (void)mjx_free(d_coef);
-    (void)mjx_free(d_tile);
-    (void)mjx_free(d_alpha);
-    return err;
+    return err != MJX_OK ? err : serr;
+}
+
+int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, int row0, int col0, int rows, int cols, const uint16_t *q,
+                          const float *tile, const float *alpha) {
+    if(plane == nullptr) return MJX_ERR_NULL_DATA;
+    if(row0 < 0 || rows < 0 || blocks_per_row <= 0 || row0 + (int64_t)rows > plane_rows) return MJX_ERR_BAD_ARG;
+    mjx_host_rect_t r;
+    r.rows_ptr = plane + (size_t)row0 * (size_t)blocks_per_row * 64;
+    r.tile = tile;
+    r.alpha = alpha;
+    r.q = q;
+    r.blocks_per_row = blocks_per_row;
+    r.col0 = col0;
+    r.rows = rows;
+    r.cols = cols;
+    return mjx_compose_host(&r, 1);
 }
 
 int mjx_convolve(const float *x, float *y, float w, int k, int l, int nblocks, mjx_stream_t stream) {
@@ -368,6 +419,68 @@ int mjx_effect_zero(int16_t *coef, int blocks_per_row, int rows, int cols, int k
     if(!aligned16(coef)) return MJX_ERR_BAD_ARG;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
     return launch_effect_zero(coef, blocks_per_row, rows, cols, keep_dc ? 1 : 0, (hipStream_t)stream);
+}
+
+// ---- host-buffer forms (per-image callers) ------------------------------------------------
+static int plane_roundtrip(int16_t *plane, int blocks_per_row, int rows, int cols, bool upload, int (*op)(int16_t *, void *), void *ctx) {
+    if(rows < 0 || cols < 0 || blocks_per_row < cols) return MJX_ERR_BAD_ARG;
+    if(rows == 0 || cols == 0) return MJX_OK;
+    if(plane == nullptr) return MJX_ERR_NULL_DATA;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    const size_t bytes = (size_t)rows * (size_t)blocks_per_row * 128;
+    DevBuf       buf;
+    int          err = buf.alloc(bytes);
+    if(err != MJX_OK) return err;
+    if(upload) MJX_HIP(hipMemcpy(buf.p, plane, bytes, hipMemcpyHostToDevice), MJX_ERR_LAUNCH);
+    err = op(static_cast<int16_t *>(buf.p), ctx);
+    if(err != MJX_OK) return err;
+    MJX_HIP(hipMemcpy(plane, buf.p, bytes, hipMemcpyDeviceToHost), MJX_ERR_LAUNCH);
+    return MJX_OK;
+}
+
+int mjx_effect_dc_host(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value) {
+    if(q0 == 0) return MJX_ERR_BAD_ARG;
+    mjx_dc_job_t j = {nullptr, blocks_per_row, rows, cols, value, q0, 0};
+    return plane_roundtrip(plane, blocks_per_row, rows, cols, true,
+                           [](int16_t *dev, void *ctx) {
+                               mjx_dc_job_t *job = static_cast<mjx_dc_job_t *>(ctx);
+                               job->coef = dev;
+                               return mjx_effect_dc(job, 1, nullptr);
+                           },
+                           &j);
+}
+
+int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc) {
+    struct Ctx {
+        int bpr, rows, cols, keep;
+    } c = {blocks_per_row, rows, cols, keep_dc};
+    // pixelate keeps the DCs and a pitch wider than `cols` keeps the padding columns: upload first
+    return plane_roundtrip(plane, blocks_per_row, rows, cols, true,
+                           [](int16_t *dev, void *ctx) {
+                               Ctx *c = static_cast<Ctx *>(ctx);
+                               int  e = mjx_effect_zero(dev, c->bpr, c->rows, c->cols, c->keep, nullptr);
+                               if(e == MJX_OK) e = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize", MJX_ERR_LAUNCH);
+                               return e;
+                           },
+                           &c);
+}
+
+int mjx_convolve_host(const float *x, float *y, float w, int k, int l, int nblocks) {
+    if(nblocks < 0 || k < 0 || k > 7 || l < 0 || l > 7) return MJX_ERR_BAD_ARG;
+    if(nblocks == 0) return MJX_OK;
+    if(x == nullptr || y == nullptr) return MJX_ERR_NULL_DATA;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    const size_t bytes = (size_t)nblocks * 256;
+    DevBuf       bx, by;
+    int          err = bx.alloc(bytes);
+    if(err == MJX_OK) err = by.alloc(bytes);
+    if(err != MJX_OK) return err;
+    MJX_HIP(hipMemcpy(bx.p, x, bytes, hipMemcpyHostToDevice), MJX_ERR_LAUNCH);
+    MJX_HIP(hipMemcpy(by.p, y, bytes, hipMemcpyHostToDevice), MJX_ERR_LAUNCH);
+    err = mjx_convolve(static_cast<const float *>(bx.p), static_cast<float *>(by.p), w, k, l, nblocks, nullptr);
+    if(err != MJX_OK) return err;
+    MJX_HIP(hipMemcpy(y, by.p, bytes, hipMemcpyDeviceToHost), MJX_ERR_LAUNCH);
+    return MJX_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,61 @@
+/*
+ * mjhost.h — internals of the libmodjpeg.h drop-in (C host on libjpeg, block loops on the GPU
+ * through include/mjx.h).  Not installed.
+ *
+ * Module map (reference file each one stands in for):
+ *      jpegio.c   coefficient JPEG in/out, pixel <-> JPEG helpers      (image.c, jpeg.c)
+ *      dropon.c   overlay readers: raw, JPEG (+mask JPEG), PNG         (dropon.c:34-323, :578-604)
+ *      tiles.c    overlay -> DCT-domain tiles ("compiled dropon")      (dropon.c:325-576, :606-)
+ *      compose.c  placement geometry + masked compose on the GPU       (compose.c, convolve.c)
+ *      effects.c  per-block effects on the GPU                         (effect.c)
+ */
+#ifndef MJHOST_H_
+#define MJHOST_H_
+
+#include "../../include/libmodjpeg.h"
+#include "../../include/mjx.h"
+
+#include <setjmp.h>
+#include <stddef.h>
+#include <stdint.h>
+
+/* libjpeg error trap: error_exit longjmps back to the API function, which returns MJ_ERR_* */
+typedef struct {
+    struct jpeg_error_mgr pub;
+    jmp_buf               trap;
+} mjh_error_trap_t;
+
+void mjh_trap_install(mjh_error_trap_t *t, j_common_ptr cinfo);
+void mjh_trap_park(j_common_ptr cinfo);
+
+/* file -> malloc()ed buffer */
+int mjh_slurp(const char *filename, unsigned char **buf, size_t *len);
+
+/* pixels (interleaved, `ncomp` samples per pixel as libjpeg will read them) -> quality-100
+ * baseline JPEG in `jpeg_colorspace` with the sampling factors of `s` (reference image.c:257) */
+int mjh_pixels_to_jpeg(unsigned char **out, size_t *outlen, unsigned char *pixels, int mj_colorspace, J_COLOR_SPACE jpeg_colorspace,
+                       const mj_sampling_t *s, int width, int height);
+
+/* JPEG -> pixels in the wanted MJ_COLORSPACE_{RGB,YCC,GRAYSCALE} (reference image.c:349-451) */
+int mjh_jpeg_to_pixels(unsigned char **pixels, int *width, int *height, int want_colorspace, const unsigned char *jpeg, size_t len);
+
+/* one component of an mj_jpeg_t copied out of / back into libjpeg's virtual array:
+ * rows [row0, row0+nrows) of `blocks_per_row` blocks each, contiguous, 128 bytes per block */
+void mjh_rows_gather(mj_jpeg_t *m, int c, int row0, int nrows, int16_t *dst);
+void mjh_rows_scatter(mj_jpeg_t *m, int c, int row0, int nrows, const int16_t *src);
+
+/* MJX_* -> MJ_ERR_* (INTEGRATION.md "error mapping"); prints once when the GPU is unusable */
+int mjh_from_mjx(int mjx_err);
+
+/* reference-internal entry points that stay exported (compose.h:28-29, convolve.h:28,
+ * dropon.h:28-38) because downstream code and tests link against them */
+int  mj_compose_with_mask(mj_jpeg_t *m, mj_compileddropon_t *cd, int block_x, int block_y);
+void mj_convolve(mj_block_t *x, mj_block_t *y, float w, int k, int l);
+int  mj_compile_dropon(mj_compileddropon_t *cd, mj_dropon_t *d, J_COLOR_SPACE colorspace, mj_sampling_t *s, int blockoffset_x, int blockoffset_y,
+                       int crop_x, int crop_y, int crop_w, int crop_h);
+int  mj_read_droponimage_from_memory(mj_compileddropon_t *cd, const unsigned char *memory, size_t len);
+int  mj_read_droponalpha_from_memory(mj_compileddropon_t *cd, const unsigned char *memory, size_t len);
+void mj_free_compileddropon(mj_compileddropon_t *cd);
+void mj_free_component(mj_component_t *c);
+
+#endif

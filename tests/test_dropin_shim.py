@@ -1,0 +1,180 @@
+"""The libmodjpeg.h drop-in (libmodjpeg_amd/host/libmodjpeg.so.1: C host on libjpeg + GPU block
+loops).  CPU tests cover what runs on the host (JPEG round trip, tile preparation against the tiles
+the reference prepared, error behaviour without a device); GPU tests run the README-style example
+program end to end and compare its coefficient planes with the vectors dumped from the reference.
+Needs jpeglib.h (IJG 9, as in the build container and the GPU box image); skipped otherwise."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "libmodjpeg_amd", "host")
+IMAGES = os.path.join(ROOT, "tests", "golden", "images")
+
+PUBLIC_API = ["mj_init_dropon", "mj_read_dropon_from_raw", "mj_read_dropon_from_memory", "mj_read_dropon_from_file", "mj_init_jpeg",
+              "mj_read_jpeg_from_memory", "mj_read_jpeg_from_file", "mj_compose", "mj_write_jpeg_to_memory", "mj_write_jpeg_to_file",
+              "mj_free_jpeg", "mj_free_dropon", "mj_effect_grayscale", "mj_effect_pixelate", "mj_effect_tint", "mj_effect_luminance"]
+INTERNAL_EXPORTS = ["mj_compose_with_mask", "mj_convolve", "mj_compile_dropon", "mj_free_compileddropon", "mj_free_component",
+                    "mj_read_droponimage_from_memory", "mj_read_droponalpha_from_memory"]
+
+
+@pytest.fixture(scope="module")
+def shim():
+    if not os.path.exists("/opt/conda/include/jpeglib.h"):
+        pytest.skip("no jpeglib.h in this image")
+    # torch first: it carries its own HIP runtime, and a process must not end up with two of them
+    # (libmjx_hip.so then binds to the one torch has already loaded, as in every other test)
+    import torch  # noqa: F401
+    import __graft_entry__ as g
+    g.build_hip()
+    g.build_host_shim()
+    so = os.path.join(HOST, "libmodjpeg.so.1")
+    assert os.path.exists(so)
+    return so
+
+
+def _planes(path, meta, count=1):
+    raw = np.fromfile(path, dtype=np.int16)
+    dims = [(int(meta[5 + 4 * c]), int(meta[4 + 4 * c])) for c in range(3)]
+    per = sum(h * w * 64 for h, w in dims)
+    assert raw.size == per * count
+    out = []
+    for k in range(count):
+        off, planes = k * per, []
+        for h, w in dims:
+            planes.append(raw[off:off + h * w * 64].reshape(h, w, 64))
+            off += h * w * 64
+        out.append(planes)
+    return out
+
+
+def test_exports(shim):
+    L = ctypes.CDLL(shim)
+    for name in PUBLIC_API + INTERNAL_EXPORTS:
+        assert hasattr(L, name), name
+
+
+def test_jpeg_roundtrip_on_host(shim, golden_dir, tmp_path):
+    g = np.load(os.path.join(golden_dir, "compose_kat.npz"))
+    out = tmp_path / "rt.bin"
+    subprocess.check_call([os.path.join(HOST, "mjhost_probe"), "roundtrip", os.path.join(IMAGES, "image.jpg"), str(out)])
+    a, b = _planes(out, g["meta"], 2)
+    for c in range(3):
+        assert np.array_equal(a[c].reshape(-1), g[f"before_c{c}"])  # same coefficients as the reference read
+        assert np.array_equal(a[c], b[c])  # write (optimised + progressive) -> read is lossless
+
+
+def _placement(g, case):
+    """overlay placement as compose.c:33-172 defines it (test-side restatement)"""
+    align, ox, oy = [int(v) for v in g[f"{case}_call"]]
+    w, h = int(g[f"{case}_dropon_meta"][0]), int(g[f"{case}_dropon_meta"][1])
+    W, H = int(g["meta"][0]), int(g["meta"][1])
+
+    def axis(L, l, near, far, off):
+        pos = 0 if near else (L - l if far else L // 2 - l // 2)
+        pos += off
+        crop = -pos if pos < 0 else 0
+        n = l - crop
+        if pos + crop + n > L:
+            n = L - crop - pos
+        return pos, crop, n
+
+    px, cx, cw = axis(W, w, align & 1, align & 2, ox)
+    py, cy, ch = axis(H, h, align & 4, align & 8, oy)
+    bx = px % 16 if px >= 0 else 0
+    by = py % 16 if py >= 0 else 0
+    return bx, by, cx, cy, cw, ch
+
+
+@pytest.mark.parametrize("case", ["tl", "br", "crop"])
+def test_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case):
+    """mj_compile_dropon of the drop-in == tiles prepared by the reference's mj_compile_dropon
+    (same libjpeg): contiguous tiles, alpha DC offset and scaling, padding"""
+    g = np.load(os.path.join(golden_dir, "compose_kat.npz"))
+    w, h, cs, blend = [int(v) for v in g[f"{case}_dropon_meta"]]
+    img = g[f"{case}_dropon_image"].reshape(h, w, 3)
+    alp = g[f"{case}_dropon_alpha"].reshape(h, w, 3)
+    assert cs == 1  # stored as RGB
+    rgba = np.concatenate([img, alp[:, :, :1]], axis=2).astype(np.uint8)
+    raw = tmp_path / "raw.bin"
+    rgba.tofile(raw)
+    bx, by, cx, cy, cw, ch = _placement(g, case)
+    out = tmp_path / "tiles.bin"
+    subprocess.check_call([os.path.join(HOST, "mjhost_probe"), "tiles", os.path.join(IMAGES, "image.jpg"), str(raw), str(w), str(h), "2", "255",
+                           str(bx), str(by), str(cx), str(cy), str(cw), str(ch), str(out)])
+    buf = open(out, "rb").read()
+    off = 0
+    for c in range(3):
+        wib, hib = np.frombuffer(buf, np.int32, 2, off)
+        off += 8
+        n = int(wib) * int(hib) * 64
+        tile = np.frombuffer(buf, np.float32, n, off)
+        off += n * 4
+        alpha = np.frombuffer(buf, np.float32, n, off)
+        off += n * 4
+        rows, cols = int(g[f"{case}_rect_c{c}"][2]), int(g[f"{case}_rect_c{c}"][3])
+        assert (hib, wib) == (rows, cols)
+        assert np.array_equal(tile.view(np.uint32), g[f"{case}_tile_c{c}"].reshape(-1).view(np.uint32)), (case, c)
+        assert np.array_equal(alpha.view(np.uint32), g[f"{case}_alpha_c{c}"].reshape(-1).view(np.uint32)), (case, c)
+    assert off == len(buf)
+
+
+def test_block_loops_fail_loudly_without_device(shim):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "nodevice", os.path.join(IMAGES, "image.jpg")], capture_output=True, text=True, check=True)
+    lum, compose, null, pix = [int(v) for v in res.stdout.split()]
+    assert (lum, compose, null, pix) == (1, 1, 2, 1)  # MJ_ERR_MEMORY, MJ_ERR_MEMORY, MJ_ERR_NULL_DATA, MJ_ERR_MEMORY
+    assert "no CPU fallback" in res.stderr
+
+
+CASES = {"tl": ("dropon.png", "-"), "br": ("dropon.jpg", "mask.jpg"), "crop": ("dropon.png", "-")}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["tl", "br", "crop"])
+def test_example_program_matches_reference(shim, golden_dir, tmp_path, case):
+    """the reference README flow (read, read dropon, mj_compose, write) compiled against the
+    drop-in: coefficient planes identical to the reference's own output; `tl` is the reference
+    repository's image_dropon.jpg"""
+    g = np.load(os.path.join(golden_dir, "compose_kat.npz"))
+    align, ox, oy = [int(v) for v in g[f"{case}_call"]]
+    dropon, mask = CASES[case]
+    out_jpg, out_bin = tmp_path / "out.jpg", tmp_path / "planes.bin"
+    subprocess.check_call([os.path.join(HOST, "modjpeg_example"), os.path.join(IMAGES, "image.jpg"), os.path.join(IMAGES, dropon),
+                           mask if mask == "-" else os.path.join(IMAGES, mask), str(align), str(ox), str(oy), "0", "0", "0", str(out_jpg), str(out_bin)])
+    got = _planes(out_bin, g["meta"])[0]
+    for c in range(3):
+        row0, col0, rows, cols = [int(v) for v in g[f"{case}_rect_c{c}"][:4]]
+        want = g[f"before_c{c}"].reshape(got[c].shape).copy()
+        want[row0:row0 + rows, col0:col0 + cols] = g[f"{case}_after_rect_c{c}"]
+        assert np.array_equal(got[c], want), (case, c)
+    assert os.path.getsize(out_jpg) > 1000
+
+
+@pytest.mark.gpu
+def test_example_program_effects(shim, golden_dir, tmp_path):
+    g = np.load(os.path.join(golden_dir, "effect_kat.npz"))
+    out_jpg, out_bin = tmp_path / "out.jpg", tmp_path / "planes.bin"
+    subprocess.check_call([os.path.join(HOST, "modjpeg_example"), os.path.join(IMAGES, "image.jpg"), "-", "-", "0", "0", "0", "100", "50", "0",
+                           str(out_jpg), str(out_bin)])
+    got = _planes(out_bin, g["meta"])[0]
+    for c in range(3):
+        assert np.array_equal(got[c].reshape(-1), g[f"lum100_tint50_0_c{c}"]), c
+
+
+@pytest.mark.gpu
+def test_mj_convolve_entry_point(shim, golden_dir):
+    g = np.load(os.path.join(golden_dir, "convolve_kat.npz"))
+    L = ctypes.CDLL(shim)
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.mj_convolve.argtypes = [fp, fp, ctypes.c_float, ctypes.c_int, ctypes.c_int]
+    L.mj_convolve.restype = None
+    for i in range(0, g["x"].shape[0], 7):
+        x, y = np.ascontiguousarray(g["x"][i]), g["yin"][i].copy()
+        L.mj_convolve(x.ctypes.data_as(fp), y.ctypes.data_as(fp), float(g["w"][i]), int(g["kl"][i, 0]), int(g["kl"][i, 1]))
+        assert np.array_equal(y.view(np.uint32), g["yout"][i].view(np.uint32)), i
