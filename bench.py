@@ -113,14 +113,61 @@ def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0):
     return info, expected
 
 
+# ---- the multi-rank protocol (backend-agnostic: RCCL on the GPU box, gloo in the CPU tests) ----
+
+def rank_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard_image0(rank, images_per_gpu):
+    """weak scaling: rank r owns the images [r*images_per_gpu, (r+1)*images_per_gpu); nothing is
+    exchanged between ranks"""
+    return rank * images_per_gpu
+
+
+def timed_steps(step, sync, steps, world, device, make_event=None):
+    """Exactly `steps` calls of `step()` bracketed by barrier + sync on both sides.  Returns
+    (elapsed seconds = MAX over ranks, per-step event pairs or None)."""
+    import torch
+    import torch.distributed as dist
+    ev = [(make_event(), make_event()) for _ in range(steps)] if make_event else None
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        if ev:
+            ev[k][0].record()  # on the current stream == the stream the kernels are launched on
+        step()
+        if ev:
+            ev[k][1].record()
+    sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, ev
+
+
+def sum_over_ranks(value, world, device):
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return value
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = rank_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -135,7 +182,7 @@ def main():
     width, height, dw, dh, mcu_x, mcu_y, default_images = WORKLOADS[args.workload]
     images = args.images or default_images
     regime = REGIMES[args.regime]
-    image0 = rank * images
+    image0 = shard_image0(rank, images)
     batch = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, regime, image0=image0)
     batch.fill_synthetic()
     batch.build_plan()
@@ -167,30 +214,10 @@ def main():
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps ----
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()  # on the current stream == the stream mjx_compose_run launches on
-        batch.run()
-        ev[k][1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-
+    elapsed, ev = timed_steps(batch.run, torch.cuda.synchronize, args.steps, world, "cuda", lambda: torch.cuda.Event(enable_timing=True))
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     mean_kern_ms = sum(kern_ms) / len(kern_ms)
-    tot_blocks = blocks_per_step
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        b = torch.tensor([blocks_per_step], dtype=torch.float64, device="cuda")
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
-        tot_blocks = int(b.item())
+    tot_blocks = sum_over_ranks(blocks_per_step, world, "cuda")
 
     if rank == 0:
         achieved = blocks_per_step * BYTES_PER_BLOCK / (mean_kern_ms * 1e-3) / 1e9
@@ -231,34 +258,17 @@ def bench_effects(args, rank, world):
     from libmodjpeg_amd.batch import EffectBatch
 
     images = args.images or 1024
-    eb = EffectBatch(images, 3840, 2160, image0=rank * images)
+    eb = EffectBatch(images, 3840, 2160, image0=shard_image0(rank, images))
     eb.fill_synthetic()
     eb.build_plans(7, 5, -3, fused=False)
     dcs = eb.dc_blocks_per_image() * images
     for _ in range(max(args.warmup, 1)):
         eb.run()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        eb.run()
-        ev[k][1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, ev = timed_steps(eb.run, torch.cuda.synchronize, args.steps, world, "cuda", lambda: torch.cuda.Event(enable_timing=True))
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     mean_ms = sum(kern_ms) / len(kern_ms)
-    tot = dcs
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = dcs * world
+    tot = sum_over_ranks(dcs, world, "cuda")
     if rank == 0:
         achieved = dcs * 4 / (mean_ms * 1e-3) / 1e9
         print(json.dumps({
