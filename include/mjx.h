@@ -107,8 +107,20 @@ typedef struct mjx_host_rect {
     int32_t         blocks_per_row; /* plane pitch in blocks */
     int32_t         col0;           /* first block column of the rectangle */
     int32_t         rows, cols;
+    int32_t         flags;          /* MJX_RECT_* */
+    int32_t         reserved;
 } mjx_host_rect_t;
+/* tile and alpha are DEVICE pointers (tiles kept resident across calls, e.g. one dropon composed
+ * into many images): only the plane rows cross PCIe */
+#define MJX_RECT_TILES_ON_DEVICE 1
 int mjx_compose_host(const mjx_host_rect_t *rects, int n);
+/* The host-buffer calls keep a grow-only staging arena (device buffer, pinned descriptor buffer,
+ * stream) per calling thread, so that a steady stream of per-image calls allocates nothing.
+ * mjx_release_thread_cache() frees the calling thread's arena (it is also freed at thread exit). */
+int mjx_release_thread_cache(void);
+/* pinned (page-locked) host memory: plane rows gathered into it upload at full PCIe rate */
+int mjx_malloc_host(void **host, size_t bytes);
+int mjx_free_host(void *host);
 
 /* single rectangle given the whole plane (blocks_per_row * plane_rows blocks) */
 int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, int row0, int col0, int rows, int cols,

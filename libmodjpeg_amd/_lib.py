@@ -34,7 +34,8 @@ class RectJob(ctypes.Structure):
 class HostRect(ctypes.Structure):
     """struct mjx_host_rect (include/mjx.h)"""
     _fields_ = [("rows_ptr", ctypes.c_void_p), ("tile", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("q", ctypes.c_void_p),
-                ("blocks_per_row", ctypes.c_int32), ("col0", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
+                ("blocks_per_row", ctypes.c_int32), ("col0", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class DcJob(ctypes.Structure):
@@ -59,6 +60,9 @@ SYMBOLS = [
     ("mjx_compose_plan_blocks", ctypes.c_int64, [_vp]),
     ("mjx_compose_run", _i, [_vp, _vp]),
     ("mjx_compose_host", _i, [ctypes.POINTER(HostRect), _i]),
+    ("mjx_release_thread_cache", _i, []),
+    ("mjx_malloc_host", _i, [ctypes.POINTER(_vp), _sz]),
+    ("mjx_free_host", _i, [_vp]),
     ("mjx_compose_rect_host", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("mjx_effect_dc_host", _i, [_vp, _i, _i, _i, ctypes.c_uint16, _i]),
     ("mjx_effect_zero_host", _i, [_vp, _i, _i, _i, _i]),

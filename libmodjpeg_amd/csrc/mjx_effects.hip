@@ -55,6 +55,44 @@ int launch_effect_dc(const DevDcJob *jobs, int njobs, int64_t max_blocks, hipStr
     return check_hip(hipGetLastError(), "effect_dc_kernel launch", MJX_ERR_LAUNCH);
 }
 
+// dense vector of DCs (per-image host path: only the DCs cross PCIe), 8 per lane
+__global__ __launch_bounds__(256) void effect_dc_vector_kernel(int16_t *__restrict__ dc, size_t n, int q0, float rq0, int value) {
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if(i0 >= n) return;
+    if(i0 + 8 <= n) {
+        uint4    v = *reinterpret_cast<uint4 *>(dc + i0);
+        unsigned w[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+        for(int k = 0; k < 4; ++k) {
+            int lo = (int)(short)(w[k] & 0xFFFFu), hi = ((int)w[k]) >> 16;
+            int d = dequant(lo, q0);
+            d = wrap16((int)((unsigned)d + (unsigned)value));
+            d = d > 2047 ? 2047 : (d < -2047 ? -2047 : d);
+            lo = requant(d, rq0);
+            d = dequant(hi, q0);
+            d = wrap16((int)((unsigned)d + (unsigned)value));
+            d = d > 2047 ? 2047 : (d < -2047 ? -2047 : d);
+            hi = requant(d, rq0);
+            o[k] = ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16);
+        }
+        *reinterpret_cast<uint4 *>(dc + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    else {
+        for(size_t i = i0; i < n; ++i) {
+            int d = dequant((int)dc[i], q0);
+            d = wrap16((int)((unsigned)d + (unsigned)value));
+            d = d > 2047 ? 2047 : (d < -2047 ? -2047 : d);
+            dc[i] = (int16_t)requant(d, rq0);
+        }
+    }
+}
+
+int launch_effect_dc_vector(int16_t *dc, size_t n, int q0, float rq0, int value, hipStream_t s) {
+    if(n == 0) return MJX_OK;
+    hipLaunchKernelGGL(effect_dc_vector_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, dc, n, q0, rq0, value);
+    return check_hip(hipGetLastError(), "effect_dc_vector_kernel launch", MJX_ERR_LAUNCH);
+}
+
 // one lane per 16 bytes (one block row); keep_dc: row 0 keeps coefficient 0
 __global__ __launch_bounds__(256) void effect_zero_kernel(int16_t *__restrict__ coef, int bpr, int rows, int cols, int keep_dc) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;

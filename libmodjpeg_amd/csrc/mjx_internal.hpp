@@ -59,6 +59,7 @@ int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_
 int run_octets();
 int launch_convolve(const float *x, float *y, float w, int k, int l, int nblocks, hipStream_t s);
 int launch_effect_dc(const DevDcJob *jobs, int njobs, int64_t max_blocks_per_job, hipStream_t s);
+int launch_effect_dc_vector(int16_t *dc, size_t n, int q0, float rq0, int value, hipStream_t s);
 int launch_effect_zero(int16_t *coef, int bpr, int rows, int cols, int keep_dc, hipStream_t s);
 int launch_synth_coef(int16_t *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, const QTable &q, hipStream_t s);
 int launch_synth_tile(float *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, hipStream_t s);

@@ -139,20 +139,20 @@ void mjx_compose_plan_destroy(mjx_compose_plan_t *p) {
     delete p;
 }
 
-int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq) {
-    if(plan == nullptr) return MJX_ERR_NULL_DATA;
-    *plan = nullptr;
-    if(njobs < 0 || nq < 0) return MJX_ERR_BAD_ARG;
-    if(njobs > 0 && (jobs == nullptr || qtables == nullptr || nq == 0)) return MJX_ERR_NULL_DATA;
-    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+// host-side launch tables of a set of rectangles (shared by plans and the host-buffer path)
+namespace {
+struct Tables {
+    std::vector<DevJob> jobs;
+    std::vector<Run>    runs;
+    std::vector<float>  rq;
+    int64_t             blocks = 0;
+};
 
+int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, Tables &t) {
     // the reference divides by quantval (compose.c:327-336): q == 0 is a caller bug there (SIGFPE)
     for(int i = 0; i < nq * 64; ++i) {
         if(qtables[i] == 0) return MJX_ERR_BAD_ARG;
     }
-
-    std::vector<DevJob> dj;
-    std::vector<Run>    runs;
     // Run length (octets per wave): long runs amortise the un-prefetched first octet, short runs
     // keep all 256 CUs x 12 resident waves busy when the whole launch is small (one 4K image is
     // only 24 300 octets).  Aim at >= 1 round of resident waves, within [2, MJX_RUN_OCTETS]
@@ -169,7 +169,6 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
         if(v >= 1 && v <= 1024) run_len = v;
     }
     const int run_blocks = run_len * kWaveBlocks;
-    int64_t             blocks = 0;
     // rectangles of >= 2^24 blocks are split by rows so that the kernel's float row/column split
     // of the linear tile index stays exact
     const int64_t kMaxJobBlocks = (1ll << 24) - 1;
@@ -200,37 +199,49 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
             d.qidx = j.qtable;
             d.inv_cols = 1.0f / (float)j.cols;
             d.pad = 0;
-            const int jid = (int)dj.size();
-            dj.push_back(d);
+            const int jid = (int)t.jobs.size();
+            t.jobs.push_back(d);
             for(int f = 0; f < d.nblocks; f += run_blocks) {
                 const int left = d.nblocks - f;
                 const int nb = left < run_blocks ? left : run_blocks;
-                runs.push_back(Run{jid, f, (nb + kWaveBlocks - 1) / kWaveBlocks, 0});
+                t.runs.push_back(Run{jid, f, (nb + kWaveBlocks - 1) / kWaveBlocks, 0});
             }
-            blocks += d.nblocks;
+            t.blocks += d.nblocks;
         }
     }
+    t.rq.resize((size_t)nq * 64);
+    for(int i = 0; i < nq * 64; ++i) t.rq[(size_t)i] = rq_of(qtables[i]);
+    return MJX_OK;
+}
+} // namespace
+
+int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq) {
+    if(plan == nullptr) return MJX_ERR_NULL_DATA;
+    *plan = nullptr;
+    if(njobs < 0 || nq < 0) return MJX_ERR_BAD_ARG;
+    if(njobs > 0 && (jobs == nullptr || qtables == nullptr || nq == 0)) return MJX_ERR_NULL_DATA;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+
+    Tables t;
+    int    err = build_tables(jobs, njobs, qtables, nq, t);
+    if(err != MJX_OK) return err;
 
     mjx_compose_plan *p = new(std::nothrow) mjx_compose_plan;
     if(p == nullptr) return MJX_ERR_MEMORY;
-    p->njobs = (int)dj.size();
-    p->nruns = (int)runs.size();
-    p->blocks = blocks;
+    p->njobs = (int)t.jobs.size();
+    p->nruns = (int)t.runs.size();
+    p->blocks = t.blocks;
 
-    std::vector<float> rq((size_t)nq * 64);
-    for(int i = 0; i < nq * 64; ++i) rq[(size_t)i] = rq_of(qtables[i]);
-
-    int err = MJX_OK;
     do {
         if(p->njobs == 0) break;
-        if((err = check_hip(hipMalloc((void **)&p->d_jobs, dj.size() * sizeof(DevJob)), "hipMalloc(jobs)", MJX_ERR_MEMORY))) break;
+        if((err = check_hip(hipMalloc((void **)&p->d_jobs, t.jobs.size() * sizeof(DevJob)), "hipMalloc(jobs)", MJX_ERR_MEMORY))) break;
+        if((err = check_hip(hipMalloc((void **)&p->d_runs, t.runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMalloc((void **)&p->d_q, (size_t)nq * 64 * sizeof(uint16_t)), "hipMalloc(q)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMalloc((void **)&p->d_rq, (size_t)nq * 64 * sizeof(float)), "hipMalloc(rq)", MJX_ERR_MEMORY))) break;
-        if((err = check_hip(hipMemcpy(p->d_jobs, dj.data(), dj.size() * sizeof(DevJob), hipMemcpyHostToDevice), "hipMemcpy(jobs)", MJX_ERR_LAUNCH))) break;
-        if((err = check_hip(hipMalloc((void **)&p->d_runs, runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
-        if((err = check_hip(hipMemcpy(p->d_runs, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
+        if((err = check_hip(hipMemcpy(p->d_jobs, t.jobs.data(), t.jobs.size() * sizeof(DevJob), hipMemcpyHostToDevice), "hipMemcpy(jobs)", MJX_ERR_LAUNCH))) break;
+        if((err = check_hip(hipMemcpy(p->d_runs, t.runs.data(), t.runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
         if((err = check_hip(hipMemcpy(p->d_q, qtables, (size_t)nq * 64 * sizeof(uint16_t), hipMemcpyHostToDevice), "hipMemcpy(q)", MJX_ERR_LAUNCH))) break;
-        if((err = check_hip(hipMemcpy(p->d_rq, rq.data(), (size_t)nq * 64 * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(rq)", MJX_ERR_LAUNCH))) break;
+        if((err = check_hip(hipMemcpy(p->d_rq, t.rq.data(), (size_t)nq * 64 * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(rq)", MJX_ERR_LAUNCH))) break;
     } while(0);
     if(err != MJX_OK) {
         mjx_compose_plan_destroy(p);
@@ -248,8 +259,13 @@ int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     return launch_compose(plan->d_jobs, plan->d_runs, plan->nruns, plan->d_q, plan->d_rq, (hipStream_t)stream);
 }
 
-// scoped device buffer for the host-buffer entry points
+// ------------------------------------------------------------------------------------------
+// host-buffer path (per-image callers): per-thread staging arena, no allocation in steady state
+// ------------------------------------------------------------------------------------------
 namespace {
+size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// scoped device buffer for the one-shot effect calls
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() {
@@ -257,51 +273,113 @@ struct DevBuf {
     }
     int alloc(size_t bytes) { return check_hip(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc(staging)", MJX_ERR_MEMORY); }
 };
-size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Grow-only device staging + pinned descriptor buffer + stream of the calling thread.  A service
+// calls mj_compose for image after image of similar size: after the first call no hipMalloc /
+// hipFree / plan object is involved any more, one packet of descriptors and the plane rows go
+// up, one kernel runs, the rows come back.
+struct Arena {
+    int         device = -1;
+    char       *dev = nullptr;
+    size_t      dev_cap = 0;
+    char       *pin = nullptr;
+    size_t      pin_cap = 0;
+    hipStream_t stream = nullptr;
+
+    void release() {
+        if(dev) (void)hipFree(dev);
+        if(pin) (void)hipHostFree(pin);
+        if(stream) (void)hipStreamDestroy(stream);
+        dev = nullptr; pin = nullptr; stream = nullptr; dev_cap = pin_cap = 0; device = -1;
+    }
+    ~Arena() { release(); }
+
+    int prepare(size_t dev_bytes, size_t pin_bytes) {
+        int cur = 0;
+        if(int e = check_hip(hipGetDevice(&cur), "hipGetDevice", MJX_ERR_NO_DEVICE)) return e;
+        if(cur != device) { // the thread moved to another GPU (mjx_set_device)
+            release();
+            device = cur;
+        }
+        if(stream == nullptr) {
+            if(int e = check_hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate", MJX_ERR_LAUNCH)) return e;
+        }
+        if(dev_bytes > dev_cap) {
+            if(dev) (void)hipFree(dev);
+            dev = nullptr;
+            dev_cap = 0;
+            const size_t want = dev_bytes + dev_bytes / 4;
+            if(int e = check_hip(hipMalloc((void **)&dev, want), "hipMalloc(arena)", MJX_ERR_MEMORY)) return e;
+            dev_cap = want;
+        }
+        if(pin_bytes > pin_cap) {
+            if(pin) (void)hipHostFree(pin);
+            pin = nullptr;
+            pin_cap = 0;
+            const size_t want = pin_bytes * 2;
+            if(int e = check_hip(hipHostMalloc((void **)&pin, want, hipHostMallocDefault), "hipHostMalloc(arena)", MJX_ERR_MEMORY)) return e;
+            pin_cap = want;
+        }
+        return MJX_OK;
+    }
+};
+thread_local Arena g_arena;
 } // namespace
+
+int mjx_release_thread_cache(void) {
+    g_arena.release();
+    return MJX_OK;
+}
+
+int mjx_malloc_host(void **host, size_t bytes) {
+    if(host == nullptr) return MJX_ERR_NULL_DATA;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    MJX_HIP(hipHostMalloc(host, bytes ? bytes : 16, hipHostMallocDefault), MJX_ERR_MEMORY);
+    return MJX_OK;
+}
+
+int mjx_free_host(void *host) {
+    if(host == nullptr) return MJX_OK;
+    MJX_HIP(hipHostFree(host), MJX_ERR_MEMORY);
+    return MJX_OK;
+}
 
 int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     if(n < 0) return MJX_ERR_BAD_ARG;
     if(n == 0) return MJX_OK;
     if(rects == nullptr) return MJX_ERR_NULL_DATA;
-    size_t total = 0;
-    int    live = 0;
+    int live = 0;
     for(int i = 0; i < n; ++i) {
         const mjx_host_rect_t &r = rects[i];
         if(r.rows < 0 || r.cols < 0 || r.col0 < 0 || r.blocks_per_row <= 0 || r.col0 + (int64_t)r.cols > r.blocks_per_row) return MJX_ERR_BAD_ARG;
         if(r.rows == 0 || r.cols == 0) continue;
         if(r.rows_ptr == nullptr || r.tile == nullptr || r.alpha == nullptr || r.q == nullptr) return MJX_ERR_NULL_DATA;
-        total += round256((size_t)r.rows * r.blocks_per_row * 128) + 2 * round256((size_t)r.rows * r.cols * 256);
         ++live;
     }
     if(live == 0) return MJX_OK;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
 
-    DevBuf buf;
-    int    err = buf.alloc(total);
-    if(err != MJX_OK) return err;
-
+    // device layout: [descriptor packet | per rectangle: plane rows, tile, alpha (unless resident)]
     std::vector<mjx_rect_job_t> jobs;
     std::vector<uint16_t>       qt;
     std::vector<size_t>         coef_off;
-    char                       *base = static_cast<char *>(buf.p);
-    size_t                      off = 0;
-    hipStream_t                 s = nullptr;
+    size_t                      data_bytes = 0;
     for(int i = 0; i < n; ++i) {
         const mjx_host_rect_t &r = rects[i];
         if(r.rows == 0 || r.cols == 0) continue;
-        const size_t cb = (size_t)r.rows * r.blocks_per_row * 128, tb = (size_t)r.rows * r.cols * 256;
+        data_bytes += round256((size_t)r.rows * r.blocks_per_row * 128);
+        if(!(r.flags & MJX_RECT_TILES_ON_DEVICE)) data_bytes += 2 * round256((size_t)r.rows * r.cols * 256);
+    }
+    // upper bound of the packet: jobs may be split (never for real JPEG sizes) -> size after build
+    // first pass with placeholder pointers to learn the table sizes
+    for(int i = 0; i < n; ++i) {
+        const mjx_host_rect_t &r = rects[i];
+        if(r.rows == 0 || r.cols == 0) continue;
         mjx_rect_job_t j;
-        j.coef = reinterpret_cast<int16_t *>(base + off);
-        coef_off.push_back(off);
-        MJX_HIP(hipMemcpyAsync(base + off, r.rows_ptr, cb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-        off += round256(cb);
-        j.tile = reinterpret_cast<const float *>(base + off);
-        MJX_HIP(hipMemcpyAsync(base + off, r.tile, tb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-        off += round256(tb);
-        j.alpha = reinterpret_cast<const float *>(base + off);
-        MJX_HIP(hipMemcpyAsync(base + off, r.alpha, tb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-        off += round256(tb);
+        memset(&j, 0, sizeof(j));
+        j.coef = reinterpret_cast<int16_t *>(uintptr_t(16)); // patched below
+        j.tile = reinterpret_cast<const float *>(uintptr_t(16));
+        j.alpha = reinterpret_cast<const float *>(uintptr_t(16));
         j.blocks_per_row = r.blocks_per_row;
         j.plane_rows = r.rows;
         j.row0 = 0;
@@ -312,12 +390,56 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         jobs.push_back(j);
         qt.insert(qt.end(), r.q, r.q + 64);
     }
+    const int    nq = (int)jobs.size();
+    const size_t packet_cap = round256(2 * jobs.size() * sizeof(DevJob)) + round256((size_t)nq * 64 * 6) +
+                              round256(((size_t)data_bytes / (kWaveBlocks * 128 * 2) + 4 * jobs.size() + 16) * sizeof(Run));
+    int err = g_arena.prepare(packet_cap + data_bytes, packet_cap);
+    if(err != MJX_OK) return err;
+    hipStream_t s = g_arena.stream;
+    char       *base = g_arena.dev;
 
-    mjx_compose_plan_t *plan = nullptr;
-    err = mjx_compose_plan_create(&plan, jobs.data(), (int)jobs.size(), qt.data(), (int)jobs.size());
-    if(err == MJX_OK) err = mjx_compose_run(plan, s);
+    // second pass: real device addresses, uploads
+    size_t off = packet_cap, k = 0;
+    for(int i = 0; i < n; ++i) {
+        const mjx_host_rect_t &r = rects[i];
+        if(r.rows == 0 || r.cols == 0) continue;
+        const size_t cb = (size_t)r.rows * r.blocks_per_row * 128, tb = (size_t)r.rows * r.cols * 256;
+        mjx_rect_job_t &j = jobs[k++];
+        j.coef = reinterpret_cast<int16_t *>(base + off);
+        coef_off.push_back(off);
+        MJX_HIP(hipMemcpyAsync(base + off, r.rows_ptr, cb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+        off += round256(cb);
+        if(r.flags & MJX_RECT_TILES_ON_DEVICE) {
+            j.tile = r.tile;
+            j.alpha = r.alpha;
+        }
+        else {
+            j.tile = reinterpret_cast<const float *>(base + off);
+            MJX_HIP(hipMemcpyAsync(base + off, r.tile, tb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+            off += round256(tb);
+            j.alpha = reinterpret_cast<const float *>(base + off);
+            MJX_HIP(hipMemcpyAsync(base + off, r.alpha, tb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+            off += round256(tb);
+        }
+    }
+    Tables t;
+    err = build_tables(jobs.data(), (int)jobs.size(), qt.data(), nq, t);
+    if(err != MJX_OK) return err;
+
+    // descriptor packet in pinned memory: [DevJob[] | Run[] | q | rq], one copy
+    const size_t o_jobs = 0, o_runs = round256(t.jobs.size() * sizeof(DevJob)), o_q = o_runs + round256(t.runs.size() * sizeof(Run)),
+                 o_rq = o_q + round256((size_t)nq * 128), packet = o_rq + round256((size_t)nq * 256);
+    if(packet > packet_cap) return MJX_ERR_BAD_ARG; // cannot happen for rectangles below 2^24 blocks
+    memcpy(g_arena.pin + o_jobs, t.jobs.data(), t.jobs.size() * sizeof(DevJob));
+    memcpy(g_arena.pin + o_runs, t.runs.data(), t.runs.size() * sizeof(Run));
+    memcpy(g_arena.pin + o_q, qt.data(), (size_t)nq * 128);
+    memcpy(g_arena.pin + o_rq, t.rq.data(), (size_t)nq * 256);
+    MJX_HIP(hipMemcpyAsync(base, g_arena.pin, packet, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+
+    err = launch_compose(reinterpret_cast<const DevJob *>(base + o_jobs), reinterpret_cast<const Run *>(base + o_runs), (int)t.runs.size(),
+                         reinterpret_cast<const uint16_t *>(base + o_q), reinterpret_cast<const float *>(base + o_rq), s);
     if(err == MJX_OK) {
-        size_t k = 0;
+        k = 0;
         for(int i = 0; i < n && err == MJX_OK; ++i) {
             const mjx_host_rect_t &r = rects[i];
             if(r.rows == 0 || r.cols == 0) continue;
@@ -326,7 +448,6 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         }
     }
     const int serr = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
-    mjx_compose_plan_destroy(plan);
     return err != MJX_OK ? err : serr;
 }
 
@@ -343,6 +464,8 @@ int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, in
     r.col0 = col0;
     r.rows = rows;
     r.cols = cols;
+    r.flags = 0;
+    r.reserved = 0;
     return mjx_compose_host(&r, 1);
 }
 
@@ -437,47 +560,55 @@ int mjx_effect_zero(int16_t *coef, int blocks_per_row, int rows, int cols, int k
 }
 
 // ---- host-buffer forms (per-image callers) ------------------------------------------------
-static int plane_roundtrip(int16_t *plane, int blocks_per_row, int rows, int cols, bool upload, int (*op)(int16_t *, void *), void *ctx) {
+// DC effects: only the DCs travel.  The 2-byte DC of every 128-byte block is gathered into the
+// calling thread's pinned staging buffer (host, strided copy), goes up as a dense vector, is
+// updated by the same device arithmetic as the batch kernel, comes back and is scattered.
+int mjx_effect_dc_host(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value) {
+    if(rows < 0 || cols < 0 || blocks_per_row < cols) return MJX_ERR_BAD_ARG;
+    if(rows == 0 || cols == 0) return MJX_OK;
+    if(plane == nullptr) return MJX_ERR_NULL_DATA;
+    if(q0 == 0) return MJX_ERR_BAD_ARG;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    const size_t n = (size_t)rows * (size_t)cols, bytes = round256(n * sizeof(int16_t));
+    int          err = g_arena.prepare(bytes, bytes);
+    if(err != MJX_OK) return err;
+    int16_t *stage = reinterpret_cast<int16_t *>(g_arena.pin);
+    for(int r = 0; r < rows; ++r) {
+        const int16_t *src = plane + (size_t)r * (size_t)blocks_per_row * 64;
+        int16_t       *dst = stage + (size_t)r * (size_t)cols;
+        for(int c = 0; c < cols; ++c) dst[c] = src[(size_t)c * 64];
+    }
+    hipStream_t s = g_arena.stream;
+    MJX_HIP(hipMemcpyAsync(g_arena.dev, stage, n * sizeof(int16_t), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    err = launch_effect_dc_vector(reinterpret_cast<int16_t *>(g_arena.dev), n, q0, rq_of(q0), value, s);
+    if(err != MJX_OK) return err;
+    MJX_HIP(hipMemcpyAsync(stage, g_arena.dev, n * sizeof(int16_t), hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
+    for(int r = 0; r < rows; ++r) {
+        int16_t       *dst = plane + (size_t)r * (size_t)blocks_per_row * 64;
+        const int16_t *src = stage + (size_t)r * (size_t)cols;
+        for(int c = 0; c < cols; ++c) dst[(size_t)c * 64] = src[c];
+    }
+    return MJX_OK;
+}
+
+// zero fills: the plane goes up (pixelate keeps the DCs, a pitch wider than `cols` keeps its
+// padding columns), is zeroed on the device and comes back
+int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc) {
     if(rows < 0 || cols < 0 || blocks_per_row < cols) return MJX_ERR_BAD_ARG;
     if(rows == 0 || cols == 0) return MJX_OK;
     if(plane == nullptr) return MJX_ERR_NULL_DATA;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
     const size_t bytes = (size_t)rows * (size_t)blocks_per_row * 128;
-    DevBuf       buf;
-    int          err = buf.alloc(bytes);
+    int          err = g_arena.prepare(bytes, 256);
     if(err != MJX_OK) return err;
-    if(upload) MJX_HIP(hipMemcpy(buf.p, plane, bytes, hipMemcpyHostToDevice), MJX_ERR_LAUNCH);
-    err = op(static_cast<int16_t *>(buf.p), ctx);
+    hipStream_t s = g_arena.stream;
+    MJX_HIP(hipMemcpyAsync(g_arena.dev, plane, bytes, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    err = launch_effect_zero(reinterpret_cast<int16_t *>(g_arena.dev), blocks_per_row, rows, cols, keep_dc ? 1 : 0, s);
     if(err != MJX_OK) return err;
-    MJX_HIP(hipMemcpy(plane, buf.p, bytes, hipMemcpyDeviceToHost), MJX_ERR_LAUNCH);
+    MJX_HIP(hipMemcpyAsync(plane, g_arena.dev, bytes, hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
     return MJX_OK;
-}
-
-int mjx_effect_dc_host(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value) {
-    if(q0 == 0) return MJX_ERR_BAD_ARG;
-    mjx_dc_job_t j = {nullptr, blocks_per_row, rows, cols, value, q0, 0};
-    return plane_roundtrip(plane, blocks_per_row, rows, cols, true,
-                           [](int16_t *dev, void *ctx) {
-                               mjx_dc_job_t *job = static_cast<mjx_dc_job_t *>(ctx);
-                               job->coef = dev;
-                               return mjx_effect_dc(job, 1, nullptr);
-                           },
-                           &j);
-}
-
-int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc) {
-    struct Ctx {
-        int bpr, rows, cols, keep;
-    } c = {blocks_per_row, rows, cols, keep_dc};
-    // pixelate keeps the DCs and a pitch wider than `cols` keeps the padding columns: upload first
-    return plane_roundtrip(plane, blocks_per_row, rows, cols, true,
-                           [](int16_t *dev, void *ctx) {
-                               Ctx *c = static_cast<Ctx *>(ctx);
-                               int  e = mjx_effect_zero(dev, c->bpr, c->rows, c->cols, c->keep, nullptr);
-                               if(e == MJX_OK) e = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize", MJX_ERR_LAUNCH);
-                               return e;
-                           },
-                           &c);
 }
 
 int mjx_convolve_host(const float *x, float *y, float w, int k, int l, int nblocks) {

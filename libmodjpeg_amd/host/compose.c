@@ -11,6 +11,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* one component's share of a compose call */
+typedef struct {
+    int          rows, cols;   /* tile grid */
+    const float *tile, *alpha; /* host or device memory, as the caller of blend_components says */
+} comp_tiles_t;
+
+static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int tiles_on_device, int block_x, int block_y);
+
 /* one axis of the placement: where the overlay starts on the image and what survives cropping */
 typedef struct {
     int position; /* image coordinate of the overlay's first pixel (may be negative) */
@@ -37,6 +45,7 @@ static axis_t place_axis(int image_len, int overlay_len, int near_flag, int far_
 
 int mj_compose(mj_jpeg_t *m, mj_dropon_t *d, unsigned int align, int offset_x, int offset_y) {
     mj_compileddropon_t cd;
+    struct mjh_tiles   *cached = NULL;
     axis_t              ax, ay;
     int                 inblock_x, inblock_y, mcu_x, mcu_y, rv;
 
@@ -55,14 +64,28 @@ int mj_compose(mj_jpeg_t *m, mj_dropon_t *d, unsigned int align, int offset_x, i
     if(inblock_x < 0) inblock_x = 0;
     if(inblock_y < 0) inblock_y = 0;
 
-    rv = mj_compile_dropon(&cd, d, m->cinfo.jpeg_color_space, &m->sampling, inblock_x, inblock_y, ax.crop_at, ay.crop_at, ax.crop_len, ay.crop_len);
-    if(rv != MJ_OK) return rv;
-
     mcu_x = ax.position / m->sampling.h_factor; /* compose.c:163-172 */
     mcu_y = ay.position / m->sampling.v_factor;
     if(mcu_x < 0) mcu_x = 0;
     if(mcu_y < 0) mcu_y = 0;
+    if(m->coef == NULL) return MJ_ERR_NULL_DATA;
 
+    /* tiles: from the device-resident cache when this (overlay window, offset, target format) has
+     * been prepared before, else prepared now exactly as the reference does on every call */
+    rv = mjh_tiles_acquire(&cached, d, m->cinfo.jpeg_color_space, &m->sampling, inblock_x, inblock_y, ax.crop_at, ay.crop_at, ax.crop_len, ay.crop_len);
+    if(rv != MJ_OK) return rv;
+    if(cached != NULL) {
+        comp_tiles_t ct[4];
+        int          c, n = mjh_tiles_ncomp(cached);
+        memset(ct, 0, sizeof(ct));
+        for(c = 0; c < n && c < 4; c++) mjh_tiles_component(cached, c, &ct[c].rows, &ct[c].cols, &ct[c].tile, &ct[c].alpha);
+        rv = blend_components(m, n, ct, 1, mcu_x, mcu_y);
+        mjh_tiles_release(cached);
+        return rv;
+    }
+
+    rv = mj_compile_dropon(&cd, d, m->cinfo.jpeg_color_space, &m->sampling, inblock_x, inblock_y, ax.crop_at, ay.crop_at, ax.crop_len, ay.crop_len);
+    if(rv != MJ_OK) return rv;
     rv = mj_compose_with_mask(m, &cd, mcu_x, mcu_y);
     mj_free_compileddropon(&cd);
     return rv;
@@ -84,63 +107,94 @@ static const float *contiguous_tiles(const mj_component_t *t, float **owned) {
     return *owned;
 }
 
-int mj_compose_with_mask(mj_jpeg_t *m, mj_compileddropon_t *cd, int block_x, int block_y) {
+/* The block loop of mj_compose_with_mask (compose.c:256-338) for all components in ONE launch:
+ * the plane rows under the rectangle go to the GPU (straight out of libjpeg's pool when the plane
+ * is one contiguous chunk, else through a gathered copy), tiles come from the host or are already
+ * resident on the device. */
+static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int tiles_on_device, int block_x, int block_y) {
     enum { MAXC = 4 };
     mjx_host_rect_t rect[MAXC];
     uint16_t        q[MAXC][64];
-    int16_t        *rows[MAXC] = {NULL, NULL, NULL, NULL};
-    float          *own_t[MAXC] = {NULL, NULL, NULL, NULL}, *own_a[MAXC] = {NULL, NULL, NULL, NULL};
+    int16_t        *staged[MAXC] = {NULL, NULL, NULL, NULL};
     int             row0[MAXC];
-    int             c, i, n, rv = MJ_OK;
+    int             c, i, rv = MJ_OK;
 
-    if(m == NULL || cd == NULL) return MJ_ERR_NULL_DATA; /* compose.c:238 */
-    if(m->coef == NULL) return MJ_ERR_NULL_DATA;
+    if(n > MAXC || n > m->cinfo.num_components) return MJ_ERR_DROPON_DIMENSIONS;
     memset(rect, 0, sizeof(rect));
-    n = cd->image_ncomponents;
-    if(n > MAXC || n > m->cinfo.num_components || cd->alpha_ncomponents < n) return MJ_ERR_DROPON_DIMENSIONS;
-
     for(c = 0; c < n && rv == MJ_OK; c++) {
-        jpeg_component_info  *ci = &m->cinfo.comp_info[c];
-        const mj_component_t *ti = &cd->image[c], *ta = &cd->alpha[c];
-        const int             bpr = (int)ci->width_in_blocks;
+        jpeg_component_info *ci = &m->cinfo.comp_info[c];
+        const int            bpr = (int)ci->width_in_blocks;
+        int16_t             *plane;
 
-        memset(&rect[c], 0, sizeof(rect[c]));
-        rect[c].rows = ti->height_in_blocks;
-        rect[c].cols = ti->width_in_blocks;
+        rect[c].rows = ct[c].rows;
+        rect[c].cols = ct[c].cols;
         rect[c].blocks_per_row = bpr;
         rect[c].col0 = block_x * ci->h_samp_factor; /* compose.c:264 */
         row0[c] = block_y * ci->v_samp_factor;      /* compose.c:265 */
+        rect[c].flags = tiles_on_device ? MJX_RECT_TILES_ON_DEVICE : 0;
         if(rect[c].rows <= 0 || rect[c].cols <= 0) {
             rect[c].rows = rect[c].cols = 0;
             continue;
         }
         /* the reference would walk off the coefficient array here (libjpeg error / overrun) */
-        if(ta->nblocks != ti->nblocks || rect[c].col0 + rect[c].cols > bpr || row0[c] + rect[c].rows > (int)ci->height_in_blocks || ci->quant_table == NULL) {
+        if(rect[c].col0 + rect[c].cols > bpr || row0[c] + rect[c].rows > (int)ci->height_in_blocks || ci->quant_table == NULL) {
             rv = MJ_ERR_DROPON_DIMENSIONS;
+            break;
+        }
+        if(ct[c].tile == NULL || ct[c].alpha == NULL) {
+            rv = MJ_ERR_MEMORY;
             break;
         }
         for(i = 0; i < 64; i++) q[c][i] = ci->quant_table->quantval[i];
         rect[c].q = q[c];
-        rect[c].tile = contiguous_tiles(ti, &own_t[c]);
-        rect[c].alpha = contiguous_tiles(ta, &own_a[c]);
-        rows[c] = (int16_t *)malloc((size_t)rect[c].rows * (size_t)bpr * sizeof(JBLOCK));
-        if(rect[c].tile == NULL || rect[c].alpha == NULL || rows[c] == NULL) {
-            rv = MJ_ERR_MEMORY;
+        rect[c].tile = ct[c].tile;
+        rect[c].alpha = ct[c].alpha;
+        plane = mjh_plane_direct(m, c);
+        if(plane != NULL) {
+            rect[c].rows_ptr = plane + (size_t)row0[c] * (size_t)bpr * 64;
+        }
+        else {
+            staged[c] = (int16_t *)malloc((size_t)rect[c].rows * (size_t)bpr * sizeof(JBLOCK));
+            if(staged[c] == NULL) {
+                rv = MJ_ERR_MEMORY;
+                break;
+            }
+            mjh_rows_gather(m, c, row0[c], rect[c].rows, staged[c]);
+            rect[c].rows_ptr = staged[c];
+        }
+    }
+    if(rv == MJ_OK) rv = mjh_from_mjx(mjx_compose_host(rect, n));
+    for(c = 0; c < MAXC; c++) {
+        if(staged[c] != NULL) {
+            if(rv == MJ_OK) mjh_rows_scatter(m, c, row0[c], rect[c].rows, staged[c]);
+            free(staged[c]);
+        }
+    }
+    return rv;
+}
+
+int mj_compose_with_mask(mj_jpeg_t *m, mj_compileddropon_t *cd, int block_x, int block_y) {
+    comp_tiles_t ct[4];
+    float       *own_t[4] = {NULL, NULL, NULL, NULL}, *own_a[4] = {NULL, NULL, NULL, NULL};
+    int          c, n, rv = MJ_OK;
+
+    if(m == NULL || cd == NULL) return MJ_ERR_NULL_DATA; /* compose.c:238 */
+    if(m->coef == NULL) return MJ_ERR_NULL_DATA;
+    n = cd->image_ncomponents;
+    if(n > 4 || cd->alpha_ncomponents < n) return MJ_ERR_DROPON_DIMENSIONS;
+    memset(ct, 0, sizeof(ct));
+    for(c = 0; c < n; c++) {
+        if(cd->alpha[c].nblocks != cd->image[c].nblocks) {
+            rv = MJ_ERR_DROPON_DIMENSIONS;
             break;
         }
-        mjh_rows_gather(m, c, row0[c], rect[c].rows, rows[c]);
-        rect[c].rows_ptr = rows[c];
+        ct[c].rows = cd->image[c].height_in_blocks;
+        ct[c].cols = cd->image[c].width_in_blocks;
+        ct[c].tile = contiguous_tiles(&cd->image[c], &own_t[c]);
+        ct[c].alpha = contiguous_tiles(&cd->alpha[c], &own_a[c]);
     }
-
-    if(rv == MJ_OK) rv = mjh_from_mjx(mjx_compose_host(rect, n));
-
-    if(rv == MJ_OK) {
-        for(c = 0; c < n; c++) {
-            if(rows[c] != NULL) mjh_rows_scatter(m, c, row0[c], rect[c].rows, rows[c]);
-        }
-    }
-    for(c = 0; c < MAXC; c++) {
-        free(rows[c]);
+    if(rv == MJ_OK) rv = blend_components(m, n, ct, 0, block_x, block_y);
+    for(c = 0; c < 4; c++) {
         free(own_t[c]);
         free(own_a[c]);
     }

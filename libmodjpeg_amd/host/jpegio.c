@@ -314,6 +314,21 @@ static JBLOCKROW coef_row(mj_jpeg_t *m, int c, int row, boolean writable) {
     return a[0];
 }
 
+int16_t *mjh_plane_direct(mj_jpeg_t *m, int c) {
+    const jpeg_component_info *ci = &m->cinfo.comp_info[c];
+    const size_t               row_blocks = (size_t)ci->width_in_blocks;
+    JBLOCKROW                  first, prev;
+    JDIMENSION                 r;
+    if(ci->height_in_blocks == 0) return NULL;
+    first = prev = coef_row(m, c, 0, TRUE);
+    for(r = 1; r < ci->height_in_blocks; r++) {
+        JBLOCKROW cur = coef_row(m, c, (int)r, TRUE);
+        if(cur != prev + row_blocks) return NULL;
+        prev = cur;
+    }
+    return (int16_t *)first;
+}
+
 void mjh_rows_gather(mj_jpeg_t *m, int c, int row0, int nrows, int16_t *dst) {
     const size_t row_bytes = (size_t)m->cinfo.comp_info[c].width_in_blocks * sizeof(JBLOCK);
     int          r;

@@ -44,6 +44,19 @@ int mjh_jpeg_to_pixels(unsigned char **pixels, int *width, int *height, int want
 void mjh_rows_gather(mj_jpeg_t *m, int c, int row0, int nrows, int16_t *dst);
 void mjh_rows_scatter(mj_jpeg_t *m, int c, int row0, int nrows, const int16_t *src);
 
+/* whole component plane as one contiguous array inside libjpeg's pool, or NULL when libjpeg
+ * split it into several chunks (then the rows are gathered/scattered) */
+int16_t *mjh_plane_direct(mj_jpeg_t *m, int c);
+
+/* prepared tiles resident on the device, cached across mj_compose calls (tilecache.c).
+ * acquire() sets *out = NULL (and returns MJ_OK) when the cache is disabled or full of busy
+ * entries: the caller then prepares tiles itself. */
+struct mjh_tiles;
+int  mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, mj_sampling_t *s, int bx, int by, int cx, int cy, int cw, int ch);
+void mjh_tiles_release(struct mjh_tiles *t);
+int  mjh_tiles_ncomp(const struct mjh_tiles *t);
+void mjh_tiles_component(const struct mjh_tiles *t, int c, int *rows, int *cols, const float **dev_tile, const float **dev_alpha);
+
 /* MJX_* -> MJ_ERR_* (INTEGRATION.md "error mapping"); prints once when the GPU is unusable */
 int mjh_from_mjx(int mjx_err);
 

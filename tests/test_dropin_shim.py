@@ -178,3 +178,20 @@ def test_mj_convolve_entry_point(shim, golden_dir):
         x, y = np.ascontiguousarray(g["x"][i]), g["yin"][i].copy()
         L.mj_convolve(x.ctypes.data_as(fp), y.ctypes.data_as(fp), float(g["w"][i]), int(g["kl"][i, 0]), int(g["kl"][i, 1]))
         assert np.array_equal(y.view(np.uint32), g["yout"][i].view(np.uint32)), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [("640", "480", "160", "96", "3"), ("1920", "1080", "256", "256", "2", "7", "5", "-3")])
+def test_written_jpegs_byte_identical_to_reference(shim, args):
+    """the same program (read -> mj_compose at an unaligned position -> effects -> write) run
+    against the unmodified reference library and against the drop-in writes identical files.
+    Needs oracle/_ref (built in the container, travels with gpurun)."""
+    import json
+    ref = os.path.join(ROOT, "oracle", "_ref", "libmodjpeg_ref.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not present")
+    exe = os.path.join(HOST, "bench_dropin")
+    for env in (dict(os.environ, BENCH_VARY_POSITION="1"), dict(os.environ), dict(os.environ, MJ_TILE_CACHE="0")):
+        a = json.loads(subprocess.check_output([exe, ref, *args], text=True, env=env))
+        b = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))  # tile cache: misses, hits, disabled
+        assert a["out_bytes"] == b["out_bytes"] and a["fnv1a"] == b["fnv1a"], (a, b)
