@@ -114,9 +114,9 @@ typedef struct mjx_host_rect {
  * into many images): only the plane rows cross PCIe */
 #define MJX_RECT_TILES_ON_DEVICE 1
 int mjx_compose_host(const mjx_host_rect_t *rects, int n);
-/* The host-buffer calls keep a grow-only staging arena (device buffer, pinned descriptor buffer,
- * stream) per calling thread, so that a steady stream of per-image calls allocates nothing.
- * mjx_release_thread_cache() frees the calling thread's arena (it is also freed at thread exit). */
+/* The host-buffer calls borrow a staging arena (grow-only device buffer, pinned descriptor buffer,
+ * stream) from a small process-wide pool, so that a steady stream of per-image calls from any
+ * number of threads allocates nothing.  mjx_release_thread_cache() frees the idle arenas. */
 int mjx_release_thread_cache(void);
 /* pinned (page-locked) host memory: plane rows gathered into it upload at full PCIe rate */
 int mjx_malloc_host(void **host, size_t bytes);

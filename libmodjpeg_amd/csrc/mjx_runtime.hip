@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <pthread.h>
+
 #include <atomic>
 #include <new>
 #include <vector>
@@ -274,10 +276,10 @@ struct DevBuf {
     int alloc(size_t bytes) { return check_hip(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc(staging)", MJX_ERR_MEMORY); }
 };
 
-// Grow-only device staging + pinned descriptor buffer + stream of the calling thread.  A service
-// calls mj_compose for image after image of similar size: after the first call no hipMalloc /
-// hipFree / plan object is involved any more, one packet of descriptors and the plane rows go
-// up, one kernel runs, the rows come back.
+// Grow-only device staging + pinned descriptor buffer + stream.  A service calls mj_compose for
+// image after image of similar size: after the first calls no hipMalloc / hipFree / plan object is
+// involved any more, one packet of descriptors and the plane rows go up, one kernel runs, the
+// rows come back.
 struct Arena {
     int         device = -1;
     char       *dev = nullptr;
@@ -292,7 +294,8 @@ struct Arena {
         if(stream) (void)hipStreamDestroy(stream);
         dev = nullptr; pin = nullptr; stream = nullptr; dev_cap = pin_cap = 0; device = -1;
     }
-    ~Arena() { release(); }
+    // no destructor on purpose: the pool is a process-lifetime static, and at exit the HIP runtime
+    // may already be gone; the driver reclaims the memory with the process
 
     int prepare(size_t dev_bytes, size_t pin_bytes) {
         int cur = 0;
@@ -323,11 +326,66 @@ struct Arena {
         return MJX_OK;
     }
 };
-thread_local Arena g_arena;
+// Pool of arenas shared by all host threads.  A per-image call needs the GPU for a fraction of a
+// millisecond out of the ~17 ms a thread spends on one 1080p image (entropy decode/encode on the
+// host), so a handful of arenas serves any number of threads; creating one per thread instead
+// costs ~6 ms of serialised driver work per thread (measured with the batch CLI at 64 threads).
+constexpr int   kMaxArenas = 8;
+Arena           g_pool[kMaxArenas];
+bool            g_busy[kMaxArenas];
+pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
+pthread_cond_t  g_pool_free = PTHREAD_COND_INITIALIZER;
+
+// borrow an arena that already lives on the calling thread's device if there is one, else an
+// unused slot; blocks while all slots are busy
+struct ArenaLease {
+    Arena *a = nullptr;
+    int    slot = -1;
+    ArenaLease() {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        pthread_mutex_lock(&g_pool_lock);
+        for(;;) {
+            int pick = -1;
+            for(int i = 0; i < kMaxArenas; ++i) {
+                if(!g_busy[i] && g_pool[i].device == cur) { pick = i; break; }
+            }
+            if(pick < 0) {
+                for(int i = 0; i < kMaxArenas; ++i) {
+                    if(!g_busy[i] && g_pool[i].device < 0) { pick = i; break; }
+                }
+            }
+            if(pick < 0) {
+                for(int i = 0; i < kMaxArenas; ++i) {
+                    if(!g_busy[i]) { pick = i; break; } // idle arena of another device: prepare() rebuilds it
+                }
+            }
+            if(pick >= 0) {
+                g_busy[pick] = true;
+                slot = pick;
+                a = &g_pool[pick];
+                break;
+            }
+            pthread_cond_wait(&g_pool_free, &g_pool_lock);
+        }
+        pthread_mutex_unlock(&g_pool_lock);
+    }
+    ~ArenaLease() {
+        pthread_mutex_lock(&g_pool_lock);
+        g_busy[slot] = false;
+        pthread_cond_signal(&g_pool_free);
+        pthread_mutex_unlock(&g_pool_lock);
+    }
+    Arena *operator->() { return a; }
+};
 } // namespace
 
 int mjx_release_thread_cache(void) {
-    g_arena.release();
+    pthread_mutex_lock(&g_pool_lock);
+    for(int i = 0; i < kMaxArenas; ++i) {
+        if(!g_busy[i]) g_pool[i].release();
+    }
+    pthread_mutex_unlock(&g_pool_lock);
     return MJX_OK;
 }
 
@@ -393,10 +451,11 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     const int    nq = (int)jobs.size();
     const size_t packet_cap = round256(2 * jobs.size() * sizeof(DevJob)) + round256((size_t)nq * 64 * 6) +
                               round256(((size_t)data_bytes / (kWaveBlocks * 128 * 2) + 4 * jobs.size() + 16) * sizeof(Run));
-    int err = g_arena.prepare(packet_cap + data_bytes, packet_cap);
+    ArenaLease arena;
+    int        err = arena->prepare(packet_cap + data_bytes, packet_cap);
     if(err != MJX_OK) return err;
-    hipStream_t s = g_arena.stream;
-    char       *base = g_arena.dev;
+    hipStream_t s = arena->stream;
+    char       *base = arena->dev;
 
     // second pass: real device addresses, uploads
     size_t off = packet_cap, k = 0;
@@ -430,11 +489,11 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     const size_t o_jobs = 0, o_runs = round256(t.jobs.size() * sizeof(DevJob)), o_q = o_runs + round256(t.runs.size() * sizeof(Run)),
                  o_rq = o_q + round256((size_t)nq * 128), packet = o_rq + round256((size_t)nq * 256);
     if(packet > packet_cap) return MJX_ERR_BAD_ARG; // cannot happen for rectangles below 2^24 blocks
-    memcpy(g_arena.pin + o_jobs, t.jobs.data(), t.jobs.size() * sizeof(DevJob));
-    memcpy(g_arena.pin + o_runs, t.runs.data(), t.runs.size() * sizeof(Run));
-    memcpy(g_arena.pin + o_q, qt.data(), (size_t)nq * 128);
-    memcpy(g_arena.pin + o_rq, t.rq.data(), (size_t)nq * 256);
-    MJX_HIP(hipMemcpyAsync(base, g_arena.pin, packet, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    memcpy(arena->pin + o_jobs, t.jobs.data(), t.jobs.size() * sizeof(DevJob));
+    memcpy(arena->pin + o_runs, t.runs.data(), t.runs.size() * sizeof(Run));
+    memcpy(arena->pin + o_q, qt.data(), (size_t)nq * 128);
+    memcpy(arena->pin + o_rq, t.rq.data(), (size_t)nq * 256);
+    MJX_HIP(hipMemcpyAsync(base, arena->pin, packet, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
 
     err = launch_compose(reinterpret_cast<const DevJob *>(base + o_jobs), reinterpret_cast<const Run *>(base + o_runs), (int)t.runs.size(),
                          reinterpret_cast<const uint16_t *>(base + o_q), reinterpret_cast<const float *>(base + o_rq), s);
@@ -570,19 +629,20 @@ int mjx_effect_dc_host(int16_t *plane, int blocks_per_row, int rows, int cols, u
     if(q0 == 0) return MJX_ERR_BAD_ARG;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
     const size_t n = (size_t)rows * (size_t)cols, bytes = round256(n * sizeof(int16_t));
-    int          err = g_arena.prepare(bytes, bytes);
+    ArenaLease   arena;
+    int          err = arena->prepare(bytes, bytes);
     if(err != MJX_OK) return err;
-    int16_t *stage = reinterpret_cast<int16_t *>(g_arena.pin);
+    int16_t *stage = reinterpret_cast<int16_t *>(arena->pin);
     for(int r = 0; r < rows; ++r) {
         const int16_t *src = plane + (size_t)r * (size_t)blocks_per_row * 64;
         int16_t       *dst = stage + (size_t)r * (size_t)cols;
         for(int c = 0; c < cols; ++c) dst[c] = src[(size_t)c * 64];
     }
-    hipStream_t s = g_arena.stream;
-    MJX_HIP(hipMemcpyAsync(g_arena.dev, stage, n * sizeof(int16_t), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-    err = launch_effect_dc_vector(reinterpret_cast<int16_t *>(g_arena.dev), n, q0, rq_of(q0), value, s);
+    hipStream_t s = arena->stream;
+    MJX_HIP(hipMemcpyAsync(arena->dev, stage, n * sizeof(int16_t), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    err = launch_effect_dc_vector(reinterpret_cast<int16_t *>(arena->dev), n, q0, rq_of(q0), value, s);
     if(err != MJX_OK) return err;
-    MJX_HIP(hipMemcpyAsync(stage, g_arena.dev, n * sizeof(int16_t), hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipMemcpyAsync(stage, arena->dev, n * sizeof(int16_t), hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
     MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
     for(int r = 0; r < rows; ++r) {
         int16_t       *dst = plane + (size_t)r * (size_t)blocks_per_row * 64;
@@ -600,13 +660,14 @@ int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols,
     if(plane == nullptr) return MJX_ERR_NULL_DATA;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
     const size_t bytes = (size_t)rows * (size_t)blocks_per_row * 128;
-    int          err = g_arena.prepare(bytes, 256);
+    ArenaLease   arena;
+    int          err = arena->prepare(bytes, 256);
     if(err != MJX_OK) return err;
-    hipStream_t s = g_arena.stream;
-    MJX_HIP(hipMemcpyAsync(g_arena.dev, plane, bytes, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-    err = launch_effect_zero(reinterpret_cast<int16_t *>(g_arena.dev), blocks_per_row, rows, cols, keep_dc ? 1 : 0, s);
+    hipStream_t s = arena->stream;
+    MJX_HIP(hipMemcpyAsync(arena->dev, plane, bytes, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    err = launch_effect_zero(reinterpret_cast<int16_t *>(arena->dev), blocks_per_row, rows, cols, keep_dc ? 1 : 0, s);
     if(err != MJX_OK) return err;
-    MJX_HIP(hipMemcpyAsync(plane, g_arena.dev, bytes, hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipMemcpyAsync(plane, arena->dev, bytes, hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
     MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
     return MJX_OK;
 }
