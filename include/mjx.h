@@ -162,6 +162,41 @@ int mjx_effect_dc_host(int16_t *plane, int blocks_per_row, int rows, int cols, u
 int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc);
 int mjx_convolve_host(const float *x, float *y, float w, int k, int l, int nblocks);
 
+/* ---- baseline Huffman entropy encoder (write side) ------------------
+ * Encodes the entropy-coded segment of ONE sequential (baseline) JPEG scan - all components
+ * interleaved, or the single component of a grayscale image - exactly as libjpeg's
+ * jpeg_write_coefficients() does with fixed Huffman tables (jctrans.c compress_output +
+ * jchuff.c encode_mcu_huff): MCU order, dummy blocks at the right/bottom edge (AC zero, DC of
+ * the previous block), DC prediction, run-length/size symbols with ZRL and EOB, 0xFF00 byte
+ * stuffing, final padding with 1-bits.  The caller supplies the coefficient planes (HOST), the
+ * geometry and the derived code tables; markers (headers, EOI) stay with the caller. */
+typedef struct mjx_huff_table {
+    uint32_t code[256]; /* Huffman code of symbol s, right-aligned */
+    uint8_t  size[256]; /* its length in bits, 0 = symbol not in the table */
+} mjx_huff_table_t;
+
+typedef struct mjx_huff_component {
+    const int16_t *plane;           /* HOST: int16[rows][blocks_per_row][64], natural order */
+    int32_t        blocks_per_row;  /* array pitch in blocks (>= width_in_blocks) */
+    int32_t        width_in_blocks; /* true size: blocks beyond it inside an MCU are dummies */
+    int32_t        height_in_blocks;
+    int32_t        h_samp, v_samp;  /* blocks per MCU in x and y (1,1 for a single-component scan) */
+    int32_t        dc_tbl, ac_tbl;  /* indices into dc[] / ac[] */
+} mjx_huff_component_t;
+
+typedef struct mjx_huff_scan {
+    int32_t                 ncomp;          /* 1..4 */
+    int32_t                 mcus_x, mcus_y; /* MCUs per row / MCU rows */
+    mjx_huff_component_t    comp[4];
+    const mjx_huff_table_t *dc[4];
+    const mjx_huff_table_t *ac[4];
+    int32_t                 max_coef_bits;  /* 10 for 8-bit JPEG: larger categories are an error as in libjpeg */
+} mjx_huff_scan_t;
+
+/* *out is malloc()ed (caller free()s); returns MJX_ERR_BAD_ARG when a coefficient does not fit
+ * the JPEG symbol alphabet (libjpeg: JERR_BAD_DCT_COEF) or a needed symbol has no code. */
+int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char **out, size_t *outlen);
+
 /* ---- synthetic workload generators (bench / test support; definition: mjx_synth.h) ------ */
 int mjx_synth_coef(int16_t *dst /* DEVICE */, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks,
                    const uint16_t *q /* HOST[64] */, mjx_stream_t stream);

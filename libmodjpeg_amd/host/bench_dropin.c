@@ -47,6 +47,13 @@ static unsigned char *make_jpeg(int w, int h, uint32_t seed, unsigned long *len)
     c.in_color_space = JCS_RGB;
     jpeg_set_defaults(&c);
     jpeg_set_quality(&c, 85, TRUE);
+    { /* BENCH_SAMPLING = 420 (default) | 422 | 444 | 440 | gray */
+        const char *sm = getenv("BENCH_SAMPLING");
+        if(sm != NULL && strcmp(sm, "gray") == 0) jpeg_set_colorspace(&c, JCS_GRAYSCALE);
+        else if(sm != NULL && strcmp(sm, "444") == 0) c.comp_info[0].h_samp_factor = c.comp_info[0].v_samp_factor = 1;
+        else if(sm != NULL && strcmp(sm, "422") == 0) c.comp_info[0].v_samp_factor = 1;
+        else if(sm != NULL && strcmp(sm, "440") == 0) c.comp_info[0].h_samp_factor = 1;
+    }
     jpeg_start_compress(&c, TRUE);
     for(y = 0; y < h; y++) {
         for(x = 0; x < w; x++) {
@@ -152,7 +159,11 @@ int main(int argc, char **argv) {
         free(out);
         p_mj_free_jpeg(&m);
     }
-    printf("{\"lib\": \"%s\", \"images\": %d, \"size\": \"%dx%d\", \"dropon\": \"%dx%d\", \"read_ms\": %.4f, \"compose_ms\": %.4f, \"effects_ms\": %.4f, "
+    {
+        const int *cnt = (const int *)dlsym(lib, "mjh_gpu_encode_count");
+        printf("{\"gpu_encodes\": %d, ", cnt != NULL ? *cnt : -1);
+    }
+    printf("\"lib\": \"%s\", \"images\": %d, \"size\": \"%dx%d\", \"dropon\": \"%dx%d\", \"read_ms\": %.4f, \"compose_ms\": %.4f, \"effects_ms\": %.4f, "
            "\"write_ms\": %.4f, \"out_bytes\": %zu, \"fnv1a\": \"%016llx\"}\n",
            argv[1], n, w, h, dw, dh, t_read / n, t_compose / n, t_fx / n, t_write / n, outbytes, (unsigned long long)hash);
     for(i = 0; i < n; i++) free(in[i]);

@@ -123,12 +123,11 @@ static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int til
     memset(rect, 0, sizeof(rect));
     for(c = 0; c < n && rv == MJ_OK; c++) {
         jpeg_component_info *ci = &m->cinfo.comp_info[c];
-        const int            bpr = (int)ci->width_in_blocks;
+        int                  bpr = mjh_row_pitch(m, c);
         int16_t             *plane;
 
         rect[c].rows = ct[c].rows;
         rect[c].cols = ct[c].cols;
-        rect[c].blocks_per_row = bpr;
         rect[c].col0 = block_x * ci->h_samp_factor; /* compose.c:264 */
         row0[c] = block_y * ci->v_samp_factor;      /* compose.c:265 */
         rect[c].flags = tiles_on_device ? MJX_RECT_TILES_ON_DEVICE : 0;
@@ -136,8 +135,9 @@ static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int til
             rect[c].rows = rect[c].cols = 0;
             continue;
         }
-        /* the reference would walk off the coefficient array here (libjpeg error / overrun) */
-        if(rect[c].col0 + rect[c].cols > bpr || row0[c] + rect[c].rows > (int)ci->height_in_blocks || ci->quant_table == NULL) {
+        /* like the reference, tiles may reach into the array's MCU padding; beyond the array the
+         * reference runs into a libjpeg virtual-array error */
+        if(rect[c].col0 + rect[c].cols > bpr || row0[c] + rect[c].rows > mjh_row_count(m, c) || ci->quant_table == NULL) {
             rv = MJ_ERR_DROPON_DIMENSIONS;
             break;
         }
@@ -149,7 +149,8 @@ static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int til
         rect[c].q = q[c];
         rect[c].tile = ct[c].tile;
         rect[c].alpha = ct[c].alpha;
-        plane = mjh_plane_direct(m, c);
+        plane = mjh_plane_direct(m, c, &bpr); /* bpr becomes the array pitch (whole MCUs) */
+        rect[c].blocks_per_row = bpr;
         if(plane != NULL) {
             rect[c].rows_ptr = plane + (size_t)row0[c] * (size_t)bpr * 64;
         }

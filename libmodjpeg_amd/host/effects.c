@@ -17,12 +17,15 @@ static int on_component(mj_jpeg_t *m, int c, plane_op_t op, int arg) {
     int                  rv;
 
     if(rows == 0 || cols == 0) return MJ_OK;
-    plane = mjh_plane_direct(m, c); /* libjpeg keeps a plane of this size in one chunk: no copy */
-    if(plane != NULL) return op(plane, cols, rows, cols, ci, arg);
-    plane = (int16_t *)malloc((size_t)rows * (size_t)cols * sizeof(JBLOCK));
+    {
+        int pitch = 0; /* libjpeg keeps a plane of this size in one chunk: work on it in place */
+        plane = mjh_plane_direct(m, c, &pitch);
+        if(plane != NULL) return op(plane, pitch, rows, cols, ci, arg);
+    }
+    plane = (int16_t *)malloc((size_t)rows * (size_t)mjh_row_pitch(m, c) * sizeof(JBLOCK));
     if(plane == NULL) return MJ_ERR_MEMORY;
     mjh_rows_gather(m, c, 0, rows, plane);
-    rv = op(plane, cols, rows, cols, ci, arg);
+    rv = op(plane, mjh_row_pitch(m, c), rows, cols, ci, arg);
     if(rv == MJ_OK) mjh_rows_scatter(m, c, 0, rows, plane);
     free(plane);
     return rv;

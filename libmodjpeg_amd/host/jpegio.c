@@ -161,6 +161,13 @@ int mj_write_jpeg_to_memory(mj_jpeg_t *m, unsigned char **memory, size_t *len, i
     if(m == NULL || memory == NULL || len == NULL) return MJ_ERR_NULL_DATA;
     if(m->coef == NULL) return MJ_ERR_NULL_DATA;
 
+    /* fixed tables, sequential: the entropy-coded segment is produced on the GPU, byte-identical
+     * to libjpeg's (MJ_GPU_ENCODE=0 keeps everything in libjpeg) */
+    if(options == MJ_OPTION_NONE && !(getenv("MJ_GPU_ENCODE") != NULL && getenv("MJ_GPU_ENCODE")[0] == '0')) {
+        const int rv = mjh_write_gpu_entropy(m, memory, len);
+        if(rv != MJH_ENCODE_UNSUPPORTED) return rv;
+    }
+
     mjh_trap_install(&trap, (j_common_ptr)&out);
     /* jpeg_write_coefficients reads the source's virtual arrays: errors there unwind here too */
     mjh_trap_install(&src_trap, (j_common_ptr)&m->cinfo);
@@ -314,11 +321,12 @@ static JBLOCKROW coef_row(mj_jpeg_t *m, int c, int row, boolean writable) {
     return a[0];
 }
 
-int16_t *mjh_plane_direct(mj_jpeg_t *m, int c) {
+int16_t *mjh_plane_direct(mj_jpeg_t *m, int c, int *pitch) {
     const jpeg_component_info *ci = &m->cinfo.comp_info[c];
-    const size_t               row_blocks = (size_t)ci->width_in_blocks;
-    JBLOCKROW                  first, prev;
-    JDIMENSION                 r;
+    /* what jdcoefct.c asked the memory manager for: rows of whole MCUs */
+    const size_t row_blocks = (size_t)mjh_row_pitch(m, c);
+    JBLOCKROW    first, prev;
+    JDIMENSION   r;
     if(ci->height_in_blocks == 0) return NULL;
     first = prev = coef_row(m, c, 0, TRUE);
     for(r = 1; r < ci->height_in_blocks; r++) {
@@ -326,17 +334,30 @@ int16_t *mjh_plane_direct(mj_jpeg_t *m, int c) {
         if(cur != prev + row_blocks) return NULL;
         prev = cur;
     }
+    *pitch = (int)row_blocks;
     return (int16_t *)first;
 }
 
+/* blocks per array row: jdcoefct.c allocates whole MCUs (the blocks beyond width_in_blocks hold
+ * the file's own edge padding and are addressable, which mj_compose relies on for overlays that
+ * end in the last, partial MCU) */
+int mjh_row_pitch(const mj_jpeg_t *m, int c) {
+    const jpeg_component_info *ci = &m->cinfo.comp_info[c];
+    return (int)(((size_t)ci->width_in_blocks + (size_t)ci->h_samp_factor - 1) / (size_t)ci->h_samp_factor * (size_t)ci->h_samp_factor);
+}
+int mjh_row_count(const mj_jpeg_t *m, int c) {
+    const jpeg_component_info *ci = &m->cinfo.comp_info[c];
+    return (int)(((size_t)ci->height_in_blocks + (size_t)ci->v_samp_factor - 1) / (size_t)ci->v_samp_factor * (size_t)ci->v_samp_factor);
+}
+
 void mjh_rows_gather(mj_jpeg_t *m, int c, int row0, int nrows, int16_t *dst) {
-    const size_t row_bytes = (size_t)m->cinfo.comp_info[c].width_in_blocks * sizeof(JBLOCK);
+    const size_t row_bytes = (size_t)mjh_row_pitch(m, c) * sizeof(JBLOCK);
     int          r;
     for(r = 0; r < nrows; r++) memcpy((char *)dst + (size_t)r * row_bytes, coef_row(m, c, row0 + r, FALSE), row_bytes);
 }
 
 void mjh_rows_scatter(mj_jpeg_t *m, int c, int row0, int nrows, const int16_t *src) {
-    const size_t row_bytes = (size_t)m->cinfo.comp_info[c].width_in_blocks * sizeof(JBLOCK);
+    const size_t row_bytes = (size_t)mjh_row_pitch(m, c) * sizeof(JBLOCK);
     int          r;
     for(r = 0; r < nrows; r++) memcpy(coef_row(m, c, row0 + r, TRUE), (const char *)src + (size_t)r * row_bytes, row_bytes);
 }

@@ -39,14 +39,24 @@ int mjh_pixels_to_jpeg(unsigned char **out, size_t *outlen, unsigned char *pixel
 /* JPEG -> pixels in the wanted MJ_COLORSPACE_{RGB,YCC,GRAYSCALE} (reference image.c:349-451) */
 int mjh_jpeg_to_pixels(unsigned char **pixels, int *width, int *height, int want_colorspace, const unsigned char *jpeg, size_t len);
 
+/* array geometry of component c as libjpeg allocated it (whole MCUs) */
+int mjh_row_pitch(const mj_jpeg_t *m, int c);
+int mjh_row_count(const mj_jpeg_t *m, int c);
+
 /* one component of an mj_jpeg_t copied out of / back into libjpeg's virtual array:
- * rows [row0, row0+nrows) of `blocks_per_row` blocks each, contiguous, 128 bytes per block */
+ * rows [row0, row0+nrows) of mjh_row_pitch() blocks each, contiguous, 128 bytes per block */
 void mjh_rows_gather(mj_jpeg_t *m, int c, int row0, int nrows, int16_t *dst);
 void mjh_rows_scatter(mj_jpeg_t *m, int c, int row0, int nrows, const int16_t *src);
 
-/* whole component plane as one contiguous array inside libjpeg's pool, or NULL when libjpeg
- * split it into several chunks (then the rows are gathered/scattered) */
-int16_t *mjh_plane_direct(mj_jpeg_t *m, int c);
+/* whole component plane as one array inside libjpeg's pool, or NULL when libjpeg split it into
+ * several chunks (then the rows are gathered/scattered).  *pitch = blocks from one row to the
+ * next: libjpeg pads the arrays to whole MCUs (jdcoefct.c), so it can exceed width_in_blocks. */
+int16_t *mjh_plane_direct(mj_jpeg_t *m, int c, int *pitch);
+
+/* mj_write_jpeg_to_memory with the scan data encoded on the GPU (gpuencode.c); returns
+ * MJH_ENCODE_UNSUPPORTED when the file needs libjpeg's own encoder */
+#define MJH_ENCODE_UNSUPPORTED (-1)
+int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len);
 
 /* prepared tiles resident on the device, cached across mj_compose calls (tilecache.c).
  * acquire() sets *out = NULL (and returns MJ_OK) when the cache is disabled or full of busy

@@ -91,7 +91,7 @@ static int jpeg_to_tiles(const unsigned char *memory, size_t len, int is_alpha, 
         t->nblocks = (int)n;
         t->blocks = (mj_block_t **)calloc(n ? n : 1, sizeof(mj_block_t *));
         tiles = (float *)malloc((n ? n : 1) * 64 * sizeof(float));
-        coef = (int16_t *)malloc((n ? n : 1) * 64 * sizeof(int16_t));
+        coef = (int16_t *)malloc(((size_t)hib * (size_t)mjh_row_pitch(&j, c) + 1) * 64 * sizeof(int16_t));
         if(t->blocks == NULL || tiles == NULL || coef == NULL) {
             free(tiles);
             free(coef);
@@ -103,9 +103,9 @@ static int jpeg_to_tiles(const unsigned char *memory, size_t len, int is_alpha, 
             mj_free_jpeg(&j);
             return MJ_ERR_MEMORY;
         }
-        mjh_rows_gather(&j, c, 0, hib, coef);
+        mjh_rows_gather(&j, c, 0, hib, coef); /* rows of mjh_row_pitch() blocks */
         for(b = 0; b < n; b++) {
-            const int16_t *src = coef + b * 64;
+            const int16_t *src = coef + ((b / (size_t)wib) * (size_t)mjh_row_pitch(&j, c) + (b % (size_t)wib)) * 64;
             float         *dst = tiles + b * 64;
             t->blocks[b] = dst;
             if(!is_alpha) {
