@@ -371,17 +371,16 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
     const size_t o_ctot = off;   off += up256((size_t)g2 * 8);
     const size_t o_out = off;    off += up256((size_t)words_cap * 8);
 
-    void *dev = nullptr;
-    MJX_HIP(hipMalloc(&dev, off), MJX_ERR_MEMORY);
-    struct Guard {
-        void *p;
-        ~Guard() { (void)hipFree(p); }
-    } guard{dev};
-    char       *base = static_cast<char *>(dev);
-    hipStream_t s = nullptr;
+    // staging arena from the shared pool: no allocation in steady state, own stream (the NULL
+    // stream would serialise the host threads of a batch against each other)
+    ArenaLease arena;
+    int        err = arena->prepare(off, up256(sizeof(HuffTables)) + 256);
+    if(err != MJX_OK) return err;
+    char       *base = arena->dev;
+    hipStream_t s = arena->stream;
 
-    HuffTables *ht = static_cast<HuffTables *>(calloc(1, sizeof(HuffTables)));
-    if(ht == nullptr) return MJX_ERR_MEMORY;
+    HuffTables *ht = reinterpret_cast<HuffTables *>(arena->pin);
+    memset(ht, 0, sizeof(HuffTables));
     for(int i = 0; i < 4; ++i) {
         if(scan->dc[i]) {
             memcpy(ht->code[i], scan->dc[i]->code, sizeof(ht->code[i]));
@@ -392,10 +391,7 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
             memcpy(ht->size[4 + i], scan->ac[i]->size, sizeof(ht->size[i]));
         }
     }
-    int err = check_hip(hipMemcpyAsync(base + o_tables, ht, sizeof(HuffTables), hipMemcpyHostToDevice, s), "hipMemcpyAsync(tables)", MJX_ERR_LAUNCH);
-    if(err == MJX_OK) err = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
-    free(ht);
-    if(err != MJX_OK) return err;
+    MJX_HIP(hipMemcpyAsync(base + o_tables, ht, sizeof(HuffTables), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
 
     size_t po = o_planes;
     for(int c = 0; c < S.ncomp; ++c) {
@@ -427,14 +423,15 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
     hipLaunchKernelGGL(stuff_write_kernel, dim3(wb), dim3(256), 0, s, d_words, d_misc + 0, words_cap, d_cpre, d_ctot, d_out);
     MJX_HIP(hipGetLastError(), MJX_ERR_LAUNCH);
 
-    unsigned long long misc[3] = {0, 0, 0};
-    MJX_HIP(hipMemcpyAsync(misc, d_misc, sizeof(misc), hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
+    unsigned long long *misc = reinterpret_cast<unsigned long long *>(arena->pin + up256(sizeof(HuffTables)));
+    MJX_HIP(hipMemcpyAsync(misc, d_misc, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
     MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
     if((int)(misc[2] & 0xFFFFFFFFull) != 0) return MJX_ERR_BAD_ARG; // coefficient outside the JPEG alphabet
     const size_t nbytes = (size_t)((misc[0] + 7) >> 3) + (size_t)misc[1];
     unsigned char *buf = static_cast<unsigned char *>(malloc(nbytes ? nbytes : 1));
     if(buf == nullptr) return MJX_ERR_MEMORY;
-    err = check_hip(hipMemcpy(buf, d_out, nbytes, hipMemcpyDeviceToHost), "hipMemcpy(scan data)", MJX_ERR_LAUNCH);
+    err = check_hip(hipMemcpyAsync(buf, d_out, nbytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(scan data)", MJX_ERR_LAUNCH);
+    if(err == MJX_OK) err = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
     if(err != MJX_OK) {
         free(buf);
         return err;

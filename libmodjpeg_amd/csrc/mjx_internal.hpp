@@ -54,6 +54,31 @@ float rq_of(unsigned q);
         if(_e != MJX_OK) return _e;                            \
     } while(0)
 
+// Staging arena of the host-buffer entry points: grow-only device buffer, pinned buffer, stream.
+// No destructor on purpose: the pool is a process-lifetime static and at exit the HIP runtime may
+// already be gone; the driver reclaims the memory with the process.
+struct Arena {
+    int         device = -1;
+    char       *dev = nullptr;
+    size_t      dev_cap = 0;
+    char       *pin = nullptr;
+    size_t      pin_cap = 0;
+    hipStream_t stream = nullptr;
+    void        release();
+    int         prepare(size_t dev_bytes, size_t pin_bytes);
+};
+
+// borrows an arena from the process-wide pool (mjx_runtime.hip) for the lifetime of the object
+struct ArenaLease {
+    Arena *a = nullptr;
+    int    slot = -1;
+    ArenaLease();
+    ~ArenaLease();
+    ArenaLease(const ArenaLease &) = delete;
+    ArenaLease &operator=(const ArenaLease &) = delete;
+    Arena      *operator->() { return a; }
+};
+
 // launchers implemented in the kernel translation units
 int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, hipStream_t s);
 int run_octets();

@@ -276,28 +276,21 @@ struct DevBuf {
     int alloc(size_t bytes) { return check_hip(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc(staging)", MJX_ERR_MEMORY); }
 };
 
+} // namespace
+
+namespace mjx {
 // Grow-only device staging + pinned descriptor buffer + stream.  A service calls mj_compose for
 // image after image of similar size: after the first calls no hipMalloc / hipFree / plan object is
 // involved any more, one packet of descriptors and the plane rows go up, one kernel runs, the
 // rows come back.
-struct Arena {
-    int         device = -1;
-    char       *dev = nullptr;
-    size_t      dev_cap = 0;
-    char       *pin = nullptr;
-    size_t      pin_cap = 0;
-    hipStream_t stream = nullptr;
-
-    void release() {
+void Arena::release() {
         if(dev) (void)hipFree(dev);
         if(pin) (void)hipHostFree(pin);
         if(stream) (void)hipStreamDestroy(stream);
         dev = nullptr; pin = nullptr; stream = nullptr; dev_cap = pin_cap = 0; device = -1;
-    }
-    // no destructor on purpose: the pool is a process-lifetime static, and at exit the HIP runtime
-    // may already be gone; the driver reclaims the memory with the process
+}
 
-    int prepare(size_t dev_bytes, size_t pin_bytes) {
+int Arena::prepare(size_t dev_bytes, size_t pin_bytes) {
         int cur = 0;
         if(int e = check_hip(hipGetDevice(&cur), "hipGetDevice", MJX_ERR_NO_DEVICE)) return e;
         if(cur != device) { // the thread moved to another GPU (mjx_set_device)
@@ -324,8 +317,7 @@ struct Arena {
             pin_cap = want;
         }
         return MJX_OK;
-    }
-};
+}
 // Pool of arenas shared by all host threads.  A per-image call needs the GPU for a fraction of a
 // millisecond out of the ~17 ms a thread spends on one 1080p image (entropy decode/encode on the
 // host), so a handful of arenas serves any number of threads; creating one per thread instead
@@ -338,10 +330,7 @@ pthread_cond_t  g_pool_free = PTHREAD_COND_INITIALIZER;
 
 // borrow an arena that already lives on the calling thread's device if there is one, else an
 // unused slot; blocks while all slots are busy
-struct ArenaLease {
-    Arena *a = nullptr;
-    int    slot = -1;
-    ArenaLease() {
+ArenaLease::ArenaLease() {
         int cur = 0;
         (void)hipGetDevice(&cur);
         pthread_mutex_lock(&g_pool_lock);
@@ -369,15 +358,17 @@ struct ArenaLease {
             pthread_cond_wait(&g_pool_free, &g_pool_lock);
         }
         pthread_mutex_unlock(&g_pool_lock);
-    }
-    ~ArenaLease() {
+}
+
+ArenaLease::~ArenaLease() {
         pthread_mutex_lock(&g_pool_lock);
         g_busy[slot] = false;
         pthread_cond_signal(&g_pool_free);
         pthread_mutex_unlock(&g_pool_lock);
-    }
-    Arena *operator->() { return a; }
-};
+}
+} // namespace mjx
+
+namespace {
 } // namespace
 
 int mjx_release_thread_cache(void) {
