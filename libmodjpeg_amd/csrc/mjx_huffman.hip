@@ -178,10 +178,14 @@ __global__ __launch_bounds__(kHuffThreads) void huff_length_kernel(HuffScan S, c
 }
 
 __global__ __launch_bounds__(kHuffThreads) void huff_emit_kernel(HuffScan S, const HuffTables *__restrict__ T, long long nslots, const unsigned *__restrict__ local_prefix,
-                                                                  const unsigned long long *__restrict__ group_prefix, int group_items, unsigned *__restrict__ words) {
+                                                                  const unsigned long long *__restrict__ group_prefix, int group_items, unsigned *__restrict__ words,
+                                                                  const int *__restrict__ error) {
     __shared__ __attribute__((aligned(16))) short stage[kHuffThreads][64];
     const long long t = (long long)blockIdx.x * kHuffThreads + threadIdx.x;
     if(t >= nslots) return;
+    // a coefficient outside the JPEG alphabet was seen by the length pass: the host reports the
+    // error, and nothing may be written (such symbols can exceed the per-block bit budget)
+    if(*error != 0) return;
     const Slot sl = decode_slot(S, t);
     stage_block(S, sl, stage[threadIdx.x]);
 
@@ -416,7 +420,7 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
     hipLaunchKernelGGL(huff_length_kernel, dim3(hb), dim3(kHuffThreads), 0, s, S, d_tables, nslots, d_len, d_error);
     hipLaunchKernelGGL(scan_groups_kernel, dim3((unsigned)g1), dim3(kScanThreads), 0, s, d_len, d_lpre, d_gtot, nslots);
     hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, d_gtot, g1, d_misc + 0);
-    hipLaunchKernelGGL(huff_emit_kernel, dim3(hb), dim3(kHuffThreads), 0, s, S, d_tables, nslots, d_lpre, d_gtot, (int)kScanItems, d_words);
+    hipLaunchKernelGGL(huff_emit_kernel, dim3(hb), dim3(kHuffThreads), 0, s, S, d_tables, nslots, d_lpre, d_gtot, (int)kScanItems, d_words, d_error);
     hipLaunchKernelGGL(stuff_count_kernel, dim3(wb), dim3(256), 0, s, d_words, d_misc + 0, words_cap, d_cnt);
     hipLaunchKernelGGL(scan_groups_kernel, dim3((unsigned)g2), dim3(kScanThreads), 0, s, d_cnt, d_cpre, d_ctot, words_cap);
     hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, d_ctot, g2, d_misc + 1);
