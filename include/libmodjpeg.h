@@ -92,14 +92,14 @@ typedef struct {
 typedef float mj_block_t;
 
 typedef struct {
-    int width_in_blocks;
-    int height_in_blocks;
+    int width_in_blocks;  /* tile grid of this component ... */
+    int height_in_blocks; /* ... in 8x8 blocks */
 
-    int h_samp_factor;
+    int h_samp_factor;    /* sampling factors of the target image's component */
     int v_samp_factor;
 
-    int          nblocks;
-    mj_block_t **blocks;
+    int          nblocks; /* width_in_blocks * height_in_blocks */
+    mj_block_t **blocks;  /* blocks[height row * width_in_blocks + column] -> 64 floats */
 } mj_component_t;
 
 /* ---- a JPEG held as quantised DCT coefficients (reference :99-107) ----------------------------- */
@@ -107,59 +107,113 @@ typedef struct {
     struct jpeg_decompress_struct cinfo; /* owns the coefficient arrays (libjpeg memory pool) */
     jvirt_barray_ptr *            coef;  /* from jpeg_read_coefficients() */
 
-    int width;
+    int width;  /* pixels */
     int height;
 
-    mj_sampling_t sampling;
+    mj_sampling_t sampling; /* filled by mj_read_jpeg_* */
 } mj_jpeg_t;
 
 /* ---- an overlay as pixels (reference :109-118): image and alpha both 3 bytes per pixel -------- */
 typedef struct {
-    unsigned char *image;
-    unsigned char *alpha;
+    unsigned char *image; /* width*height*3 samples in `colorspace` (gray replicated) */
+    unsigned char *alpha; /* width*height*3, the alpha value replicated three times */
 
     int width;
     int height;
-    int colorspace;
+    int colorspace;       /* MJ_COLORSPACE_RGB, _YCC or _GRAYSCALE */
 
-    int blend;
+    int blend;            /* MJ_BLEND_NONUNIFORM when the pixels brought their own alpha */
 } mj_dropon_t;
 
 typedef struct {
-    int             image_ncomponents;
-    int             image_colorspace;
-    mj_component_t *image;
+    int             image_ncomponents; /* = components of the target image */
+    int             image_colorspace;  /* J_COLOR_SPACE of the prepared tiles */
+    mj_component_t *image;             /* coefficients of the overlay (quality 100: value == coefficient) */
 
     int             alpha_ncomponents;
-    mj_component_t *alpha;
+    mj_component_t *alpha;             /* alpha DCT coefficients, DC + 1024, scaled by c(v)c(u)/1020 */
 } mj_compileddropon_t;
 
-/* ---- dropons (reference :129-132) ---------------------------------------------------------------- */
+/* ==== functions (reference libmodjpeg.h:129-149): identical names, parameters and results ==== */
+
+/* -- overlays ----------------------------------------------------------------------------------- */
+
+/* zero a caller-owned mj_dropon_t before its first use */
 void mj_init_dropon(mj_dropon_t *d);
-int  mj_read_dropon_from_raw(mj_dropon_t *d, const unsigned char *rawdata, unsigned int colorspace, int width, int height, short blend);
-int  mj_read_dropon_from_memory(mj_dropon_t *d, const unsigned char *memory, size_t len, const unsigned char *maskmemory, size_t masklen, short blend);
-int  mj_read_dropon_from_file(mj_dropon_t *d, const char *filename, const char *maskfilename, short blend);
 
-/* ---- images (reference :134-136) ------------------------------------------------------------------ */
-void mj_init_jpeg(mj_jpeg_t *m);
-int  mj_read_jpeg_from_memory(mj_jpeg_t *m, const unsigned char *memory, size_t len, size_t max_pixel);
-int  mj_read_jpeg_from_file(mj_jpeg_t *m, const char *filename, size_t max_pixel);
+/* take a copy of interleaved pixels; alpha (when the colour space has none) becomes `blend` */
+int mj_read_dropon_from_raw(
+    mj_dropon_t         *d,          /* out: previous contents are freed */
+    const unsigned char *rawdata,    /* width*height pixels, 1..4 bytes each */
+    unsigned int         colorspace, /* MJ_COLORSPACE_* */
+    int                  width,
+    int                  height,
+    short                blend);     /* 0..255, clamped; ignored when the pixels carry alpha */
 
-/* ---- the hot path: alpha-masked overlay in the DCT domain (reference :138) ------------------------ */
-int mj_compose(mj_jpeg_t *m, mj_dropon_t *d, unsigned int align, int offset_x, int offset_y);
+/* JPEG (optionally with a same-sized grayscale JPEG as mask) or PNG, recognised by signature */
+int mj_read_dropon_from_memory(
+    mj_dropon_t         *d,
+    const unsigned char *memory,
+    size_t               len,
+    const unsigned char *maskmemory, /* may be NULL */
+    size_t               masklen,
+    short                blend);
 
-/* ---- output (reference :140-141); the memory variant returns a malloc()ed buffer ------------------- */
-int mj_write_jpeg_to_memory(mj_jpeg_t *m, unsigned char **memory, size_t *len, int options);
-int mj_write_jpeg_to_file(mj_jpeg_t *m, char *filename, int options);
+int mj_read_dropon_from_file(
+    mj_dropon_t *d,
+    const char  *filename,
+    const char  *maskfilename,       /* may be NULL */
+    short        blend);
 
-void mj_free_jpeg(mj_jpeg_t *m);
 void mj_free_dropon(mj_dropon_t *d);
 
-/* ---- per-block effects (reference :146-149) ---------------------------------------------------------- */
-int mj_effect_grayscale(mj_jpeg_t *m);
-int mj_effect_pixelate(mj_jpeg_t *m);
-int mj_effect_tint(mj_jpeg_t *m, int cb_value, int cr_value);
-int mj_effect_luminance(mj_jpeg_t *m, int value);
+/* -- images ------------------------------------------------------------------------------------- */
+
+void mj_init_jpeg(mj_jpeg_t *m);
+
+/* decode the entropy-coded data only: the image is held as quantised coefficients.
+ * max_pixel != 0 rejects images with more pixels (MJ_ERR_IMAGE_SIZE). */
+int mj_read_jpeg_from_memory(
+    mj_jpeg_t           *m,
+    const unsigned char *memory,
+    size_t               len,
+    size_t               max_pixel);
+
+int mj_read_jpeg_from_file(
+    mj_jpeg_t  *m,
+    const char *filename,
+    size_t      max_pixel);
+
+/* *memory is malloc()ed, the caller free()s it; options: MJ_OPTION_* */
+int mj_write_jpeg_to_memory(
+    mj_jpeg_t      *m,
+    unsigned char **memory,
+    size_t         *len,
+    int             options);
+
+int mj_write_jpeg_to_file(
+    mj_jpeg_t *m,
+    char      *filename,
+    int        options);
+
+void mj_free_jpeg(mj_jpeg_t *m);
+
+/* -- the hot path --------------------------------------------------------------------------------- */
+
+/* alpha-masked overlay in the DCT domain: `d` is placed by `align` (MJ_ALIGN_* bits) plus the
+ * pixel offsets, cropped against the image, and blended block by block on the GPU */
+int mj_compose(
+    mj_jpeg_t   *m,
+    mj_dropon_t *d,
+    unsigned int align,
+    int          offset_x,
+    int          offset_y);
+
+/* per-block effects on the coefficients (GPU); the DC effects clamp to +-2047 */
+int mj_effect_grayscale(mj_jpeg_t *m);                         /* YCbCr only: chroma planes to zero */
+int mj_effect_pixelate(mj_jpeg_t *m);                          /* every block keeps only its DC */
+int mj_effect_tint(mj_jpeg_t *m, int cb_value, int cr_value);  /* YCbCr only */
+int mj_effect_luminance(mj_jpeg_t *m, int value);              /* YCbCr only */
 
 #ifdef __cplusplus
 }
