@@ -57,7 +57,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0):
+def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0, timing=True):
     """Oracle compose on `nsample` images of the workload (only the dropon rectangles are
     generated: nothing else is read by the path).  Returns (info dict, expected rect arrays)."""
     import numpy as np
@@ -91,6 +91,8 @@ def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0):
     O.compose_jobs(jobs, cores)
     t_all = time.perf_counter() - t0
     expected = [r.copy() for r in rects]  # one composition from pristine: the parity reference
+    if not timing:
+        return None, expected
 
     # single thread (the reference is single-threaded) on a quarter of the sample, again in place:
     # the work is data-independent
@@ -201,11 +203,17 @@ def main():
     blocks_per_step = batch.total_blocks()
 
     # ---- parity (+ CPU baseline) on a bounded sample: first pass from pristine inputs ----
+    # N == 1: rank 0 times the CPU baseline on `--cpu-sample` images and checks them; N > 1: every
+    # rank checks a few images of its own shard (no CPU timing), the verdict is reduced over ranks
     cpu_info, parity = None, "skipped"
-    nsample = min(args.cpu_sample, images) if (rank == 0 and world == 1) else 0
+    if world == 1:
+        nsample = min(args.cpu_sample, images)
+    else:
+        nsample = min(args.cpu_sample, images, 4)
     expected = None
     if nsample > 0:
-        cpu_info, expected = cpu_baseline_and_expected((width, height, dw, dh, mcu_x, mcu_y), regime, nsample, image0)
+        info, expected = cpu_baseline_and_expected((width, height, dw, dh, mcu_x, mcu_y), regime, nsample, image0, timing=(world == 1))
+        cpu_info = info if world == 1 else None
     batch.run()
     torch.cuda.synchronize()
     if expected is not None:
@@ -215,8 +223,10 @@ def main():
             for c in range(3):
                 if not np.array_equal(batch.rect_numpy(i, c).reshape(-1), expected[3 * i + c]):
                     bad += 1
-        parity = "bit-exact" if bad == 0 else f"MISMATCH in {bad} of {3 * nsample} rectangles"
-        if bad:
+        bad_all = sum_over_ranks(bad, world, "cuda")
+        checked = sum_over_ranks(3 * nsample, world, "cuda")
+        parity = "bit-exact" if bad_all == 0 else f"MISMATCH in {bad_all} of {checked} rectangles"
+        if bad_all:
             print(f"bench.py: GPU output differs from the oracle: {parity}", file=sys.stderr)
             sys.exit(1)
 
