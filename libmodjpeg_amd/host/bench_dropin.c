@@ -119,7 +119,17 @@ int main(int argc, char **argv) {
         }
     mj_dropon_t d;
     p_mj_init_dropon(&d);
-    if((rv = p_mj_read_dropon_from_raw(&d, rgba, MJ_COLORSPACE_RGBA, dw, dh, MJ_BLEND_FULL)) != MJ_OK) return 10 + rv;
+    { /* BENCH_DROPON = rgba (default) | rgb | ycca | gray | graya: the raw colour space handed to the library
+       * (the same bytes reinterpreted; rgb/gray use a uniform blend of 160) */
+        const char  *kind = getenv("BENCH_DROPON");
+        unsigned int cs = MJ_COLORSPACE_RGBA;
+        short        blend = MJ_BLEND_FULL;
+        if(kind != NULL && strcmp(kind, "rgb") == 0) { cs = MJ_COLORSPACE_RGB; blend = 160; }
+        else if(kind != NULL && strcmp(kind, "ycca") == 0) cs = MJ_COLORSPACE_YCCA;
+        else if(kind != NULL && strcmp(kind, "gray") == 0) { cs = MJ_COLORSPACE_GRAYSCALE; blend = 160; }
+        else if(kind != NULL && strcmp(kind, "graya") == 0) cs = MJ_COLORSPACE_GRAYSCALEA;
+        if((rv = p_mj_read_dropon_from_raw(&d, rgba, cs, dw, dh, blend)) != MJ_OK) return 10 + rv;
+    }
 
     unsigned char **in = malloc(sizeof(*in) * (size_t)n);
     unsigned long  *inlen = malloc(sizeof(*inlen) * (size_t)n);

@@ -216,3 +216,24 @@ def test_written_jpegs_byte_identical_to_reference(shim, args):
         a = json.loads(subprocess.check_output([exe, ref, *args], text=True, env=env))
         b = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))  # tile cache: misses, hits, disabled
         assert a["out_bytes"] == b["out_bytes"] and a["fnv1a"] == b["fnv1a"], (a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampling,dropon", [("420", "rgb"), ("420", "ycca"), ("444", "rgb"), ("gray", "gray"), ("gray", "graya"), ("gray", "rgba"), ("420", "gray")])
+def test_dropon_colour_spaces_match_reference(shim, sampling, dropon):
+    """raw dropon colour spaces x target colour spaces: same files, or the same failure, as the
+    reference (a gray dropon is fed to libjpeg with the reference's 3-bytes-as-1 quirk; colour on
+    gray and gray on colour fail in libjpeg's colour conversion for both libraries)"""
+    import json
+    ref = os.path.join(ROOT, "oracle", "_ref", "libmodjpeg_ref.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not present")
+    exe = os.path.join(HOST, "bench_dropin")
+    args = ["200", "120", "48", "40", "2"]
+    env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DROPON=dropon)
+    a = subprocess.run([exe, ref, *args], capture_output=True, text=True, env=env)
+    b = subprocess.run([exe, shim, *args], capture_output=True, text=True, env=env)
+    assert a.returncode == b.returncode, (a.returncode, b.returncode, b.stderr[-500:])
+    if a.returncode == 0:
+        ja, jb = json.loads(a.stdout), json.loads(b.stdout)
+        assert ja["out_bytes"] == jb["out_bytes"] and ja["fnv1a"] == jb["fnv1a"], (ja, jb)
