@@ -8,12 +8,19 @@
  *        image tiles, then alpha tiles (float32).
  *   mjhost_probe roundtrip <image.jpg> <out.bin>
  *        read -> write (optimised, progressive) -> read again; writes both coefficient sets.
+ *   mjhost_probe stress <image.jpg> <dropon.png> <threads> <iterations>
+ *        concurrent mj_compose from many threads with more distinct overlay placements than the
+ *        tile cache has slots (evictions, misses and hits interleave, arenas are shared); every
+ *        result must equal the one a single thread computed for the same placement.  Prints
+ *        "ok" or the number of mismatches.
  *   mjhost_probe nodevice <image.jpg>
  *        prints the return codes of mj_effect_luminance and mj_compose (expects MJ_ERR_MEMORY
  *        on a machine without a GPU: there is no CPU fallback).
  */
 #include <libmodjpeg.h>
 
+#include <pthread.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -33,7 +40,61 @@ static void dump_planes(mj_jpeg_t *m, FILE *f) {
     }
 }
 
+/* ---- stress ---- */
+static unsigned char *g_img;
+static size_t         g_imglen;
+static mj_dropon_t    g_dropon;
+static uint64_t       g_want[12];
+static int            g_iters, g_bad;
+
+static uint64_t compose_hash(int placement) {
+    mj_jpeg_t      m;
+    unsigned char *out = NULL;
+    size_t         len = 0, i;
+    uint64_t       h = 0xcbf29ce484222325ull;
+    mj_init_jpeg(&m);
+    if(mj_read_jpeg_from_memory(&m, g_img, g_imglen, 0) != MJ_OK) return 1;
+    if(mj_compose(&m, &g_dropon, placement & 1 ? MJ_ALIGN_RIGHT : MJ_ALIGN_LEFT, 3 * placement, -2 * placement) != MJ_OK) return 2;
+    if(mj_effect_luminance(&m, placement) != MJ_OK) return 3;
+    if(mj_write_jpeg_to_memory(&m, &out, &len, MJ_OPTION_NONE) != MJ_OK) return 4;
+    for(i = 0; i < len; i++) h = (h ^ out[i]) * 0x100000001b3ull;
+    free(out);
+    mj_free_jpeg(&m);
+    return h;
+}
+
+static void *stress_worker(void *arg) {
+    const int id = (int)(intptr_t)arg;
+    int       k;
+    for(k = 0; k < g_iters; k++) {
+        const int placement = (id * 5 + k * 7) % 12;
+        if(compose_hash(placement) != g_want[placement]) __sync_fetch_and_add(&g_bad, 1);
+    }
+    return NULL;
+}
+
 int main(int argc, char **argv) {
+    if(argc == 6 && strcmp(argv[1], "stress") == 0) {
+        FILE     *f = fopen(argv[2], "rb");
+        int       nthreads = atoi(argv[4]), t;
+        pthread_t th[64];
+        if(f == NULL || nthreads < 1 || nthreads > 64) return 3;
+        fseek(f, 0, SEEK_END);
+        g_imglen = (size_t)ftell(f);
+        fseek(f, 0, SEEK_SET);
+        g_img = malloc(g_imglen);
+        if(fread(g_img, 1, g_imglen, f) != g_imglen) return 3;
+        fclose(f);
+        mj_init_dropon(&g_dropon);
+        if(mj_read_dropon_from_file(&g_dropon, argv[3], NULL, MJ_BLEND_FULL) != MJ_OK) return 4;
+        g_iters = atoi(argv[5]);
+        for(t = 0; t < 12; t++) g_want[t] = compose_hash(t);
+        for(t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, stress_worker, (void *)(intptr_t)t);
+        for(t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        if(g_bad == 0) printf("ok\n");
+        else printf("%d mismatches\n", g_bad);
+        return g_bad != 0;
+    }
     if(argc >= 2 && strcmp(argv[1], "tiles") == 0 && argc == 15) {
         mj_jpeg_t           m;
         mj_dropon_t         d;

@@ -237,3 +237,12 @@ def test_dropon_colour_spaces_match_reference(shim, sampling, dropon):
     if a.returncode == 0:
         ja, jb = json.loads(a.stdout), json.loads(b.stdout)
         assert ja["out_bytes"] == jb["out_bytes"] and ja["fnv1a"] == jb["fnv1a"], (ja, jb)
+
+
+@pytest.mark.gpu
+def test_concurrent_compose_with_cache_evictions(shim):
+    """16 threads, 12 overlay placements (> 8 cache slots), shared arenas: every result equals the
+    single-threaded one for the same placement"""
+    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "stress", os.path.join(IMAGES, "image.jpg"), os.path.join(IMAGES, "dropon.png"), "16", "40"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0 and res.stdout.strip() == "ok", (res.stdout, res.stderr[-500:])
