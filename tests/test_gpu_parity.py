@@ -211,3 +211,47 @@ def test_host_buffer_entry_point(mj):
     want = plane.copy()
     O.compose_rect(want, wib, row0, col0, rows, cols, q, tile, alpha)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("family", ["bitpattern", "denormal", "huge_q", "mixed_sparse"])
+def test_fuzz_blocks_vs_oracle(mj, family):
+    """large randomised differential test on adversarial inputs: raw random float bit patterns
+    (NaN, Inf, denormals, huge magnitudes) for tiles and weights, full-range int16 coefficients,
+    quantisers up to 65535, random sparsity patterns (each block its own) -- GPU == oracle"""
+    rng = np.random.default_rng(abs(hash(family)) % (2**32))
+    rows, cols = 96, 100  # 9600 blocks per plane, cols not a multiple of 8
+    n = rows * cols
+    q = rng.integers(1, 256, 64).astype(np.uint16)
+    coef = rng.integers(-2048, 2048, (n, 64)).astype(np.int16)
+    tile = np.round(rng.standard_normal((n, 64)) * 200).astype(np.float32)
+    alpha = (rng.standard_normal((n, 64)) * 0.05).astype(np.float32)
+    if family == "bitpattern":
+        tile = rng.integers(0, 2**32, (n, 64), dtype=np.uint64).astype(np.uint32).view(np.float32)
+        alpha = np.where(rng.random((n, 64)) < 0.3, rng.integers(0, 2**32, (n, 64), dtype=np.uint64).astype(np.uint32).view(np.float32), np.float32(0))
+        coef = rng.integers(-32768, 32768, (n, 64)).astype(np.int16)
+    elif family == "denormal":
+        alpha = (rng.standard_normal((n, 64)) * 1e-40).astype(np.float32)  # denormal weights are not skipped
+        alpha[:, 0] = 0.25
+        tile = (rng.standard_normal((n, 64)) * 1e-38).astype(np.float32)
+    elif family == "huge_q":
+        q = rng.integers(1, 65536, 64).astype(np.uint16)
+        coef = rng.integers(-32768, 32768, (n, 64)).astype(np.int16)
+    else:  # every block its own sparsity pattern, signed zeros included
+        keep = rng.random((n, 64)) < rng.random((n, 1)) * 0.5
+        alpha = np.where(keep, alpha, np.float32(0))
+        alpha[rng.random((n, 64)) < 0.05] = np.float32(-0.0)
+    tile, alpha = np.ascontiguousarray(tile, np.float32), np.ascontiguousarray(alpha, np.float32)
+    m = mj.Jpeg([_t(coef.reshape(rows, cols, 64))], [q], samp=[(1, 1)], colorspace=mj.JCS_GRAYSCALE)
+    cd = mj.CompiledDropon([mj.Component(_t(tile), cols, rows)], [mj.Component(_t(alpha), cols, rows)])
+    assert mj.mj_compose_with_mask(m, cd, 0, 0) == mj.MJ_OK
+    want = coef.reshape(-1).copy()
+    import os
+    nthreads = min(16, os.cpu_count() or 1)
+    step = rows // nthreads + 1
+    jobs = []
+    for r0 in range(0, rows, step):
+        r1 = min(rows, r0 + step)
+        jobs.append((want[r0 * cols * 64:r1 * cols * 64], cols, 0, 0, r1 - r0, cols, q, tile[r0 * cols:r1 * cols].reshape(-1), alpha[r0 * cols:r1 * cols].reshape(-1)))
+    O.compose_jobs(jobs, nthreads)
+    got = m.planes_numpy()[0].reshape(-1)
+    assert np.array_equal(got, want), (family, int((got != want).sum()))
