@@ -197,6 +197,42 @@ typedef struct mjx_huff_scan {
  * the JPEG symbol alphabet (libjpeg: JERR_BAD_DCT_COEF) or a needed symbol has no code. */
 int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char **out, size_t *outlen);
 
+/* ---- baseline Huffman entropy decoder (row f-4, read side) --------------------------------
+ * Decodes the entropy-coded segment of one sequential interleaved (or single-component) scan into
+ * coefficient planes, as libjpeg's jpeg_read_coefficients() does (jdhuff.c decode_mcu): every block
+ * slot of every MCU is stored, including the padding blocks of partial MCUs, into arrays of
+ * mcus_x*h_samp by mcus_y*v_samp blocks.  The bitstream is sequential; it is cut into fixed-size
+ * chunks that are decoded speculatively and re-synchronised iteratively until every chunk starts
+ * exactly where its predecessor ended (self-synchronisation of Huffman codes), then decoded once
+ * more for real.  `data` is the scan data with the 0xFF00 stuffing and the RSTn markers removed. */
+typedef struct mjx_huff_spec {
+    uint8_t bits[16];  /* number of codes of length 1..16 (DHT) */
+    uint8_t vals[256]; /* symbols in code order */
+} mjx_huff_spec_t;
+
+typedef struct mjx_huff_dcomponent {
+    int16_t *plane;          /* HOST, out: int16[mcus_y*v_samp][blocks_per_row][64], written whole (pitch padding = 0) */
+    int32_t  blocks_per_row; /* >= mcus_x*h_samp */
+    int32_t  h_samp, v_samp;
+    int32_t  dc_tbl, ac_tbl;
+} mjx_huff_dcomponent_t;
+
+typedef struct mjx_huff_dscan {
+    int32_t                ncomp, mcus_x, mcus_y;
+    mjx_huff_dcomponent_t  comp[4];
+    const mjx_huff_spec_t *dc[4];
+    const mjx_huff_spec_t *ac[4];
+    const uint8_t         *data;             /* HOST: unstuffed entropy-coded bytes */
+    size_t                 nbytes;
+    int32_t                restart_interval; /* MCUs per restart segment, 0 = one segment */
+    const uint64_t        *segment_offsets;  /* byte offset of every restart segment in `data` (NULL: one segment at 0) */
+    int32_t                nsegments;
+} mjx_huff_dscan_t;
+
+/* MJX_ERR_BAD_ARG when the stream is not a valid baseline scan of this geometry (the caller then
+ * uses its ordinary decoder). */
+int mjx_huff_decode_host(const mjx_huff_dscan_t *scan);
+
 /* ---- synthetic workload generators (bench / test support; definition: mjx_synth.h) ------ */
 int mjx_synth_coef(int16_t *dst /* DEVICE */, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks,
                    const uint16_t *q /* HOST[64] */, mjx_stream_t stream);

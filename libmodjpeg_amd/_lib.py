@@ -74,6 +74,7 @@ SYMBOLS = [
     ("mjx_dc_plan_run", _i, [_vp, _vp]),
     ("mjx_effect_zero", _i, [_vp, _i, _i, _i, _i, _vp]),
     ("mjx_huff_encode_host", _i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
+    ("mjx_huff_decode_host", _i, [_vp]),
     ("mjx_synth_coef", _i, [_vp, _u64, _u32, _u64, _sz, _vp, _vp]),
     ("mjx_synth_tile", _i, [_vp, _u64, _u32, _u64, _sz, _vp]),
     ("mjx_synth_alpha", _i, [_vp, _u64, _u32, _u64, _sz, _i, _vp]),

@@ -262,6 +262,16 @@ __global__ __launch_bounds__(kScanThreads) void scan_totals_kernel(unsigned long
     if(threadIdx.x == 0) *grand = carry;
 }
 
+// exclusive scan of n unsigned values: out[i] (relative to its group of kScanItems) + totals[i / kScanItems]
+// is the exclusive prefix of element i; *grand receives the sum.  totals needs scan_group_count(n) slots.
+int        scan_group_items() { return kScanItems; }
+long long  scan_group_count(long long n) { return (n + kScanItems - 1) / kScanItems; }
+void       launch_scan_exclusive(const unsigned *in, unsigned *out, unsigned long long *totals, long long n, unsigned long long *grand, hipStream_t s) {
+    const long long g = scan_group_count(n);
+    hipLaunchKernelGGL(scan_groups_kernel, dim3((unsigned)g), dim3(kScanThreads), 0, s, in, out, totals, n);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, g, grand);
+}
+
 // ---- byte stuffing ---------------------------------------------------------------------
 __device__ __forceinline__ unsigned padded_word(const unsigned *words, unsigned long long w, unsigned long long total_bits, int &nbytes) {
     // bytes of the stream held by word w (big-endian), the final partial byte padded with 1-bits

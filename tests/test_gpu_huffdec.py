@@ -1,0 +1,212 @@
+"""GPU Huffman decoder through the C ABI (mjx_huff_decode_host): round trips against the encoder
+of the same ABI and against the pure-Python restatement of ITU-T T.81 F.1.2 in
+tests/test_gpu_huffman.py (which also writes restart segments here).  The parity with libjpeg's own
+jpeg_read_coefficients() on real files is in tests/test_dropin_shim.py."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_huffman import AC_BITS, AC_VALS, DC_BITS, DC_VALS, ZIGZAG, derive, gpu_encode
+
+pytestmark = pytest.mark.gpu
+
+
+class HuffSpec(ctypes.Structure):
+    _fields_ = [("bits", ctypes.c_uint8 * 16), ("vals", ctypes.c_uint8 * 256)]
+
+
+class DComponent(ctypes.Structure):
+    _fields_ = [("plane", ctypes.c_void_p), ("blocks_per_row", ctypes.c_int32), ("h_samp", ctypes.c_int32), ("v_samp", ctypes.c_int32),
+                ("dc_tbl", ctypes.c_int32), ("ac_tbl", ctypes.c_int32)]
+
+
+class DScan(ctypes.Structure):
+    _fields_ = [("ncomp", ctypes.c_int32), ("mcus_x", ctypes.c_int32), ("mcus_y", ctypes.c_int32), ("comp", DComponent * 4),
+                ("dc", ctypes.POINTER(HuffSpec) * 4), ("ac", ctypes.POINTER(HuffSpec) * 4), ("data", ctypes.c_void_p), ("nbytes", ctypes.c_size_t),
+                ("restart_interval", ctypes.c_int32), ("segment_offsets", ctypes.c_void_p), ("nsegments", ctypes.c_int32)]
+
+
+def spec(bits, vals):
+    s = HuffSpec()
+    for i, b in enumerate(bits):
+        s.bits[i] = b
+    for i, v in enumerate(vals):
+        s.vals[i] = v
+    return s
+
+
+def unstuff(data):
+    """stuffed scan data -> (unstuffed bytes, segment offsets); RSTn markers split segments"""
+    out, segs, i = bytearray(), [0], 0
+    while i < len(data):
+        b = data[i]
+        if b == 0xFF:
+            nxt = data[i + 1]
+            if nxt == 0:
+                out.append(0xFF)
+            else:
+                assert 0xD0 <= nxt <= 0xD7
+                segs.append(len(out))
+            i += 2
+        else:
+            out.append(b)
+            i += 1
+    return bytes(out), segs
+
+
+def gpu_decode(data, segs, geom, mcus_x, mcus_y, restart=0, pitch_extra=0, tables=None):
+    """geom[c] = (hs, vs); returns rc, planes[c] int16[mcus_y*vs, bpr, 64]"""
+    import torch  # noqa: F401
+    from libmodjpeg_amd._lib import lib
+    sc = DScan()
+    sc.ncomp, sc.mcus_x, sc.mcus_y, sc.restart_interval = len(geom), mcus_x, mcus_y, restart
+    planes = []
+    for c, (hs, vs) in enumerate(geom):
+        p = np.full((mcus_y * vs, mcus_x * hs + pitch_extra, 64), 0x5555, np.int16)
+        planes.append(p)
+        sc.comp[c] = DComponent(p.ctypes.data, p.shape[1], hs, vs, 0, 0)
+    dc, ac = tables or (spec(DC_BITS, DC_VALS), spec(AC_BITS, AC_VALS))
+    sc.dc[0], sc.ac[0] = ctypes.pointer(dc), ctypes.pointer(ac)
+    buf = np.frombuffer(data, np.uint8).copy()
+    sc.data, sc.nbytes = buf.ctypes.data, len(data)
+    offs = np.asarray(segs, np.uint64)
+    if len(segs) > 1 or restart:
+        sc.segment_offsets, sc.nsegments = offs.ctypes.data, len(segs)
+    rc = lib().mjx_huff_decode_host(ctypes.byref(sc))
+    return rc, planes
+
+
+def random_planes(rng, geom, mcus_x, mcus_y, density, amplitude):
+    planes = []
+    for (hs, vs) in geom:
+        p = np.zeros((mcus_y * vs, mcus_x * hs, 64), np.int16)
+        mask = rng.random(p.shape) < density
+        p[mask] = rng.integers(-amplitude, amplitude + 1, int(mask.sum()), dtype=np.int16)
+        p[..., 0] = rng.integers(-1000, 1001, p.shape[:2], dtype=np.int16)
+        planes.append(p)
+    return planes
+
+
+@pytest.mark.parametrize("mcus", [(1, 1), (3, 2), (40, 30), (120, 68)])
+@pytest.mark.parametrize("density", [0.02, 0.3, 1.0])
+def test_round_trip_with_the_gpu_encoder_420(mcus, density):
+    mcus_x, mcus_y = mcus
+    rng = np.random.default_rng(mcus_x * 1000 + mcus_y + int(density * 100))
+    geom = [(2, 2), (1, 1), (1, 1)]
+    planes = random_planes(rng, geom, mcus_x, mcus_y, density, 1023 if density < 1 else 40)
+    egeom = [(p.shape[1], p.shape[0], hs, vs) for p, (hs, vs) in zip(planes, geom)]
+    rc, data = gpu_encode(planes, egeom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS))
+    assert rc == 0
+    raw, segs = unstuff(data)
+    rc, got = gpu_decode(raw, segs, geom, mcus_x, mcus_y, pitch_extra=3)
+    assert rc == 0
+    for c in range(3):
+        assert np.array_equal(got[c][:, :planes[c].shape[1]], planes[c]), c
+        assert np.all(got[c][:, planes[c].shape[1]:] == 0)  # pitch padding comes back zeroed
+
+
+def py_encode_restart(planes, geom, mcus_x, mcus_y, dc, ac, restart):
+    """like test_gpu_huffman.py_encode for full MCU grids, with RSTn markers every `restart` MCUs"""
+    out, bits = bytearray(), []
+
+    def put(code, size):
+        bits.extend((code >> (size - 1 - i)) & 1 for i in range(size))
+
+    def flush():
+        while len(bits) % 8:
+            bits.append(1)
+        for i in range(0, len(bits), 8):
+            b = int("".join(map(str, bits[i:i + 8])), 2)
+            out.append(b)
+            if b == 0xFF:
+                out.append(0)
+        bits.clear()
+
+    last, n_rst, mcu = [0] * len(planes), 0, 0
+    for my in range(mcus_y):
+        for mx in range(mcus_x):
+            if restart and mcu and mcu % restart == 0:
+                flush()
+                out.extend([0xFF, 0xD0 + (n_rst & 7)])
+                n_rst += 1
+                last = [0] * len(planes)
+            mcu += 1
+            for c, (hs, vs) in enumerate(geom):
+                for yi in range(vs):
+                    for xi in range(hs):
+                        blk = planes[c][my * vs + yi, mx * hs + xi].astype(np.int64)
+                        t = int(blk[0]) - last[c]
+                        last[c] = int(blk[0])
+                        t2 = t
+                        if t < 0:
+                            t, t2 = -t, t2 - 1
+                        n = t.bit_length()
+                        put(dc.code[n], dc.size[n])
+                        if n:
+                            put(t2 & ((1 << n) - 1), n)
+                        r = 0
+                        for k in range(1, 64):
+                            v = int(blk[ZIGZAG[k]])
+                            if v == 0:
+                                r += 1
+                                continue
+                            while r > 15:
+                                put(ac.code[0xF0], ac.size[0xF0])
+                                r -= 16
+                            v2 = v
+                            if v < 0:
+                                v, v2 = -v, v2 - 1
+                            n = v.bit_length()
+                            put(ac.code[(r << 4) + n], ac.size[(r << 4) + n])
+                            put(v2 & ((1 << n) - 1), n)
+                            r = 0
+                        if r > 0:
+                            put(ac.code[0], ac.size[0])
+    flush()
+    return bytes(out)
+
+
+@pytest.mark.parametrize("restart", [0, 1, 3, 7])
+@pytest.mark.parametrize("geom", [[(1, 1)], [(2, 1), (1, 1), (1, 1)], [(1, 1), (1, 1), (1, 1)], [(2, 2), (1, 1), (1, 1), (2, 2)]])
+def test_against_the_python_encoder_with_restart_segments(restart, geom):
+    mcus_x, mcus_y = 9, 5
+    rng = np.random.default_rng(restart * 10 + len(geom))
+    planes = random_planes(rng, geom, mcus_x, mcus_y, 0.15, 300)
+    data = py_encode_restart(planes, geom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS), restart)
+    raw, segs = unstuff(data)
+    assert len(segs) == (-(-mcus_x * mcus_y // restart) if restart else 1)
+    rc, got = gpu_decode(raw, segs, geom, mcus_x, mcus_y, restart=restart)
+    assert rc == 0
+    for c in range(len(geom)):
+        assert np.array_equal(got[c], planes[c]), c
+
+
+def test_dc_wraps_like_a_jcoef_and_long_zero_runs():
+    geom, mcus_x, mcus_y = [(1, 1)], 300, 1
+    p = np.zeros((1, 300, 64), np.int16)
+    p[0, :, 0] = np.where(np.arange(300) % 2 == 0, 1023, -1024)  # differences of +-2047
+    p[0, ::3, 63] = -1                                              # 62 zeros then a value: three ZRLs
+    p[0, 1::3, 33] = 1023
+    data = py_encode_restart([p], geom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS), 0)
+    raw, segs = unstuff(data)
+    rc, got = gpu_decode(raw, segs, geom, mcus_x, mcus_y)
+    assert rc == 0 and np.array_equal(got[0], p)
+
+
+def test_corrupt_or_mismatched_streams_are_refused_not_decoded():
+    geom, mcus_x, mcus_y = [(2, 2), (1, 1), (1, 1)], 20, 10
+    rng = np.random.default_rng(5)
+    planes = random_planes(rng, geom, mcus_x, mcus_y, 0.2, 200)
+    data = py_encode_restart(planes, geom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS), 0)
+    raw, segs = unstuff(data)
+    assert gpu_decode(raw, segs, geom, mcus_x, mcus_y)[0] == 0
+    assert gpu_decode(raw[:len(raw) // 2], segs, geom, mcus_x, mcus_y)[0] == 4       # truncated
+    assert gpu_decode(raw, segs, geom, mcus_x, mcus_y + 1)[0] == 4                    # more MCUs than the data holds
+    assert gpu_decode(raw, segs, geom, mcus_x, mcus_y - 1)[0] == 4                    # fewer
+    assert gpu_decode(raw, [0, 10], geom, mcus_x, mcus_y, restart=0)[0] == 4         # segment table without restarts
+    bad = spec([0, 3] + [0] * 14, [0, 1, 2])                                          # three codes of length 2 and nothing else is fine; 5 of length 2 is not
+    bad.bits[1] = 5
+    assert gpu_decode(raw, segs, geom, mcus_x, mcus_y, tables=(bad, spec(AC_BITS, AC_VALS)))[0] == 4
+    noise = bytes(rng.integers(0, 256, len(raw), dtype=np.uint8))
+    assert gpu_decode(noise, [0], geom, mcus_x, mcus_y)[0] == 4
