@@ -7,7 +7,8 @@
  *
  *   bench_dropin <lib.so> <width> <height> <dropon_w> <dropon_h> <n_images> [lum cb cr]
  *
- * Synthetic inputs (deterministic): n JPEGs (quality 85, 4:2:0) of a gradient + hash noise picture
+ * Synthetic inputs (deterministic): n JPEGs (quality 85, 4:2:0; BENCH_SAMPLING / BENCH_QUALITY /
+ * BENCH_RESTART / BENCH_OPTIMIZE change that) of a gradient + hash noise picture
  * that differs per image, one RGBA dropon with a soft radial alpha.  Per image: read, mj_compose at
  * an unaligned position, optional effects, write.  Prints per-stage times and an FNV-1a hash over
  * all output bytes.
@@ -53,6 +54,12 @@ static unsigned char *make_jpeg(int w, int h, uint32_t seed, unsigned long *len)
         else if(sm != NULL && strcmp(sm, "444") == 0) c.comp_info[0].h_samp_factor = c.comp_info[0].v_samp_factor = 1;
         else if(sm != NULL && strcmp(sm, "422") == 0) c.comp_info[0].v_samp_factor = 1;
         else if(sm != NULL && strcmp(sm, "440") == 0) c.comp_info[0].h_samp_factor = 1;
+    }
+    { /* BENCH_QUALITY, BENCH_RESTART (MCUs per restart segment), BENCH_OPTIMIZE (per-image Huffman tables) */
+        const char *q = getenv("BENCH_QUALITY"), *r = getenv("BENCH_RESTART"), *o = getenv("BENCH_OPTIMIZE");
+        if(q != NULL) jpeg_set_quality(&c, atoi(q), TRUE);
+        if(r != NULL) c.restart_interval = (unsigned)atoi(r);
+        if(o != NULL && o[0] == '1') c.optimize_coding = TRUE;
     }
     jpeg_start_compress(&c, TRUE);
     for(y = 0; y < h; y++) {
@@ -137,6 +144,13 @@ int main(int argc, char **argv) {
         inlen[i] = 0;
         in[i] = make_jpeg(w, h, 1000u + (uint32_t)i, &inlen[i]);
     }
+    if(getenv("BENCH_DUMP_INPUT") != NULL && n > 0) { /* the first input, for tools that take a file */
+        FILE *f = fopen(getenv("BENCH_DUMP_INPUT"), "wb");
+        if(f != NULL) {
+            fwrite(in[0], 1, inlen[0], f);
+            fclose(f);
+        }
+    }
 
     double   t_read = 0, t_compose = 0, t_fx = 0, t_write = 0, t0;
     uint64_t hash = 0xcbf29ce484222325ull;
@@ -171,7 +185,8 @@ int main(int argc, char **argv) {
     }
     {
         const int *cnt = (const int *)dlsym(lib, "mjh_gpu_encode_count");
-        printf("{\"gpu_encodes\": %d, ", cnt != NULL ? *cnt : -1);
+        const int *dcnt = (const int *)dlsym(lib, "mjh_gpu_decode_count");
+        printf("{\"gpu_encodes\": %d, \"gpu_decodes\": %d, ", cnt != NULL ? *cnt : -1, dcnt != NULL ? *dcnt : -1);
     }
     printf("\"lib\": \"%s\", \"images\": %d, \"size\": \"%dx%d\", \"dropon\": \"%dx%d\", \"read_ms\": %.4f, \"compose_ms\": %.4f, \"effects_ms\": %.4f, "
            "\"write_ms\": %.4f, \"out_bytes\": %zu, \"fnv1a\": \"%016llx\"}\n",

@@ -1,0 +1,211 @@
+/*
+ * gpudecode.c — mj_read_jpeg_from_memory() with the entropy-coded segment decoded on the GPU
+ * (read side).  Used for what libmodjpeg's inputs overwhelmingly are:
+ * 8-bit sequential Huffman JPEGs whose single scan holds every component.  Progressive,
+ * arithmetic, multi-scan and damaged files stay with libjpeg's jpeg_read_coefficients().
+ *
+ * libjpeg still parses the markers (jpeg_read_header up to and including SOS) and owns the
+ * memory: the coefficient arrays are requested from its memory manager exactly as jdcoefct.c
+ * does for a transcoding read (whole MCUs, pre-zeroed, JPOOL_IMAGE), so everything downstream —
+ * mj_compose, the effects, jpeg_write_coefficients, mj_free_jpeg — sees the same object it would
+ * after jpeg_read_coefficients().  Here the scan data is located in the source buffer, the
+ * 0xFF00 stuffing and the RSTn markers are removed, and mjx_huff_decode_host() fills the arrays;
+ * tests/test_dropin_shim.py compares them with libjpeg's for every sampling and odd size.
+ */
+#include "mjhost.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+int mjh_gpu_decode_count = 0; /* how many files went through the GPU entropy decoder (tests) */
+
+#define BAIL(code, why)                                                                              \
+    do {                                                                                             \
+        if(getenv("MJ_DEBUG") != NULL) fprintf(stderr, "gpudecode: fall back to libjpeg: %s\n", why); \
+        rv = (code);                                                                                 \
+        goto done;                                                                                   \
+    } while(0)
+
+/* scan data -> bytes without stuffing, restart segments split; returns 0 when the data is not a
+ * plain run of [segment RSTn]* segment EOI */
+static int unstuff(const unsigned char *src, size_t n, unsigned char *dst, size_t *outlen, uint64_t *segs, int max_segs, int *nsegs) {
+    size_t i = 0, o = 0;
+    int    ns = 1, expect = 0;
+    segs[0] = 0;
+    for(;;) {
+        const unsigned char *ff = (const unsigned char *)memchr(src + i, 0xFF, n - i);
+        size_t               run;
+        unsigned char        marker;
+        if(ff == NULL) return 0; /* ran off the buffer without EOI: libjpeg's business */
+        run = (size_t)(ff - (src + i));
+        memcpy(dst + o, src + i, run);
+        o += run;
+        i += run;
+        if(i + 1 >= n) return 0;
+        marker = src[i + 1];
+        if(marker == 0x00) {
+            dst[o++] = 0xFF;
+        }
+        else if(marker >= 0xD0 && marker <= 0xD7) {
+            if(marker != 0xD0 + expect || ns >= max_segs) return 0; /* out of sequence: libjpeg resynchronises */
+            expect = (expect + 1) & 7;
+            segs[ns++] = (uint64_t)o;
+        }
+        else if(marker == 0xD9) {
+            *outlen = o;
+            *nsegs = ns;
+            return 1;
+        }
+        else {
+            return 0; /* fill bytes, DNL, another scan ... */
+        }
+        i += 2;
+    }
+}
+
+int mjh_read_gpu_entropy(mj_jpeg_t *m) {
+    struct jpeg_decompress_struct *d = &m->cinfo;
+    mjx_huff_dscan_t               sc;
+    mjx_huff_spec_t                specs[8];
+    jvirt_barray_ptr              *arrays;
+    unsigned char                 *raw = NULL;
+    uint64_t                      *segs = NULL;
+    int16_t                       *staged[4] = {NULL, NULL, NULL, NULL};
+    size_t                         rawlen = 0, avail;
+    long long                      nmcu;
+    int                            c, i, rv = MJH_DECODE_UNSUPPORTED, nsegs = 0, max_segs, blocks_in_mcu = 0;
+
+    /* ---- what this path decodes (nothing has been touched yet: "clean" bail-outs) ---- */
+    {
+        /* below this much scan data libjpeg's serial decoder is faster than the round trips to
+         * the device (MJ_GPU_DECODE_MIN_BYTES overrides; the result is the same either way) */
+        static long min_bytes = -1;
+        static int  have_device = -1;
+        if(min_bytes < 0) min_bytes = getenv("MJ_GPU_DECODE_MIN_BYTES") != NULL ? atol(getenv("MJ_GPU_DECODE_MIN_BYTES")) : 16384;
+        if(d->src != NULL && (long)d->src->bytes_in_buffer < min_bytes) BAIL(MJH_DECODE_UNSUPPORTED, "small file");
+        if(have_device < 0) have_device = mjx_device_count() > 0;
+        if(!have_device) BAIL(MJH_DECODE_UNSUPPORTED, "no device");
+    }
+    if(d->progressive_mode || d->arith_code || d->data_precision != 8) BAIL(MJH_DECODE_UNSUPPORTED, "not 8-bit sequential Huffman");
+#if JPEG_LIB_VERSION >= 80
+    if(d->block_size != DCTSIZE) BAIL(MJH_DECODE_UNSUPPORTED, "scaled DCT block size");
+#endif
+    if(d->num_components < 1 || d->num_components > 4 || d->comps_in_scan != d->num_components) BAIL(MJH_DECODE_UNSUPPORTED, "scan does not hold all components");
+    if(d->Ss != 0 || d->Se != DCTSIZE2 - 1 || d->Ah != 0 || d->Al != 0) BAIL(MJH_DECODE_UNSUPPORTED, "not a full sequential scan");
+    if(d->src == NULL || d->src->next_input_byte == NULL || d->src->bytes_in_buffer < 2) BAIL(MJH_DECODE_UNSUPPORTED, "no scan data in the buffer");
+    for(i = 0; i < d->comps_in_scan; i++) {
+        const jpeg_component_info *ci = d->cur_comp_info[i];
+        if(ci != &d->comp_info[i]) BAIL(MJH_DECODE_UNSUPPORTED, "scan order differs from frame order");
+        if(ci->dc_tbl_no < 0 || ci->dc_tbl_no > 3 || ci->ac_tbl_no < 0 || ci->ac_tbl_no > 3 || d->dc_huff_tbl_ptrs[ci->dc_tbl_no] == NULL ||
+           d->ac_huff_tbl_ptrs[ci->ac_tbl_no] == NULL || ci->quant_tbl_no < 0 || ci->quant_tbl_no >= NUM_QUANT_TBLS || d->quant_tbl_ptrs[ci->quant_tbl_no] == NULL)
+            BAIL(MJH_DECODE_UNSUPPORTED, "missing table");
+        if(ci->width_in_blocks == 0 || ci->height_in_blocks == 0) BAIL(MJH_DECODE_UNSUPPORTED, "empty component");
+        blocks_in_mcu += d->num_components == 1 ? 1 : ci->h_samp_factor * ci->v_samp_factor;
+    }
+    if(blocks_in_mcu > D_MAX_BLOCKS_IN_MCU) BAIL(MJH_DECODE_UNSUPPORTED, "MCU too large");
+
+    memset(&sc, 0, sizeof(sc));
+    sc.ncomp = d->num_components;
+    if(d->num_components == 1) { /* non-interleaved: one block per MCU, only real blocks (jdinput.c per_scan_setup) */
+        sc.mcus_x = (int)d->comp_info[0].width_in_blocks;
+        sc.mcus_y = (int)d->comp_info[0].height_in_blocks;
+    }
+    else {
+        sc.mcus_x = (int)((d->image_width + (unsigned)(d->max_h_samp_factor * DCTSIZE) - 1) / (unsigned)(d->max_h_samp_factor * DCTSIZE));
+        sc.mcus_y = (int)((d->image_height + (unsigned)(d->max_v_samp_factor * DCTSIZE) - 1) / (unsigned)(d->max_v_samp_factor * DCTSIZE));
+    }
+    nmcu = (long long)sc.mcus_x * sc.mcus_y;
+    sc.restart_interval = (int)d->restart_interval;
+    max_segs = d->restart_interval ? (int)((nmcu + d->restart_interval - 1) / d->restart_interval) : 1;
+    if(d->restart_interval && (nmcu + d->restart_interval - 1) / d->restart_interval > 0x7FFFFFF) BAIL(MJH_DECODE_UNSUPPORTED, "too many restart segments");
+
+    /* Huffman tables as the file defined them */
+    for(i = 0; i < 4; i++) {
+        const JHUFF_TBL *t[2];
+        int              k;
+        t[0] = d->dc_huff_tbl_ptrs[i];
+        t[1] = d->ac_huff_tbl_ptrs[i];
+        for(k = 0; k < 2; k++) {
+            if(t[k] == NULL) continue;
+            memcpy(specs[4 * k + i].bits, t[k]->bits + 1, 16);
+            memcpy(specs[4 * k + i].vals, t[k]->huffval, 256);
+            (k == 0 ? sc.dc : sc.ac)[i] = &specs[4 * k + i];
+        }
+    }
+
+    /* scan data: from the byte after the SOS header to EOI */
+    avail = d->src->bytes_in_buffer;
+    raw = (unsigned char *)malloc(avail + 8);
+    segs = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(max_segs + 1));
+    if(raw == NULL || segs == NULL) BAIL(MJH_DECODE_UNSUPPORTED, "out of memory");
+    if(!unstuff(d->src->next_input_byte, avail, raw, &rawlen, segs, max_segs, &nsegs)) BAIL(MJH_DECODE_UNSUPPORTED, "scan data is not a plain segment list");
+    if(nsegs != max_segs || rawlen == 0) BAIL(MJH_DECODE_UNSUPPORTED, "restart segment count");
+    sc.data = raw;
+    sc.nbytes = rawlen;
+    if(d->restart_interval) {
+        sc.segment_offsets = segs;
+        sc.nsegments = nsegs;
+    }
+
+    /* ---- from here on the object is modified: failures are "dirty" ---- */
+    /* what transdecode_master_selection() computes before the coefficient controller starts;
+     * jpeg_copy_critical_parameters() reads output_width/height and min_DCT_*_scaled_size */
+    jpeg_calc_output_dimensions(d);
+    /* jdinput.c latch_quant_tables(): the table in force at the start of the scan */
+    for(c = 0; c < d->num_components; c++) {
+        jpeg_component_info *ci = &d->comp_info[c];
+        JQUANT_TBL          *q;
+        if(ci->quant_table != NULL) continue;
+        q = (JQUANT_TBL *)(*d->mem->alloc_small)((j_common_ptr)d, JPOOL_IMAGE, sizeof(JQUANT_TBL));
+        memcpy(q, d->quant_tbl_ptrs[ci->quant_tbl_no], sizeof(JQUANT_TBL));
+        ci->quant_table = q;
+    }
+    /* jdcoefct.c jinit_d_coef_controller(need_full_buffer): whole-MCU arrays, pre-zeroed */
+    arrays = (jvirt_barray_ptr *)(*d->mem->alloc_small)((j_common_ptr)d, JPOOL_IMAGE, sizeof(jvirt_barray_ptr) * MAX_COMPONENTS);
+    memset(arrays, 0, sizeof(jvirt_barray_ptr) * MAX_COMPONENTS);
+    for(c = 0; c < d->num_components; c++) {
+        const jpeg_component_info *ci = &d->comp_info[c];
+        arrays[c] = (*d->mem->request_virt_barray)((j_common_ptr)d, JPOOL_IMAGE, TRUE, (JDIMENSION)mjh_row_pitch(m, c), (JDIMENSION)mjh_row_count(m, c),
+                                                   (JDIMENSION)ci->v_samp_factor);
+    }
+    (*d->mem->realize_virt_arrays)((j_common_ptr)d);
+    m->coef = arrays;
+    rv = MJH_DECODE_FAILED;
+
+    for(c = 0; c < d->num_components; c++) {
+        const jpeg_component_info *ci = &d->comp_info[c];
+        const int                  hs = d->num_components == 1 ? 1 : ci->h_samp_factor, vs = d->num_components == 1 ? 1 : ci->v_samp_factor;
+        int                        pitch = 0;
+        int16_t                   *plane = NULL;
+        /* decode straight into libjpeg's array when it is one piece and exactly the MCU grid */
+        if(mjh_row_count(m, c) == sc.mcus_y * vs) plane = mjh_plane_direct(m, c, &pitch);
+        if(plane == NULL) {
+            pitch = mjh_row_pitch(m, c);
+            staged[c] = (int16_t *)malloc((size_t)sc.mcus_y * (size_t)vs * (size_t)pitch * sizeof(JBLOCK));
+            if(staged[c] == NULL) BAIL(MJH_DECODE_FAILED, "out of memory");
+            plane = staged[c];
+        }
+        if(pitch < sc.mcus_x * hs || mjh_row_count(m, c) < sc.mcus_y * vs) BAIL(MJH_DECODE_FAILED, "array smaller than the MCU grid");
+        sc.comp[c].plane = plane;
+        sc.comp[c].blocks_per_row = pitch;
+        sc.comp[c].h_samp = hs;
+        sc.comp[c].v_samp = vs;
+        sc.comp[c].dc_tbl = ci->dc_tbl_no;
+        sc.comp[c].ac_tbl = ci->ac_tbl_no;
+    }
+    {
+        const int e = mjx_huff_decode_host(&sc);
+        if(e != MJX_OK) BAIL(MJH_DECODE_FAILED, e == MJX_ERR_BAD_ARG ? "decoder refused the stream" : (e == MJX_ERR_NO_DEVICE ? "no device" : "device error"));
+    }
+    for(c = 0; c < d->num_components; c++)
+        if(staged[c] != NULL) mjh_rows_scatter(m, c, 0, sc.mcus_y * sc.comp[c].v_samp, staged[c]);
+    __sync_fetch_and_add(&mjh_gpu_decode_count, 1);
+    rv = MJ_OK;
+
+done:
+    for(c = 0; c < 4; c++) free(staged[c]);
+    free(raw);
+    free(segs);
+    if(rv != MJ_OK) m->coef = NULL;
+    return rv;
+}

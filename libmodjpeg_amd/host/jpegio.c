@@ -85,9 +85,20 @@ void mj_free_jpeg(mj_jpeg_t *m) {
 
 /* ---- read: JPEG -> quantised coefficients (reference image.c:33-113) ------------------- */
 
+/* create + memory source + saved markers + header (up to and including the first SOS) */
+static void open_header(mj_jpeg_t *m, const unsigned char *memory, size_t len) {
+    int marker;
+    jpeg_create_decompress(&m->cinfo);
+    jpeg_mem_src(&m->cinfo, (unsigned char *)memory, (unsigned long)len);
+    /* keep COM and APP0..APP15 so that the written file carries them again (image.c:67-72) */
+    jpeg_save_markers(&m->cinfo, JPEG_COM, 0xFFFF);
+    for(marker = 0; marker < 16; marker++) jpeg_save_markers(&m->cinfo, JPEG_APP0 + marker, 0xFFFF);
+    jpeg_read_header(&m->cinfo, TRUE);
+}
+
 int mj_read_jpeg_from_memory(mj_jpeg_t *m, const unsigned char *memory, size_t len, size_t max_pixel) {
     mjh_error_trap_t trap;
-    int              c, marker;
+    int              c;
 
     if(m == NULL || memory == NULL || len == 0) return MJ_ERR_NULL_DATA;
 
@@ -99,14 +110,7 @@ int mj_read_jpeg_from_memory(mj_jpeg_t *m, const unsigned char *memory, size_t l
         mj_init_jpeg(m);
         return MJ_ERR_DECODE_JPEG;
     }
-    jpeg_create_decompress(&m->cinfo);
-    jpeg_mem_src(&m->cinfo, (unsigned char *)memory, (unsigned long)len);
-
-    /* keep COM and APP0..APP15 so that the written file carries them again (image.c:67-72) */
-    jpeg_save_markers(&m->cinfo, JPEG_COM, 0xFFFF);
-    for(marker = 0; marker < 16; marker++) jpeg_save_markers(&m->cinfo, JPEG_APP0 + marker, 0xFFFF);
-
-    jpeg_read_header(&m->cinfo, TRUE);
+    open_header(m, memory, len);
     m->width = (int)m->cinfo.image_width;
     m->height = (int)m->cinfo.image_height;
 
@@ -121,7 +125,19 @@ int mj_read_jpeg_from_memory(mj_jpeg_t *m, const unsigned char *memory, size_t l
         return MJ_ERR_UNSUPPORTED_COLORSPACE;
     }
 
-    m->coef = jpeg_read_coefficients(&m->cinfo);
+    /* sequential Huffman files: the scan data is decoded on the GPU into arrays identical to
+     * libjpeg's (gpudecode.c; MJ_GPU_DECODE=0 keeps everything in libjpeg).  Everything else,
+     * and every file that path refuses, is read by jpeg_read_coefficients() as in the reference. */
+    if(!(getenv("MJ_GPU_DECODE") != NULL && getenv("MJ_GPU_DECODE")[0] == '0')) {
+        const int rv = mjh_read_gpu_entropy(m);
+        if(rv == MJH_DECODE_FAILED) { /* arrays were already requested: start over with a fresh object */
+            jpeg_destroy_decompress(&m->cinfo);
+            memset(&m->cinfo, 0, sizeof(m->cinfo));
+            mjh_trap_install(&trap, (j_common_ptr)&m->cinfo);
+            open_header(m, memory, len);
+        }
+    }
+    if(m->coef == NULL) m->coef = jpeg_read_coefficients(&m->cinfo);
 
     m->sampling.max_h_samp_factor = m->cinfo.max_h_samp_factor;
     m->sampling.max_v_samp_factor = m->cinfo.max_v_samp_factor;
@@ -329,7 +345,7 @@ int16_t *mjh_plane_direct(mj_jpeg_t *m, int c, int *pitch) {
     JDIMENSION   r;
     if(ci->height_in_blocks == 0) return NULL;
     first = prev = coef_row(m, c, 0, TRUE);
-    for(r = 1; r < ci->height_in_blocks; r++) {
+    for(r = 1; r < (JDIMENSION)mjh_row_count(m, c); r++) { /* all rows of the array, the MCU padding included */
         JBLOCKROW cur = coef_row(m, c, (int)r, TRUE);
         if(cur != prev + row_blocks) return NULL;
         prev = cur;

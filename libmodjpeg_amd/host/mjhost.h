@@ -4,6 +4,7 @@
  *
  * Module map (reference file each one stands in for):
  *      jpegio.c   coefficient JPEG in/out, pixel <-> JPEG helpers      (image.c, jpeg.c)
+ *      gpudecode.c / gpuencode.c   scan data <-> coefficient arrays on the GPU (libjpeg's jdhuff.c / jchuff.c role)
  *      dropon.c   overlay readers: raw, JPEG (+mask JPEG), PNG         (dropon.c:34-323, :578-604)
  *      tiles.c    overlay -> DCT-domain tiles ("compiled dropon")      (dropon.c:325-576, :606-)
  *      compose.c  placement geometry + masked compose on the GPU       (compose.c, convolve.c)
@@ -57,6 +58,14 @@ int16_t *mjh_plane_direct(mj_jpeg_t *m, int c, int *pitch);
  * MJH_ENCODE_UNSUPPORTED when the file needs libjpeg's own encoder */
 #define MJH_ENCODE_UNSUPPORTED (-1)
 int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len);
+
+/* mj_read_jpeg_from_memory after jpeg_read_header(): the scan data decoded on the GPU into
+ * arrays requested from libjpeg's memory manager (gpudecode.c).  MJ_OK: m->coef is set.
+ * MJH_DECODE_UNSUPPORTED: not a file for this path, the object is untouched.
+ * MJH_DECODE_FAILED: refused after the arrays were requested, the caller reopens the file. */
+#define MJH_DECODE_UNSUPPORTED (-1)
+#define MJH_DECODE_FAILED      (-2)
+int mjh_read_gpu_entropy(mj_jpeg_t *m);
 
 /* prepared tiles resident on the device, cached across mj_compose calls (tilecache.c).
  * acquire() sets *out = NULL (and returns MJ_OK) when the cache is disabled or full of busy

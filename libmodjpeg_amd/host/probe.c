@@ -13,6 +13,16 @@
  *        tile cache has slots (evictions, misses and hits interleave, arenas are shared); every
  *        result must equal the one a single thread computed for the same placement.  Prints
  *        "ok" or the number of mismatches.
+ *   mjhost_probe decodecmp <image.jpg>
+ *        reads the file twice, with libjpeg's entropy decoder (MJ_GPU_DECODE=0) and with the GPU
+ *        one, and compares everything downstream code looks at: every block of every array row
+ *        (the MCU padding included), the latched quantisation tables, the dimensions that
+ *        jpeg_copy_critical_parameters() copies.  Prints "same gpu" (GPU path taken),
+ *        "same fallback" (the GPU path declined the file) or "differ ...".
+ *   mjhost_probe decodefuzz <image.jpg> <trials> <seed>
+ *        the same comparison on damaged copies of the file (flipped bits, random runs, truncation,
+ *        stray restart markers): whatever libjpeg makes of a broken stream, the drop-in must
+ *        return the same arrays or the same error.  Prints the tally.
  *   mjhost_probe nodevice <image.jpg>
  *        prints the return codes of mj_effect_luminance and mj_compose (expects MJ_ERR_MEMORY
  *        on a machine without a GPU: there is no CPU fallback).
@@ -71,6 +81,75 @@ static void *stress_worker(void *arg) {
         if(compose_hash(placement) != g_want[placement]) __sync_fetch_and_add(&g_bad, 1);
     }
     return NULL;
+}
+
+/* ---- decodecmp / decodefuzz ---- */
+static uint32_t xorshift(uint32_t *s) {
+    *s ^= *s << 13;
+    *s ^= *s >> 17;
+    *s ^= *s << 5;
+    return *s;
+}
+
+static int read_file(const char *path, unsigned char **buf, size_t *len) {
+    FILE *f = fopen(path, "rb");
+    if(f == NULL) return 1;
+    fseek(f, 0, SEEK_END);
+    *len = (size_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    *buf = malloc(*len ? *len : 1);
+    if(fread(*buf, 1, *len, f) != *len) {
+        fclose(f);
+        return 1;
+    }
+    fclose(f);
+    return 0;
+}
+
+/* the same bytes read with libjpeg's entropy decoder and with the GPU one.
+ * 0: identical, GPU path taken; 1: identical, the GPU path declined; 2: they differ;
+ * 3: both reads failed with the same code */
+static int compare_reads(const unsigned char *buf, size_t len) {
+    extern int mjh_gpu_decode_count;
+    extern int mjh_row_pitch(const mj_jpeg_t *, int), mjh_row_count(const mj_jpeg_t *, int);
+    mj_jpeg_t  a, b;
+    int        c, before, took_gpu, ra, rb, result = 2;
+    mj_init_jpeg(&a);
+    mj_init_jpeg(&b);
+    setenv("MJ_GPU_DECODE", "0", 1);
+    ra = mj_read_jpeg_from_memory(&a, buf, len, 0);
+    setenv("MJ_GPU_DECODE", "1", 1);
+    before = mjh_gpu_decode_count;
+    rb = mj_read_jpeg_from_memory(&b, buf, len, 0);
+    took_gpu = mjh_gpu_decode_count - before;
+    if(ra != rb) goto out;
+    if(ra != MJ_OK) {
+        result = 3;
+        goto out;
+    }
+    if(a.cinfo.num_components != b.cinfo.num_components || a.width != b.width || a.height != b.height || memcmp(&a.sampling, &b.sampling, sizeof(a.sampling)) != 0 ||
+       a.cinfo.output_width != b.cinfo.output_width || a.cinfo.output_height != b.cinfo.output_height
+#if JPEG_LIB_VERSION >= 80
+       || a.cinfo.min_DCT_h_scaled_size != b.cinfo.min_DCT_h_scaled_size || a.cinfo.min_DCT_v_scaled_size != b.cinfo.min_DCT_v_scaled_size
+#endif
+    )
+        goto out;
+    for(c = 0; c < a.cinfo.num_components; c++) {
+        const int   rows = mjh_row_count(&a, c), pitch = mjh_row_pitch(&a, c);
+        JQUANT_TBL *qa = a.cinfo.comp_info[c].quant_table, *qb = b.cinfo.comp_info[c].quant_table;
+        int         r;
+        if(qa == NULL || qb == NULL || memcmp(qa->quantval, qb->quantval, sizeof(qa->quantval)) != 0) goto out;
+        for(r = 0; r < rows; r++) {
+            JBLOCKARRAY xa = (*a.cinfo.mem->access_virt_barray)((j_common_ptr)&a.cinfo, a.coef[c], (JDIMENSION)r, 1, FALSE);
+            JBLOCKARRAY xb = (*b.cinfo.mem->access_virt_barray)((j_common_ptr)&b.cinfo, b.coef[c], (JDIMENSION)r, 1, FALSE);
+            if(memcmp(xa[0], xb[0], sizeof(JBLOCK) * (size_t)pitch) != 0) goto out;
+        }
+    }
+    result = took_gpu ? 0 : 1;
+out:
+    mj_free_jpeg(&a);
+    mj_free_jpeg(&b);
+    return result;
 }
 
 int main(int argc, char **argv) {
@@ -147,6 +226,65 @@ int main(int argc, char **argv) {
         mj_free_jpeg(&a);
         mj_free_jpeg(&b);
         return 0;
+    }
+    if(argc == 3 && strcmp(argv[1], "decodecmp") == 0) {
+        unsigned char *buf = NULL;
+        size_t         len = 0;
+        int            r;
+        if(read_file(argv[2], &buf, &len) != 0) return 10;
+        r = compare_reads(buf, len);
+        printf("%s\n", r == 0 ? "same gpu" : (r == 1 ? "same fallback" : (r == 3 ? "same error" : "differ")));
+        free(buf);
+        return r == 2 ? 1 : 0;
+    }
+    if(argc == 5 && strcmp(argv[1], "decodefuzz") == 0) {
+        unsigned char *buf = NULL, *work;
+        size_t         len = 0, sos = 0, i;
+        const int      trials = atoi(argv[3]);
+        uint32_t       rng = (uint32_t)atoi(argv[4]) * 2654435761u + 1u;
+        int            t, count[4] = {0, 0, 0, 0};
+        if(read_file(argv[2], &buf, &len) != 0) return 10;
+        for(i = 2; i + 3 < len; i++)
+            if(buf[i] == 0xFF && buf[i + 1] == 0xDA) { /* first SOS: damage only what follows its header */
+                sos = i + 2 + (size_t)((buf[i + 2] << 8) | buf[i + 3]);
+                break;
+            }
+        if(sos == 0 || sos + 16 >= len) return 11;
+        work = malloc(len);
+        for(t = 0; t < trials; t++) {
+            int k, kind, r;
+            memcpy(work, buf, len);
+#define RND() xorshift(&rng)
+            kind = (int)(RND() % 4u);
+            if(kind == 0) { /* a few flipped bits */
+                for(k = 0; k < 1 + (int)(RND() % 3u); k++) work[sos + RND() % (len - sos - 2)] ^= (unsigned char)(1u << (RND() % 8u));
+            }
+            else if(kind == 1) { /* a run of random bytes */
+                size_t at = sos + RND() % (len - sos - 2), n = 1 + RND() % 64u;
+                for(i = at; i < at + n && i < len - 2; i++) work[i] = (unsigned char)RND();
+            }
+            else if(kind == 2) { /* truncated, EOI kept */
+                size_t cut = sos + RND() % (len - sos - 2);
+                work[cut] = 0xFF;
+                work[cut + 1] = 0xD9;
+                r = compare_reads(work, cut + 2);
+                count[r]++;
+                if(r == 2) break;
+                continue;
+            }
+            else { /* a stray marker */
+                size_t at = sos + RND() % (len - sos - 3);
+                work[at] = 0xFF;
+                work[at + 1] = (unsigned char)(0xD0 + RND() % 8u);
+            }
+            r = compare_reads(work, len);
+            count[r]++;
+            if(r == 2) break;
+        }
+        printf("%d gpu, %d fallback, %d error, %d differ\n", count[0], count[1], count[3], count[2]);
+        free(work);
+        free(buf);
+        return count[2] ? 1 : 0;
     }
     if(argc == 3 && strcmp(argv[1], "nodevice") == 0) {
         mj_jpeg_t     m;

@@ -246,3 +246,85 @@ def test_concurrent_compose_with_cache_evictions(shim):
     res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "stress", os.path.join(IMAGES, "image.jpg"), os.path.join(IMAGES, "dropon.png"), "16", "40"],
                          capture_output=True, text=True)
     assert res.returncode == 0 and res.stdout.strip() == "ok", (res.stdout, res.stderr[-500:])
+
+
+def _make_input(path, size, sampling, **knobs):
+    """one synthetic JPEG from the bench harness's generator (libjpeg encoder)"""
+    env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DUMP_INPUT=str(path), MJ_GPU_DECODE="0", MJ_GPU_ENCODE="0")
+    for k, v in knobs.items():
+        env["BENCH_" + k.upper()] = str(v)
+    subprocess.check_output([os.path.join(HOST, "bench_dropin"), os.path.join(HOST, "libmodjpeg.so.1"), *size, "16", "16", "1"], env=env)
+    assert os.path.getsize(path) > 100
+
+
+DECODE_CASES = [  # size, generator knobs
+    (("641", "479"), {}),
+    (("33", "17"), {}),
+    (("1000", "33"), {"restart": 1}),
+    (("200", "100"), {"restart": 5, "optimize": 1}),
+    (("641", "479"), {"restart": 41, "quality": 100}),
+    (("640", "480"), {"quality": 8, "optimize": 1}),
+    (("1920", "1080"), {"quality": 95}),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampling", ["420", "422", "440", "444", "gray"])
+@pytest.mark.parametrize("case", range(len(DECODE_CASES)))
+def test_gpu_entropy_decoder_matches_libjpeg(shim, tmp_path, sampling, case):
+    """mj_read_jpeg_from_memory: the scan data is decoded on the GPU (row f-4, read side) into arrays
+    that must equal jpeg_read_coefficients()'s block for block, MCU padding included, together with
+    the latched quantisation tables and the dimensions the writer copies - for every MCU layout,
+    odd sizes, restart segments, per-image Huffman tables and both ends of the quality scale"""
+    size, knobs = DECODE_CASES[case]
+    src = tmp_path / "in.jpg"
+    _make_input(src, size, sampling, **knobs)
+    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "decodecmp", str(src)], capture_output=True, text=True,
+                         env=dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0"))
+    assert res.returncode == 0 and res.stdout.strip() == "same gpu", (res.stdout, res.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_gpu_entropy_decoder_declines_what_it_does_not_decode(shim, tmp_path):
+    """progressive, arithmetic-coded and small files are read by libjpeg exactly as in the reference"""
+    src = tmp_path / "in.jpg"
+    _make_input(src, ("320", "240"), "420")
+    cli, probe = os.path.join(HOST, "modjpeg"), os.path.join(HOST, "mjhost_probe")
+    for flag in ("-P", "-A"):
+        out = tmp_path / ("out%s.jpg" % flag)
+        subprocess.check_call([cli, flag, "-i", str(src), "-o", str(out)])
+        res = subprocess.run([probe, "decodecmp", str(out)], capture_output=True, text=True, env=dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0"))
+        assert res.stdout.strip() == "same fallback", (flag, res.stdout, res.stderr[-300:])
+    res = subprocess.run([probe, "decodecmp", str(src)], capture_output=True, text=True, env=dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="100000000"))
+    assert res.stdout.strip() == "same fallback"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampling,knobs", [("420", {}), ("444", {"restart": 7}), ("gray", {"optimize": 1})])
+def test_gpu_entropy_decoder_on_damaged_files(shim, tmp_path, sampling, knobs):
+    """flipped bits, random runs, truncation and stray restart markers in the scan data: whatever
+    libjpeg makes of the broken stream (it recovers from almost everything), the drop-in returns the
+    same arrays or the same error - the GPU decoder refuses anything that is not a clean stream"""
+    src = tmp_path / "in.jpg"
+    _make_input(src, ("400", "300"), sampling, **knobs)
+    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "decodefuzz", str(src), "150", "7"], capture_output=True, text=True,
+                         env=dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0"))
+    assert res.returncode == 0 and res.stdout.strip().endswith(" 0 differ"), (res.stdout, res.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_read_compose_write_identical_with_both_entropy_paths_on_the_gpu(shim):
+    """end to end with decoder and encoder on the GPU: same bytes as with libjpeg doing both, and
+    as the reference library"""
+    import json
+    exe = os.path.join(HOST, "bench_dropin")
+    args = ["1920", "1080", "256", "256", "3", "7", "5", "-3"]
+    env = dict(os.environ, BENCH_RESTART="120")
+    gpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))
+    cpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=dict(env, MJ_GPU_DECODE="0", MJ_GPU_ENCODE="0")))
+    assert gpu["gpu_decodes"] >= 4 and cpu["gpu_decodes"] == 0
+    assert gpu["out_bytes"] == cpu["out_bytes"] and gpu["fnv1a"] == cpu["fnv1a"], (gpu, cpu)
+    ref = os.path.join(ROOT, "oracle", "_ref", "libmodjpeg_ref.so")
+    if os.path.exists(ref):
+        r = json.loads(subprocess.check_output([exe, ref, *args], text=True, env=env))
+        assert gpu["fnv1a"] == r["fnv1a"]
