@@ -113,6 +113,9 @@ typedef struct mjx_host_rect {
 /* tile and alpha are DEVICE pointers (tiles kept resident across calls, e.g. one dropon composed
  * into many images): only the plane rows cross PCIe */
 #define MJX_RECT_TILES_ON_DEVICE 1
+/* rows_ptr is a DEVICE pointer into a plane that lives on the device (an image decoded there and
+ * kept there): the rows are blended in place and nothing but the descriptors crosses PCIe */
+#define MJX_RECT_ROWS_ON_DEVICE 2
 int mjx_compose_host(const mjx_host_rect_t *rects, int n);
 /* The host-buffer calls borrow a staging arena (grow-only device buffer, pinned descriptor buffer,
  * stream) from a small process-wide pool, so that a steady stream of per-image calls from any
@@ -161,6 +164,9 @@ int mjx_effect_zero(int16_t *coef /* DEVICE */, int blocks_per_row, int rows, in
 int mjx_effect_dc_host(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value);
 int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc);
 int mjx_convolve_host(const float *x, float *y, float w, int k, int l, int nblocks);
+/* the same effects on a plane that is resident on the DEVICE (synchronous, own stream) */
+int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value);
+int mjx_effect_zero_device(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc);
 
 /* ---- baseline Huffman entropy encoder (write side) ------------------
  * Encodes the entropy-coded segment of ONE sequential (baseline) JPEG scan - all components
@@ -176,7 +182,7 @@ typedef struct mjx_huff_table {
 } mjx_huff_table_t;
 
 typedef struct mjx_huff_component {
-    const int16_t *plane;           /* HOST: int16[rows][blocks_per_row][64], natural order */
+    const int16_t *plane;           /* HOST (DEVICE with MJX_HUFF_PLANES_ON_DEVICE): int16[rows][blocks_per_row][64], natural order */
     int32_t        blocks_per_row;  /* array pitch in blocks (>= width_in_blocks) */
     int32_t        width_in_blocks; /* true size: blocks beyond it inside an MCU are dummies */
     int32_t        height_in_blocks;
@@ -191,7 +197,11 @@ typedef struct mjx_huff_scan {
     const mjx_huff_table_t *dc[4];
     const mjx_huff_table_t *ac[4];
     int32_t                 max_coef_bits;  /* 10 for 8-bit JPEG: larger categories are an error as in libjpeg */
+    int32_t                 flags;          /* MJX_HUFF_* */
 } mjx_huff_scan_t;
+/* the component planes are DEVICE pointers (an image decoded on the device and kept there): no
+ * coefficient crosses PCIe, only the compressed bytes come back */
+#define MJX_HUFF_PLANES_ON_DEVICE 1
 
 /* *out is malloc()ed (caller free()s); returns MJX_ERR_BAD_ARG when a coefficient does not fit
  * the JPEG symbol alphabet (libjpeg: JERR_BAD_DCT_COEF) or a needed symbol has no code. */
@@ -204,14 +214,15 @@ int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char **out, size_
  * mcus_x*h_samp by mcus_y*v_samp blocks.  The bitstream is sequential; it is cut into fixed-size
  * chunks that are decoded speculatively and re-synchronised iteratively until every chunk starts
  * exactly where its predecessor ended (self-synchronisation of Huffman codes), then decoded once
- * more for real.  `data` is the scan data with the 0xFF00 stuffing and the RSTn markers removed. */
+ * more for real.  `data` points at the first byte after the SOS header, as in the file: 0xFF00
+ * stuffing and RSTn markers included; the scan must end with EOI inside `nbytes`. */
 typedef struct mjx_huff_spec {
     uint8_t bits[16];  /* number of codes of length 1..16 (DHT) */
     uint8_t vals[256]; /* symbols in code order */
 } mjx_huff_spec_t;
 
 typedef struct mjx_huff_dcomponent {
-    int16_t *plane;          /* HOST, out: int16[mcus_y*v_samp][blocks_per_row][64], written whole (pitch padding = 0) */
+    int16_t *plane;          /* HOST (DEVICE with the flag), out: int16[mcus_y*v_samp][blocks_per_row][64], written whole (pitch padding = 0) */
     int32_t  blocks_per_row; /* >= mcus_x*h_samp */
     int32_t  h_samp, v_samp;
     int32_t  dc_tbl, ac_tbl;
@@ -222,15 +233,15 @@ typedef struct mjx_huff_dscan {
     mjx_huff_dcomponent_t  comp[4];
     const mjx_huff_spec_t *dc[4];
     const mjx_huff_spec_t *ac[4];
-    const uint8_t         *data;             /* HOST: unstuffed entropy-coded bytes */
-    size_t                 nbytes;
-    int32_t                restart_interval; /* MCUs per restart segment, 0 = one segment */
-    const uint64_t        *segment_offsets;  /* byte offset of every restart segment in `data` (NULL: one segment at 0) */
-    int32_t                nsegments;
+    const uint8_t         *data;             /* HOST: scan data as in the file */
+    size_t                 nbytes;           /* bytes available at `data` (may extend past EOI) */
+    int32_t                restart_interval; /* MCUs per restart segment (DRI), 0 = none */
+    int32_t                flags;            /* MJX_HUFF_PLANES_ON_DEVICE: the planes are DEVICE pointers and stay there */
 } mjx_huff_dscan_t;
 
-/* MJX_ERR_BAD_ARG when the stream is not a valid baseline scan of this geometry (the caller then
- * uses its ordinary decoder). */
+/* MJX_ERR_BAD_ARG when the data is not a clean baseline scan of this geometry: markers other than
+ * in-sequence RSTn before EOI, a wrong number of restart segments or blocks, codes or categories
+ * outside the tables.  The caller then uses its ordinary decoder, which owns those semantics. */
 int mjx_huff_decode_host(const mjx_huff_dscan_t *scan);
 
 /* ---- synthetic workload generators (bench / test support; definition: mjx_synth.h) ------ */

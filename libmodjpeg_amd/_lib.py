@@ -73,6 +73,8 @@ SYMBOLS = [
     ("mjx_dc_plan_destroy", None, [_vp]),
     ("mjx_dc_plan_run", _i, [_vp, _vp]),
     ("mjx_effect_zero", _i, [_vp, _i, _i, _i, _i, _vp]),
+    ("mjx_effect_dc_device", _i, [_vp, _i, _i, _i, ctypes.c_uint16, _i]),
+    ("mjx_effect_zero_device", _i, [_vp, _i, _i, _i, _i]),
     ("mjx_huff_encode_host", _i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
     ("mjx_huff_decode_host", _i, [_vp]),
     ("mjx_synth_coef", _i, [_vp, _u64, _u32, _u64, _sz, _vp, _vp]),

@@ -1,60 +1,97 @@
 // mjx_huffdec.hip — baseline JPEG Huffman entropy decoder on gfx950 (the
 // read side): the coefficient planes jpeg_read_coefficients() would produce for one sequential
-// scan (libjpeg jdhuff.c decode_mcu), computed from the unstuffed scan data.
+// scan (libjpeg jdhuff.c decode_mcu), computed from the scan data as it stands in the file.
 //
 // A Huffman stream has no block index, so the decoder state (bit position, block slot inside the
 // MCU, zigzag position) at an arbitrary bit is unknown — but Huffman codes self-synchronise: a
 // decoder started in a wrong state falls into step with the true one after a short distance.
+//   0. host            0xFF00 stuffing and RSTn markers are removed while the bytes are copied into
+//                      the pinned staging buffer (the one pass over the input that a DMA from
+//                      pageable memory would cost anyway)
 //   1. sync rounds     the stream is cut into chunks of kChunkBits bits, one lane per chunk.  Each
 //                      lane walks its chunk without storing anything, from the exit state of its
 //                      left neighbour (round 0: from a guess), and publishes its own exit state and
-//                      the number of blocks it completed.  Rounds repeat until no lane saw a new
-//                      entry state: then every chunk starts exactly where its predecessor stopped.
+//                      the number of blocks it completed.  Rounds repeat until one changed nothing:
+//                      then every chunk starts exactly where its predecessor stopped.
 //   2. scan            exclusive prefix sum of the block counts -> first block slot of every chunk
 //   3. store pass      every lane walks its chunk once more and stores the coefficients (DC as the
 //                      difference it read)
 //   4. DC pass         per component, prefix sum of the differences inside every restart segment
+// The walk is a latency chain (window -> table -> shift), so it is kept to one LDS look-up and a
+// handful of ALU operations per symbol: a 64-bit bit window in registers, table entries that carry
+// the code length, the total bits to skip and the zigzag advance, a second-level table for codes
+// longer than the first-level index, no data-dependent branch except the end of a block.
 // Anything that is not a clean baseline stream (bad code, run past the block, wrong block count)
 // raises an error flag; the caller then decodes with libjpeg, which owns the error semantics.
+//
+// The rounds are latency chains that occupy a sliver of the GPU, so concurrent callers are
+// combined: every caller stages its own image (own arena, own stream), then the first one to
+// arrive while no batch is in flight launches ONE set of kernels over all images staged at that
+// moment (blockIdx.y = image) and the others wait for it.  A lone caller is a batch of one and
+// waits for nobody.
 #include "mjx_internal.hpp"
+#include "mjx_scan.hpp"
 
+#include <new>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 namespace mjx {
 
 constexpr int kDecMaxSlots = 10;
 constexpr int kChunkBits = 1024;
-constexpr int kChunkWords = kChunkBits / 32 + 3; // + byte misalignment of the segment + look-ahead
+constexpr int kChunkWords = kChunkBits / 32 + 5; // + byte misalignment of the segment + overshoot + window refill
 constexpr int kDecThreads = 128;
-constexpr int kLutBits = 10;
+constexpr int kLutBits = 10, kSubBits = 16 - kLutBits;
+constexpr int kMaxSubTables = 64; // second-level tables of 1 << kSubBits entries
+
+// table entry: code length | size << 8 | run << 12 | (length + size) << 16 | zigzag advance << 22
+constexpr unsigned kEntryBad = 1u << 29;  // DC category outside the 8-bit alphabet
+constexpr unsigned kEntryLink = 1u << 31; // low 16 bits: first entry of the second-level table
 
 struct DecComp {
     int16_t  *plane;
     long long jbase; // index of this component's first block in the concatenated DC array
-    int       bpr, hs, vs, dc_tbl, ac_tbl, nslots;
+    int       bpr, hs, vs, nslots;
 };
 
 struct DecScan {
-    int       ncomp, mcus_x, mcus_y, bpm, ri;
-    int       period; // smallest cyclic period of the slots' (DC table, AC table) sequence: slots equal modulo it decode alike
-    int       pad;
-    long long nslots;
-    DecComp   c[4];
-    int       slot_comp[kDecMaxSlots], slot_x[kDecMaxSlots], slot_y[kDecMaxSlots];
-};
-
-struct DecTables { // 0..3 DC, 4..7 AC
-    uint16_t lut[8][1 << kLutBits]; // (length << 8) | symbol for codes of <= kLutBits bits, 0 otherwise
-    int32_t  maxcode[8][17];        // largest code of length l, -1 if none
-    int32_t  valoff[8][17];         // index into vals of the first code of length l, minus that code
-    uint8_t  vals[8][256];
+    int                ncomp, mcus_x, mcus_y, bpm, ri;
+    int                period; // smallest cyclic period of the slots' (DC table, AC table) sequence: slots equal modulo it decode alike
+    int                ntab, nsub;
+    long long          nslots;
+    unsigned long long dcpack, acpack; // 4 bits per slot: index of the slot's DC / AC table among the staged ones
+    DecComp            c[4];
+    int                slot_comp[kDecMaxSlots], slot_x[kDecMaxSlots], slot_y[kDecMaxSlots];
 };
 
 struct DecChunk {
     unsigned long long start, end; // bits
     int                seg;        // restart segment
     int                flags;      // 1: first chunk of its segment, 2: last
+};
+
+constexpr int kMaxRounds = 192, kFirstRounds = 12, kMoreRounds = 12;
+constexpr int kFlagInts = kMaxRounds + 2; // per image: [0] error, [1 + r] round r changed something
+constexpr int kMaxBatch = 32;
+
+// one image of a batch, as the kernels see it (device copies live in the leader's arena)
+struct DecJob {
+    DecScan             S;
+    const unsigned     *tables;
+    const unsigned     *words;
+    const DecChunk     *chunks;
+    unsigned long long *exits, *seen;
+    unsigned           *nblk, *cpre;
+    unsigned long long *ctot;
+    unsigned           *diff, *dpre;
+    unsigned long long *dtot;
+    unsigned long long *totals; // [0] blocks counted, [1] sum of the DC differences (unused)
+    int                *flags;  // kFlagInts ints, in the leader's arena
+    long long           ndc;
+    int                 nchunks, chunk_groups, dc_groups;
 };
 
 __constant__ unsigned char kDecZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -69,208 +106,221 @@ __device__ __forceinline__ void unpack_state(unsigned long long s, unsigned long
     k = (int)(s & 127);
 }
 
-__device__ __forceinline__ int16_t *block_of(const DecScan &S, long long t, int slot) {
-    const long long mi = t / S.bpm;
-    const int       mcu_row = (int)(mi / S.mcus_x), mcu_col = (int)(mi - (long long)mcu_row * S.mcus_x);
-    const DecComp  &c = S.c[S.slot_comp[slot]];
-    const int       bx = mcu_col * c.hs + S.slot_x[slot], by = mcu_row * c.vs + S.slot_y[slot];
-    return c.plane + ((size_t)by * (size_t)c.bpr + (size_t)bx) * 64;
+// LDS of the walking kernels (dynamic): first-level tables, second-level tables, every lane's
+// chunk words (lane-interleaved), the scan description
+struct DecLds {
+    const unsigned *lut;   // [ntab][1 << kLutBits]
+    const unsigned *sub;   // [nsub][1 << kSubBits]
+    unsigned       *words; // [kChunkWords][kDecThreads]
+    DecScan        *scan;
+};
+
+__device__ __forceinline__ DecLds carve(unsigned *lds, int ntab, int nsub) {
+    DecLds L;
+    L.lut = lds;
+    L.sub = lds + (ntab << kLutBits);
+    L.words = lds + (ntab << kLutBits) + (nsub << kSubBits);
+    L.scan = reinterpret_cast<DecScan *>(L.words + kChunkWords * kDecThreads);
+    return L;
+}
+
+__device__ __forceinline__ void stage_shared(unsigned *lds, const DecScan &S, const unsigned *__restrict__ tables, const unsigned *__restrict__ words, const DecChunk &ck,
+                                             bool active) {
+    const int ntable_words = (S.ntab << kLutBits) + (S.nsub << kSubBits);
+    for(int i = threadIdx.x; i < ntable_words; i += kDecThreads) lds[i] = tables[i];
+    const DecLds L = carve(lds, S.ntab, S.nsub);
+    const int   *ssrc = reinterpret_cast<const int *>(&S);
+    int         *sdst = reinterpret_cast<int *>(L.scan);
+    for(int i = threadIdx.x; i < (int)(sizeof(DecScan) / 4); i += kDecThreads) sdst[i] = ssrc[i];
+    if(active) {
+        const unsigned long long w = ck.start >> 5;
+#pragma unroll
+        for(int i = 0; i < kChunkWords; ++i) L.words[i * kDecThreads + threadIdx.x] = __builtin_bswap32(words[w + i]); // the buffer is padded
+    }
+    __syncthreads();
 }
 
 // Walks the symbols from state (p, slot, k) until p reaches p_end (a symbol that starts before
 // p_end is consumed whole).  `slot` counts modulo `wrap`: the MCU size when storing, the table
 // period when synchronising (a position inside the MCU that no table distinguishes cannot
-// synchronise, and need not: the store pass takes it from the block count).  STORE: also stops at block slot t_stop, stores coefficients and
-// validates.  `cw` holds this lane's words from bit `base_bit` on, most significant bit first.
+// synchronise, and need not: the store pass takes it from the block count).  STORE: also stops at
+// block slot t_stop, stores coefficients and validates.
 template <bool STORE>
-__device__ __forceinline__ void walk(const DecScan &S, const uint16_t (*lut)[1 << kLutBits], const DecTables *__restrict__ T, const unsigned *cw, int cw_stride,
-                                     unsigned long long base_bit, unsigned long long &p, unsigned long long p_end, int &slot, int wrap, int &k, unsigned &nblocks,
-                                     long long &t, long long t_stop, int &err) {
-    int16_t *blk = nullptr;
-    if(STORE && t < t_stop) blk = block_of(S, t, slot);
+__device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack, unsigned long long acpack, unsigned long long base_bit, unsigned long long &p,
+                                     unsigned long long p_end, int &slot, int wrap, int &k, unsigned &nblocks, long long &t, long long t_stop, int &err) {
+    const unsigned *cw = L.words + threadIdx.x;
+    // bit window: the next `navail` (>= 32) bits of the stream, left-aligned
+    const int          rel = (int)(p - base_bit);
+    int                widx = (rel >> 5) + 2;
+    unsigned long long win = ((((unsigned long long)cw[(rel >> 5) * kDecThreads]) << 32) | cw[((rel >> 5) + 1) * kDecThreads]) << (rel & 31);
+    int                navail = 64 - (rel & 31);
+
+    // where the current block goes (STORE)
+    const DecScan &S = *L.scan;
+    int16_t       *blk = nullptr;
+    int            mcu_col = 0, mcu_row = 0;
+    auto           locate = [&]() {
+        const DecComp &c = S.c[S.slot_comp[slot]];
+        const int      bx = mcu_col * c.hs + S.slot_x[slot], by = mcu_row * c.vs + S.slot_y[slot];
+        blk = c.plane + ((size_t)by * (size_t)c.bpr + (size_t)bx) * 64;
+    };
+    if(STORE && t < t_stop) {
+        const unsigned mi = (unsigned)(t / S.bpm);
+        mcu_row = (int)(mi / (unsigned)S.mcus_x);
+        mcu_col = (int)(mi - (unsigned)mcu_row * (unsigned)S.mcus_x);
+        locate();
+    }
+
     while(p < p_end && (!STORE || t < t_stop)) {
-        const int                rel = (int)(p - base_bit);
-        const unsigned           w0 = cw[(rel >> 5) * cw_stride], w1 = cw[((rel >> 5) + 1) * cw_stride];
-        const unsigned           v = (unsigned)(((((unsigned long long)w0) << 32) | w1) >> (32 - (rel & 31)));
-        const DecComp           &c = S.c[S.slot_comp[slot]];
-        const int                tbl = k == 0 ? c.dc_tbl : 4 + c.ac_tbl;
-        const unsigned           e = lut[tbl][v >> (32 - kLutBits)];
-        int                      len = (int)(e >> 8), sym = (int)(e & 255u);
-        if(e == 0) { // longer than the look-ahead: canonical search (jdhuff.c jpeg_huff_decode)
-            len = 0;
-            for(int l = kLutBits + 1; l <= 16; ++l) {
-                const int code = (int)(v >> (32 - l));
-                if(code <= T->maxcode[tbl][l]) {
-                    len = l;
-                    sym = T->vals[tbl][(code + T->valoff[tbl][l]) & 255];
-                    break;
-                }
-            }
-            if(len == 0) { // not a code: the padding at the end of a segment, or a wrong guess
-                if(STORE) err = 1;
-                p = p_end;
-                break;
+        const unsigned tbl = (unsigned)((k == 0 ? dcpack : acpack) >> (4 * slot)) & 15u;
+        unsigned       e = L.lut[(tbl << kLutBits) + (unsigned)(win >> (64 - kLutBits))];
+        if(e & kEntryLink) e = L.sub[(e & 0xFFFFu) + ((unsigned)(win >> (64 - 16)) & ((1u << kSubBits) - 1u))];
+        if(e == 0) { // not a code: the padding at the end of a segment, or a wrong guess
+            if(STORE) err = 1;
+            p = p_end;
+            break;
+        }
+        const int total = (int)((e >> 16) & 63u), kinc = (int)((e >> 22) & 127u);
+        if(STORE) {
+            const int len = (int)(e & 31u), s = (int)((e >> 8) & 15u);
+            if(e & kEntryBad) err = 1;
+            if(s) {
+                const unsigned extra = ((unsigned)(win >> 32) << len) >> (32 - s);
+                const int      value = extra < (1u << (s - 1)) ? (int)extra - (1 << s) + 1 : (int)extra; // HUFF_EXTEND
+                const int      at = k + kinc - 1; // DC: 0 (the difference; the DC pass integrates); AC: k + run
+                if(at > 63) err = 1;
+                else blk[kDecZigzag[at]] = (int16_t)value;
             }
         }
-        int s, r = 0;
-        if(k == 0) {
-            s = sym;
-            if(s > 11) { // outside the 8-bit baseline alphabet
-                if(STORE) err = 1;
-                s = s > 16 ? 16 : s;
-            }
+        p += (unsigned)total;
+        win <<= total;
+        navail -= total;
+        if(navail < 32) {
+            win |= ((unsigned long long)cw[(widx < kChunkWords ? widx : kChunkWords - 1) * kDecThreads]) << (32 - navail);
+            navail += 32;
+            widx++;
         }
-        else {
-            s = sym & 15;
-            r = sym >> 4;
-        }
-        int value = 0;
-        if(s) {
-            const unsigned extra = (v << len) >> (32 - s);
-            value = extra < (1u << (s - 1)) ? (int)extra - (1 << s) + 1 : (int)extra; // HUFF_EXTEND
-        }
-        p += (unsigned)(len + s);
-        if(k == 0) {
-            if(STORE) blk[0] = (int16_t)value; // the difference; the DC pass integrates
-            k = 1;
-        }
-        else if(s) {
-            k += r;
-            if(k > 63) {
-                if(STORE) err = 1;
-                k = 64;
-            }
-            else {
-                if(STORE) blk[kDecZigzag[k]] = (int16_t)value;
-                k++;
-            }
-        }
-        else if(r == 15) {
-            k += 16;
-            if(k > 64) {
-                if(STORE) err = 1;
-                k = 64;
-            }
-        }
-        else {
-            k = 64; // EOB
-        }
-        if(k >= 64) {
+        k += kinc;
+        if(k >= 64) { // EOB, or the 63rd coefficient
+            if(STORE && k > 64 && kinc != 64) err = 1;
             k = 0;
             nblocks++;
             slot = slot + 1 == wrap ? 0 : slot + 1;
             if(STORE) {
                 t++;
-                if(t < t_stop) blk = block_of(S, t, slot);
+                if(slot == 0) {
+                    mcu_col++;
+                    if(mcu_col == S.mcus_x) {
+                        mcu_col = 0;
+                        mcu_row++;
+                    }
+                }
+                if(t < t_stop) locate();
             }
         }
     }
 }
 
-// LDS staging shared by the two walking kernels: the look-up tables, the scan description and
-// every lane's chunk words (lane-interleaved, so a lane's word i sits in bank (i*kDecThreads+lane)%banks)
-struct DecShared {
-    uint16_t lut[8][1 << kLutBits];
-    unsigned words[kChunkWords][kDecThreads];
-    DecScan  scan;
-};
-
-__device__ __forceinline__ void stage_shared(DecShared &sh, const DecScan &S, const DecTables *__restrict__ T, const unsigned *__restrict__ words, const DecChunk &ck,
-                                             bool active) {
-    const unsigned *src = reinterpret_cast<const unsigned *>(T->lut);
-    unsigned       *dst = reinterpret_cast<unsigned *>(sh.lut);
-    for(int i = threadIdx.x; i < 8 * (1 << kLutBits) / 2; i += kDecThreads) dst[i] = src[i];
-    const int *ssrc = reinterpret_cast<const int *>(&S);
-    int       *sdst = reinterpret_cast<int *>(&sh.scan);
-    for(int i = threadIdx.x; i < (int)(sizeof(DecScan) / 4); i += kDecThreads) sdst[i] = ssrc[i];
-    if(active) {
-        const unsigned long long w = ck.start >> 5;
-#pragma unroll
-        for(int i = 0; i < kChunkWords; ++i) sh.words[i][threadIdx.x] = __builtin_bswap32(words[w + i]); // the buffer is padded
-    }
-    __syncthreads();
-}
-
-// one synchronisation round (in place: a lane may see its neighbour's old or new exit state;
-// the rounds end when a whole round changed nothing, and then every read was of a final value)
-__global__ __launch_bounds__(kDecThreads) void huffdec_sync_kernel(DecScan S, const DecTables *__restrict__ T, const unsigned *__restrict__ words,
-                                                                    const DecChunk *__restrict__ chunks, int nchunks, unsigned long long *exits,
-                                                                    unsigned long long *__restrict__ seen, unsigned *__restrict__ nblocks, int *__restrict__ changed,
-                                                                    int round) {
-    __shared__ DecShared sh;
-    const int  i = blockIdx.x * kDecThreads + threadIdx.x;
-    const bool in_range = i < nchunks;
-    DecChunk   ck = {};
+// one synchronisation round (in place: a lane may see its neighbour's old or new exit state; the
+// rounds end when a whole round changed nothing, and then every read was of a final value).
+// flags[1 + r] says whether round r changed anything; once a round did not, later rounds return at once.
+__global__ __launch_bounds__(kDecThreads) void huffdec_sync_kernel(const DecJob *__restrict__ jobs, int round) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    const DecJob &J = jobs[blockIdx.y];
+    if(blockIdx.x * kDecThreads >= (unsigned)J.nchunks) return;
+    int *changed = J.flags + 1;
+    if(round >= 2 && __hip_atomic_load(&changed[round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return; // settled (changed[round] stays 0)
+    const int          i = blockIdx.x * kDecThreads + threadIdx.x;
+    const bool         in_range = i < J.nchunks;
+    DecChunk           ck = {};
     unsigned long long entry = 0;
     bool               active = false;
     if(in_range) {
-        ck = chunks[i];
-        entry = ((ck.flags & 1) || round == 0) ? pack_state(ck.start, 0, 0) : __hip_atomic_load(&exits[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        active = round == 0 || entry != seen[i];
+        ck = J.chunks[i];
+        entry = ((ck.flags & 1) || round == 0) ? pack_state(ck.start, 0, 0) : __hip_atomic_load(&J.exits[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        active = round == 0 || entry != J.seen[i];
     }
     if(__syncthreads_or(active ? 1 : 0) == 0) return; // nothing to redo in this workgroup
-    stage_shared(sh, S, T, words, ck, active);
+    stage_shared(lds, J.S, J.tables, J.words, ck, active);
     if(!active) return;
 
+    const DecLds       L = carve(lds, J.S.ntab, J.S.nsub);
     unsigned long long p;
     int                slot, k, err = 0;
     unsigned           nb = 0;
     long long          t = 0;
     unpack_state(entry, p, slot, k);
-    if(slot >= sh.scan.period) slot = 0;
+    if(slot >= J.S.period) slot = 0;
     if(p < ck.start) p = ck.start; // cannot happen; keeps the LDS window valid whatever the input
-    walk<false>(sh.scan, sh.lut, T, &sh.words[0][threadIdx.x], kDecThreads, (ck.start >> 5) << 5, p, ck.end, slot, sh.scan.period, k, nb, t, 0, err);
-    seen[i] = entry;
-    nblocks[i] = nb;
-    __hip_atomic_store(&exits[i], pack_state(p, slot, k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if(round != 0) atomicOr(&changed[round], 1);
+    if(p < ck.end) walk<false>(L, J.S.dcpack, J.S.acpack, (ck.start >> 5) << 5, p, ck.end, slot, J.S.period, k, nb, t, 0, err);
+    J.seen[i] = entry;
+    const unsigned long long out = pack_state(p, slot, k);
+    if(round == 0 || out != J.exits[i] || nb != J.nblk[i]) {
+        J.nblk[i] = nb;
+        __hip_atomic_store(&J.exits[i], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if(round != 0) atomicOr(&changed[round], 1);
+    }
 }
 
-__global__ __launch_bounds__(kDecThreads) void huffdec_store_kernel(DecScan S, const DecTables *__restrict__ T, const unsigned *__restrict__ words,
-                                                                     const DecChunk *__restrict__ chunks, int nchunks, const unsigned long long *__restrict__ exits,
-                                                                     const unsigned *__restrict__ local_prefix, const unsigned long long *__restrict__ group_prefix,
-                                                                     int group_items, const unsigned long long *__restrict__ total_blocks, int *__restrict__ error) {
-    __shared__ DecShared sh;
+__global__ __launch_bounds__(kDecThreads) void huffdec_store_kernel(const DecJob *__restrict__ jobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    const DecJob &J = jobs[blockIdx.y];
+    if(blockIdx.x * kDecThreads >= (unsigned)J.nchunks) return;
     const int  i = blockIdx.x * kDecThreads + threadIdx.x;
-    const bool active = i < nchunks;
+    const bool active = i < J.nchunks;
     DecChunk   ck = {};
-    if(active) ck = chunks[i];
-    stage_shared(sh, S, T, words, ck, active);
+    if(active) ck = J.chunks[i];
+    stage_shared(lds, J.S, J.tables, J.words, ck, active);
     if(!active) return;
-    if(*total_blocks != (unsigned long long)S.nslots) { // the stream does not hold this image
-        if(i == 0) atomicOr(error, 2);
+    const DecScan &S = J.S;
+    if(J.totals[0] != (unsigned long long)S.nslots) { // the stream does not hold this image
+        if(i == 0) atomicOr(&J.flags[0], 2);
         return;
     }
-    const DecScan &L = sh.scan;
-    const long long seg_blocks = L.ri > 0 ? (long long)L.ri * L.bpm : L.nslots;
+    const DecLds    L = carve(lds, S.ntab, S.nsub);
+    const long long seg_blocks = S.ri > 0 ? (long long)S.ri * S.bpm : S.nslots;
     const long long seg_t0 = (long long)ck.seg * seg_blocks;
     long long       t_stop = seg_t0 + seg_blocks;
-    if(t_stop > L.nslots) t_stop = L.nslots;
+    if(t_stop > S.nslots) t_stop = S.nslots;
 
     unsigned long long p;
     int                slot, k, err = 0;
     unsigned           nb = 0;
-    long long          t = (long long)(group_prefix[i / group_items] + local_prefix[i]);
-    unpack_state((ck.flags & 1) ? pack_state(ck.start, 0, 0) : exits[i - 1], p, slot, k);
-    if((ck.flags & 1) && t != seg_t0) err = 1;            // a restart segment with the wrong number of blocks
-    if(t < seg_t0 || t > t_stop || slot != (int)((t % L.bpm) % L.period) || p < ck.start) err = 1;
-    slot = (int)(t % L.bpm);
+    long long          t = (long long)(J.ctot[i / kScanItems] + J.cpre[i]);
+    unpack_state((ck.flags & 1) ? pack_state(ck.start, 0, 0) : J.exits[i - 1], p, slot, k);
+    if((ck.flags & 1) && t != seg_t0) err = 1; // a restart segment with the wrong number of blocks
+    if(t < seg_t0 || t > t_stop || slot != (int)((t % S.bpm) % S.period) || p < ck.start) err = 1;
+    slot = (int)(t % S.bpm);
     if(err == 0) {
-        walk<true>(L, sh.lut, T, &sh.words[0][threadIdx.x], kDecThreads, (ck.start >> 5) << 5, p, ck.end, slot, L.bpm, k, nb, t, t_stop, err);
+        if(p < ck.end) walk<true>(L, S.dcpack, S.acpack, (ck.start >> 5) << 5, p, ck.end, slot, S.bpm, k, nb, t, t_stop, err);
         if(ck.flags & 2) {
             if(t != t_stop || k != 0 || p > ck.end) err = 1; // segment ended inside a block / blocks missing
         }
     }
-    if(err) atomicOr(error, 1);
+    if(err) atomicOr(&J.flags[0], 1);
+}
+
+// ---- prefix sums over every image of the batch (which = 0: block counts of the chunks, 1: DC differences)
+__global__ __launch_bounds__(kScanThreads) void huffdec_scan_groups_kernel(const DecJob *__restrict__ jobs, int which) {
+    const DecJob &J = jobs[blockIdx.y];
+    if((int)blockIdx.x >= (which == 0 ? J.chunk_groups : J.dc_groups)) return;
+    if(which == 0) scan_groups_body(J.nblk, J.cpre, J.ctot, J.nchunks, blockIdx.x);
+    else scan_groups_body(J.diff, J.dpre, J.dtot, J.ndc, blockIdx.x);
+}
+
+__global__ __launch_bounds__(kScanThreads) void huffdec_scan_totals_kernel(const DecJob *__restrict__ jobs, int which) {
+    const DecJob &J = jobs[blockIdx.y];
+    if(which == 0) scan_totals_body(J.ctot, J.chunk_groups, J.totals + 0);
+    else scan_totals_body(J.dtot, J.dc_groups, J.totals + 1);
 }
 
 // ---- DC integration ---------------------------------------------------------------------
-__device__ __forceinline__ int16_t *dc_block(const DecScan &S, long long J, int &comp, long long &j) {
+__device__ __forceinline__ int16_t *dc_block(const DecScan &S, long long Jx, int &comp, long long &j) {
     comp = 0;
     for(int c = 1; c < S.ncomp; ++c)
-        if(J >= S.c[c].jbase) comp = c;
+        if(Jx >= S.c[c].jbase) comp = c;
     const DecComp &c = S.c[comp];
-    j = J - c.jbase;
+    j = Jx - c.jbase;
     const long long mi = j / c.nslots;
     const int       s = (int)(j - mi * c.nslots);
     const int       mcu_row = (int)(mi / S.mcus_x), mcu_col = (int)(mi - (long long)mcu_row * S.mcus_x);
@@ -278,21 +328,23 @@ __device__ __forceinline__ int16_t *dc_block(const DecScan &S, long long J, int 
     return c.plane + ((size_t)by * (size_t)c.bpr + (size_t)bx) * 64;
 }
 
-__global__ __launch_bounds__(256) void huffdec_dc_gather_kernel(DecScan S, long long n, unsigned *__restrict__ diffs) {
-    const long long J = (long long)blockIdx.x * 256 + threadIdx.x;
-    if(J >= n) return;
+__global__ __launch_bounds__(256) void huffdec_dc_gather_kernel(const DecJob *__restrict__ jobs) {
+    const DecJob   &J = jobs[blockIdx.y];
+    const long long Jx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if(Jx >= J.ndc) return;
     int       comp;
     long long j;
-    diffs[J] = (unsigned)(int)dc_block(S, J, comp, j)[0];
+    J.diff[Jx] = (unsigned)(int)dc_block(J.S, Jx, comp, j)[0];
 }
 
-__global__ __launch_bounds__(256) void huffdec_dc_finish_kernel(DecScan S, long long n, const unsigned *__restrict__ diffs, const unsigned *__restrict__ local_prefix,
-                                                                 const unsigned long long *__restrict__ group_prefix, int group_items, const int *__restrict__ error) {
-    const long long J = (long long)blockIdx.x * 256 + threadIdx.x;
-    if(J >= n || *error != 0) return;
+__global__ __launch_bounds__(256) void huffdec_dc_finish_kernel(const DecJob *__restrict__ jobs) {
+    const DecJob   &J = jobs[blockIdx.y];
+    const long long Jx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if(Jx >= J.ndc || J.flags[0] != 0) return;
+    const DecScan &S = J.S;
     int            comp;
     long long      j;
-    int16_t       *blk = dc_block(S, J, comp, j);
+    int16_t       *blk = dc_block(S, Jx, comp, j);
     const DecComp &c = S.c[comp];
     // predictor reset: start of the component, and every restart segment (jdhuff.c process_restart)
     long long j0 = 0;
@@ -301,9 +353,9 @@ __global__ __launch_bounds__(256) void huffdec_dc_finish_kernel(DecScan S, long 
         j0 = (mi - mi % S.ri) * c.nslots;
     }
     const long long J0 = c.jbase + j0;
-    const unsigned  before = (unsigned)(group_prefix[J / group_items] + local_prefix[J]);
-    const unsigned  base = (unsigned)(group_prefix[J0 / group_items] + local_prefix[J0]);
-    blk[0] = (int16_t)(int)(before + diffs[J] - base);
+    const unsigned  before = (unsigned)(J.dtot[Jx / kScanItems] + J.dpre[Jx]);
+    const unsigned  base = (unsigned)(J.dtot[J0 / kScanItems] + J.dpre[J0]);
+    blk[0] = (int16_t)(int)(before + J.diff[Jx] - base);
 }
 
 } // namespace mjx
@@ -314,40 +366,248 @@ namespace {
 
 size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// DHT -> look-up tables (jdhuff.c jpeg_make_d_derived_tbl); false when the counts are not a prefix code
-bool derive(const mjx_huff_spec_t *spec, DecTables *T, int idx) {
+struct TableBuilder {
+    unsigned lut[8][1 << kLutBits];
+    unsigned sub[kMaxSubTables][1 << kSubBits];
+    int      ntab = 0, nsub = 0;
+};
+
+unsigned make_entry(int len, int sym, bool is_dc) {
+    int      s, r, kinc;
+    unsigned flags = 0;
+    if(is_dc) {
+        s = sym;
+        r = 0;
+        kinc = 1;
+        if(s > 11) flags = kEntryBad; // outside the 8-bit baseline alphabet (the store pass refuses it)
+        if(s > 15) s = 15;
+    }
+    else {
+        s = sym & 15;
+        r = sym >> 4;
+        kinc = s ? r + 1 : (r == 15 ? 16 : 64); // coefficient after a run / ZRL / EOB (jdhuff.c: any other run with size 0 ends the block too)
+    }
+    return (unsigned)len | ((unsigned)s << 8) | ((unsigned)r << 12) | ((unsigned)(len + s) << 16) | ((unsigned)kinc << 22) | flags;
+}
+
+// DHT -> two-level look-up table (the role of jdhuff.c jpeg_make_d_derived_tbl); false when the
+// counts are not a prefix code or the second level does not fit
+bool derive(const mjx_huff_spec_t *spec, TableBuilder &B, bool is_dc) {
+    if(B.ntab >= 8) return false;
+    unsigned *lut = B.lut[B.ntab];
+    memset(lut, 0, sizeof(B.lut[0]));
     int total = 0;
     for(int l = 0; l < 16; ++l) total += spec->bits[l];
     if(total < 1 || total > 256) return false;
     unsigned code = 0;
     int      p = 0;
     for(int l = 1; l <= 16; ++l) {
-        const int n = spec->bits[l - 1];
-        T->valoff[idx][l] = p - (int)code;
-        for(int i = 0; i < n; ++i, ++p, ++code) {
+        for(int i = 0; i < spec->bits[l - 1]; ++i, ++p, ++code) {
             if(code >= (1u << l)) return false;
+            const unsigned e = make_entry(l, spec->vals[p], is_dc);
             if(l <= kLutBits) {
                 const unsigned first = code << (kLutBits - l), count = 1u << (kLutBits - l);
-                for(unsigned e = 0; e < count; ++e) T->lut[idx][first + e] = (uint16_t)((l << 8) | spec->vals[p]);
+                for(unsigned j = 0; j < count; ++j) lut[first + j] = e;
+            }
+            else {
+                const unsigned prefix = code >> (l - kLutBits), rest = (code & ((1u << (l - kLutBits)) - 1u)) << (16 - l);
+                if(lut[prefix] == 0) {
+                    if(B.nsub >= kMaxSubTables) return false;
+                    memset(B.sub[B.nsub], 0, sizeof(B.sub[0]));
+                    lut[prefix] = kEntryLink | (unsigned)(B.nsub << kSubBits);
+                    B.nsub++;
+                }
+                else if(!(lut[prefix] & kEntryLink)) {
+                    return false; // a shorter code already owns this prefix
+                }
+                unsigned *sub = B.sub[(lut[prefix] & 0xFFFFu) >> kSubBits];
+                for(unsigned j = 0; j < (1u << (16 - l)); ++j) sub[rest + j] = e;
             }
         }
-        T->maxcode[idx][l] = n ? (int)code - 1 : -1;
         code <<= 1;
     }
-    T->maxcode[idx][0] = -1;
-    T->valoff[idx][0] = 0;
-    memcpy(T->vals[idx], spec->vals, 256);
+    B.ntab++;
     return true;
+}
+
+// scan data as it stands in the file -> bytes without stuffing, the restart segments' offsets.
+// false when the data is not a plain run of [segment RSTn]* segment EOI (fill bytes, markers out of
+// sequence, no EOI inside the buffer, ...: libjpeg knows what to do with those)
+bool unstuff(const unsigned char *src, size_t n, unsigned char *dst, size_t *outlen, unsigned long long *segs, long long max_segs, long long *nsegs) {
+    size_t    i = 0, o = 0;
+    long long ns = 1;
+    int       expect = 0;
+    segs[0] = 0;
+    for(;;) {
+        const unsigned char *ff = static_cast<const unsigned char *>(memchr(src + i, 0xFF, n - i));
+        if(ff == nullptr) return false;
+        const size_t run = (size_t)(ff - (src + i));
+        memcpy(dst + o, src + i, run);
+        o += run;
+        i += run;
+        if(i + 1 >= n) return false;
+        const unsigned char marker = src[i + 1];
+        if(marker == 0x00) {
+            dst[o++] = 0xFF;
+        }
+        else if(marker >= 0xD0 && marker <= 0xD7) {
+            if(marker != 0xD0 + expect || ns >= max_segs) return false;
+            expect = (expect + 1) & 7;
+            segs[ns++] = o;
+        }
+        else if(marker == 0xD9) {
+            *outlen = o;
+            *nsegs = ns;
+            return true;
+        }
+        else {
+            return false;
+        }
+        i += 2;
+    }
+}
+
+} // namespace
+
+// ---- combining concurrent callers into one batch ------------------------------------------
+namespace {
+
+struct Request {
+    DecJob   job;        // flags is filled in by the batch leader
+    Arena   *arena;      // the caller's staging arena: its buffers stay valid while the request is pending
+    size_t   lds_bytes;
+    char    *plane_ptr[4]; // device
+    size_t   plane_len[4];
+    unsigned chunk_wgs, dc_wgs;
+    size_t   o_batch, pin_batch; // where a leader keeps the batch's descriptors and flags in this request's arena
+    int      result, rounds;
+    bool     done;
+};
+
+constexpr size_t kBatchBytes = ((sizeof(DecJob) * kMaxBatch + 255) & ~(size_t)255) + (((size_t)kFlagInts * 4 * kMaxBatch + 255) & ~(size_t)255);
+constexpr size_t kBatchFlagsAt = (sizeof(DecJob) * kMaxBatch + 255) & ~(size_t)255;
+
+pthread_mutex_t g_batch_lock = PTHREAD_MUTEX_INITIALIZER;
+pthread_cond_t  g_batch_done = PTHREAD_COND_INITIALIZER;
+Request        *g_queue[256];
+int             g_queued = 0;
+bool            g_leader_active = false;
+
+// the leader's part: one set of kernels over all images of the batch, on the leader's stream
+void run_batch(Request *lead, Request **batch, int n) {
+    hipStream_t s = lead->arena->stream;
+    char       *dev = lead->arena->dev + lead->o_batch, *pin = lead->arena->pin + lead->pin_batch;
+    DecJob     *h_jobs = reinterpret_cast<DecJob *>(pin), *d_jobs = reinterpret_cast<DecJob *>(dev);
+    int        *h_flags = reinterpret_cast<int *>(pin + kBatchFlagsAt), *d_flags = reinterpret_cast<int *>(dev + kBatchFlagsAt);
+    auto        fail_all = [&](int code) {
+        for(int i = 0; i < n; ++i)
+            if(batch[i]->result < 0) batch[i]->result = code;
+    };
+    for(int i = 0; i < n; ++i) {
+        batch[i]->result = -1;
+        batch[i]->job.flags = d_flags + (size_t)i * kFlagInts;
+        if(batch[i] != lead && hipStreamWaitEvent(s, batch[i]->arena->staged, 0) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+    }
+    if(hipMemsetAsync(d_flags, 0, sizeof(int) * (size_t)kFlagInts * (size_t)n, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+
+    int pending[kMaxBatch], npending = n, round = 0;
+    for(int i = 0; i < n; ++i) pending[i] = i;
+    while(npending > 0) {
+        const int first = round, nrounds = round == 0 ? kFirstRounds : kMoreRounds;
+        unsigned  cbx = 1, dbx = 1, gcx = 1, gdx = 1;
+        size_t    lds = 0;
+        for(int k = 0; k < npending; ++k) {
+            const Request *r = batch[pending[k]];
+            h_jobs[k] = r->job;
+            if(r->chunk_wgs > cbx) cbx = r->chunk_wgs;
+            if(r->dc_wgs > dbx) dbx = r->dc_wgs;
+            if((unsigned)r->job.chunk_groups > gcx) gcx = (unsigned)r->job.chunk_groups;
+            if((unsigned)r->job.dc_groups > gdx) gdx = (unsigned)r->job.dc_groups;
+            if(r->lds_bytes > lds) lds = r->lds_bytes;
+        }
+        if(hipMemcpyAsync(d_jobs, h_jobs, sizeof(DecJob) * (size_t)npending, hipMemcpyHostToDevice, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+        const unsigned m = (unsigned)npending;
+        // 1. synchronisation rounds.  Settled rounds cost a launch each, so a generous batch of them
+        //    is queued together with everything that follows; the flags are looked at once, at the
+        //    end, and only an image that had not settled by then goes round again.
+        for(int r = 0; r < nrounds; ++r, ++round) hipLaunchKernelGGL(huffdec_sync_kernel, dim3(cbx, m), dim3(kDecThreads), lds, s, d_jobs, round);
+        // 2.-4. block offsets, coefficients, DC values (wasted for an image whose rounds had not settled: rare)
+        hipLaunchKernelGGL(huffdec_scan_groups_kernel, dim3(gcx, m), dim3(kScanThreads), 0, s, d_jobs, 0);
+        hipLaunchKernelGGL(huffdec_scan_totals_kernel, dim3(1, m), dim3(kScanThreads), 0, s, d_jobs, 0);
+        hipLaunchKernelGGL(huffdec_store_kernel, dim3(cbx, m), dim3(kDecThreads), lds, s, d_jobs);
+        hipLaunchKernelGGL(huffdec_dc_gather_kernel, dim3(dbx, m), dim3(256), 0, s, d_jobs);
+        hipLaunchKernelGGL(huffdec_scan_groups_kernel, dim3(gdx, m), dim3(kScanThreads), 0, s, d_jobs, 1);
+        hipLaunchKernelGGL(huffdec_scan_totals_kernel, dim3(1, m), dim3(kScanThreads), 0, s, d_jobs, 1);
+        hipLaunchKernelGGL(huffdec_dc_finish_kernel, dim3(dbx, m), dim3(256), 0, s, d_jobs);
+        if(hipGetLastError() != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+        if(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * (size_t)kFlagInts * (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+        if(hipStreamSynchronize(s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+
+        int keep = 0;
+        for(int k = 0; k < npending; ++k) {
+            Request   *r = batch[pending[k]];
+            const int *f = h_flags + (size_t)pending[k] * kFlagInts;
+            bool       settled = r->job.nchunks == 1;
+            for(int q = first > 1 ? first : 1; q < round && !settled; ++q) settled = f[1 + q] == 0;
+            r->rounds = round;
+            if(settled) {
+                r->result = f[0] != 0 ? MJX_ERR_BAD_ARG : MJX_OK;
+            }
+            else if(round + kMoreRounds > kMaxRounds) {
+                r->result = MJX_ERR_BAD_ARG; // does not settle: leave it to the sequential decoder
+            }
+            else { // the store pass ran on unsettled states: wipe what it wrote and go round again
+                for(int c = 0; c < r->job.S.ncomp; ++c)
+                    if(hipMemsetAsync(r->plane_ptr[c], 0, r->plane_len[c], s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+                if(hipMemsetAsync(r->job.flags, 0, sizeof(int), s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+                pending[keep++] = pending[k];
+            }
+        }
+        npending = keep;
+    }
+}
+
+// joins the queue; whoever finds no batch in flight leads one over everything queued at that moment
+void submit(Request *req) {
+    pthread_mutex_lock(&g_batch_lock);
+    g_queue[g_queued++] = req; // the queue holds at most one request per arena
+    while(!req->done) {
+        if(g_leader_active) {
+            pthread_cond_wait(&g_batch_done, &g_batch_lock);
+            continue;
+        }
+        Request *batch[kMaxBatch];
+        int      n = 0;
+        bool     mine = false;
+        for(int i = 0; i < g_queued && n < kMaxBatch; ++i) mine |= g_queue[i] == req, batch[n++] = g_queue[i];
+        if(!mine) batch[n - 1] = req; // more queued than a batch takes: make sure the leader's own image is in it
+        int left = 0;
+        for(int i = 0; i < g_queued; ++i) {
+            bool taken = false;
+            for(int k = 0; k < n; ++k) taken |= batch[k] == g_queue[i];
+            if(!taken) g_queue[left++] = g_queue[i];
+        }
+        g_queued = left;
+        g_leader_active = true;
+        pthread_mutex_unlock(&g_batch_lock);
+        run_batch(req, batch, n);
+        pthread_mutex_lock(&g_batch_lock);
+        for(int k = 0; k < n; ++k) batch[k]->done = true;
+        g_leader_active = false;
+        pthread_cond_broadcast(&g_batch_done);
+    }
+    pthread_mutex_unlock(&g_batch_lock);
 }
 
 } // namespace
 
 extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     if(scan == nullptr || scan->data == nullptr) return MJX_ERR_NULL_DATA;
-    if(scan->ncomp < 1 || scan->ncomp > 4 || scan->mcus_x <= 0 || scan->mcus_y <= 0 || scan->restart_interval < 0) return MJX_ERR_BAD_ARG;
+    if(scan->ncomp < 1 || scan->ncomp > 4 || scan->mcus_x <= 0 || scan->mcus_y <= 0 || scan->restart_interval < 0 || scan->nbytes < 2) return MJX_ERR_BAD_ARG;
 
-    DecScan S;
-    memset(&S, 0, sizeof(S));
+    Request req;
+    memset(&req, 0, sizeof(req));
+    DecScan &S = req.job.S;
     S.ncomp = scan->ncomp;
     S.mcus_x = scan->mcus_x;
     S.mcus_y = scan->mcus_y;
@@ -355,18 +615,35 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     const long long nmcu = (long long)S.mcus_x * S.mcus_y;
     size_t          plane_bytes[4] = {0, 0, 0, 0}, planes_total = 0;
     long long       ndc = 0;
+    const bool      on_device = (scan->flags & MJX_HUFF_PLANES_ON_DEVICE) != 0;
+    int             dc_of[4] = {-1, -1, -1, -1}, ac_of[4] = {-1, -1, -1, -1}; // table id -> staged index
+    TableBuilder   *B = new(std::nothrow) TableBuilder;
+    if(B == nullptr) return MJX_ERR_MEMORY;
+    struct Free {
+        TableBuilder *b;
+        ~Free() { delete b; }
+    } free_builder{B};
+    int comp_dc[4] = {0, 0, 0, 0}, comp_ac[4] = {0, 0, 0, 0};
     for(int c = 0; c < S.ncomp; ++c) {
         const mjx_huff_dcomponent_t &h = scan->comp[c];
         if(h.plane == nullptr) return MJX_ERR_NULL_DATA;
         if(h.h_samp < 1 || h.h_samp > 4 || h.v_samp < 1 || h.v_samp > 4 || (long long)h.blocks_per_row < (long long)S.mcus_x * h.h_samp || h.dc_tbl < 0 ||
            h.dc_tbl > 3 || h.ac_tbl < 0 || h.ac_tbl > 3 || scan->dc[h.dc_tbl] == nullptr || scan->ac[h.ac_tbl] == nullptr)
             return MJX_ERR_BAD_ARG;
+        if(dc_of[h.dc_tbl] < 0) {
+            dc_of[h.dc_tbl] = B->ntab;
+            if(!derive(scan->dc[h.dc_tbl], *B, true)) return MJX_ERR_BAD_ARG;
+        }
+        if(ac_of[h.ac_tbl] < 0) {
+            ac_of[h.ac_tbl] = B->ntab;
+            if(!derive(scan->ac[h.ac_tbl], *B, false)) return MJX_ERR_BAD_ARG;
+        }
+        comp_dc[c] = dc_of[h.dc_tbl];
+        comp_ac[c] = ac_of[h.ac_tbl];
         DecComp &d = S.c[c];
         d.bpr = h.blocks_per_row;
         d.hs = h.h_samp;
         d.vs = h.v_samp;
-        d.dc_tbl = h.dc_tbl;
-        d.ac_tbl = h.ac_tbl;
         d.nslots = h.h_samp * h.v_samp;
         d.jbase = ndc;
         ndc += nmcu * d.nslots;
@@ -376,147 +653,156 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
                 S.slot_comp[S.bpm] = c;
                 S.slot_x[S.bpm] = x;
                 S.slot_y[S.bpm] = y;
+                S.dcpack |= (unsigned long long)comp_dc[c] << (4 * S.bpm);
+                S.acpack |= (unsigned long long)comp_ac[c] << (4 * S.bpm);
                 S.bpm++;
             }
         plane_bytes[c] = (size_t)S.mcus_y * (size_t)h.v_samp * (size_t)h.blocks_per_row * 128;
-        planes_total += up256(plane_bytes[c]);
+        if(!on_device) planes_total += up256(plane_bytes[c]);
     }
     S.nslots = nmcu * S.bpm;
+    S.ntab = B->ntab;
+    S.nsub = B->nsub;
+    if(S.nslots > 0x7FFFFFFFll) return MJX_ERR_BAD_ARG;
     for(S.period = 1; S.period < S.bpm; ++S.period) {
         if(S.bpm % S.period) continue;
         bool same = true;
         for(int i = S.period; i < S.bpm && same; ++i) {
-            const DecComp &a = S.c[S.slot_comp[i]], &b = S.c[S.slot_comp[i - S.period]];
-            same = a.dc_tbl == b.dc_tbl && a.ac_tbl == b.ac_tbl;
+            const int a = S.slot_comp[i], b = S.slot_comp[i - S.period];
+            same = comp_dc[a] == comp_dc[b] && comp_ac[a] == comp_ac[b];
         }
         if(same) break;
     }
+    const size_t table_words = ((size_t)S.ntab << kLutBits) + ((size_t)S.nsub << kSubBits);
+    const size_t lds_bytes = (table_words + (size_t)kChunkWords * kDecThreads) * 4 + sizeof(DecScan);
+    if(lds_bytes > 64 * 1024) return MJX_ERR_BAD_ARG; // more distinct long-code tables than a workgroup can stage
 
-    // restart segments -> chunk table
-    const int       nseg = (scan->segment_offsets != nullptr && scan->nsegments > 0) ? scan->nsegments : 1;
     const long long want_seg = S.ri > 0 ? (nmcu + S.ri - 1) / S.ri : 1;
-    if((long long)nseg != want_seg) return MJX_ERR_BAD_ARG;
-    long long nchunks = 0;
-    for(int g = 0; g < nseg; ++g) {
-        const size_t b0 = scan->segment_offsets ? (size_t)scan->segment_offsets[g] : 0;
-        const size_t b1 = g + 1 < nseg ? (size_t)scan->segment_offsets[g + 1] : scan->nbytes;
-        if(b0 >= b1 || b1 > scan->nbytes) return MJX_ERR_BAD_ARG; // every segment holds at least one byte
-        nchunks += (long long)(((b1 - b0) * 8 + kChunkBits - 1) / kChunkBits);
-    }
-    if(nchunks > 0x7FFFFFFFll / 2) return MJX_ERR_BAD_ARG;
+    if(want_seg > (long long)(scan->nbytes / 2 + 1)) return MJX_ERR_BAD_ARG;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
 
-    constexpr int   kMaxRounds = 192, kRoundsPerCheck = 6;
-    const long long gc = scan_group_count(nchunks), gd = scan_group_count(ndc);
-    const size_t    data_words = (scan->nbytes + 3) / 4 + kChunkWords + 1;
+    // bounds known before the data has been looked at (the staging buffers are sized with them)
+    const long long max_chunks = (long long)((scan->nbytes * 8 + kChunkBits - 1) / kChunkBits) + want_seg;
+    if(max_chunks > 0x7FFFFFFFll / 2) return MJX_ERR_BAD_ARG;
+    const long long gc = (max_chunks + kScanItems - 1) / kScanItems, gd = (ndc + kScanItems - 1) / kScanItems;
+    const size_t    data_bytes = ((scan->nbytes + 3) & ~(size_t)3) + (size_t)(kChunkWords + 1) * 4;
 
     size_t       off = 0;
-    const size_t o_tables = off; off += up256(sizeof(DecTables));
-    const size_t o_chunks = off; off += up256((size_t)nchunks * sizeof(DecChunk));
-    const size_t o_misc = off;   off += up256(64 + sizeof(int) * (kMaxRounds + 1)); // [0] total blocks, [1] dc total, error @16, changed[] @64
-    const size_t o_words = off;  off += up256(data_words * 4);
-    const size_t o_exit = off;   off += up256((size_t)nchunks * 8);
-    const size_t o_seen = off;   off += up256((size_t)nchunks * 8);
-    const size_t o_nblk = off;   off += up256((size_t)nchunks * 4);
-    const size_t o_cpre = off;   off += up256((size_t)nchunks * 4);
+    const size_t o_tables = off; off += up256(table_words * 4);
+    const size_t o_chunks = off; off += up256((size_t)max_chunks * sizeof(DecChunk));
+    const size_t o_totals = off; off += 256;
+    const size_t o_batch = off;  off += kBatchBytes;
+    const size_t o_words = off;  off += up256(data_bytes);
+    const size_t o_exit = off;   off += up256((size_t)max_chunks * 8);
+    const size_t o_seen = off;   off += up256((size_t)max_chunks * 8);
+    const size_t o_nblk = off;   off += up256((size_t)max_chunks * 4);
+    const size_t o_cpre = off;   off += up256((size_t)max_chunks * 4);
     const size_t o_ctot = off;   off += up256((size_t)gc * 8);
     const size_t o_diff = off;   off += up256((size_t)ndc * 4);
     const size_t o_dpre = off;   off += up256((size_t)ndc * 4);
     const size_t o_dtot = off;   off += up256((size_t)gd * 8);
     const size_t o_planes = off; off += planes_total;
 
-    const size_t pin_tables = 0, pin_chunks = up256(sizeof(DecTables)), pin_misc = pin_chunks + up256((size_t)nchunks * sizeof(DecChunk));
+    // pinned: tables | chunk table | unstuffed data | segment offsets | batch descriptors and flags
+    const size_t pin_tables = 0, pin_chunks = up256(table_words * 4), pin_data = pin_chunks + up256((size_t)max_chunks * sizeof(DecChunk));
+    const size_t pin_segs = pin_data + up256(data_bytes), pin_batch = pin_segs + up256((size_t)(want_seg + 1) * 8);
     ArenaLease   arena;
-    int          err = arena->prepare(off, pin_misc + 512);
+    int          err = arena->prepare(off, pin_batch + kBatchBytes);
     if(err != MJX_OK) return err;
     char       *base = arena->dev;
     hipStream_t s = arena->stream;
 
-    DecTables *ht = reinterpret_cast<DecTables *>(arena->pin + pin_tables);
-    memset(ht, 0, sizeof(DecTables));
-    for(int i = 0; i < 4; ++i) {
-        if(scan->dc[i] && !derive(scan->dc[i], ht, i)) return MJX_ERR_BAD_ARG;
-        if(scan->ac[i] && !derive(scan->ac[i], ht, 4 + i)) return MJX_ERR_BAD_ARG;
-    }
+    static const bool debug = getenv("MJX_HUFFDEC_DEBUG") != nullptr;
+    double            t_mark[4] = {0, 0, 0, 0};
+    auto              mark = [&](int i) {
+        if(!debug) return;
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        t_mark[i] = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    };
+    mark(0);
+
+    // 0. unstuff into the pinned buffer, cut into chunks, upload on this caller's stream
+    unsigned char      *h_data = reinterpret_cast<unsigned char *>(arena->pin + pin_data);
+    unsigned long long *h_segs = reinterpret_cast<unsigned long long *>(arena->pin + pin_segs);
+    size_t              rawlen = 0;
+    long long           nseg = 0;
+    if(!unstuff(scan->data, scan->nbytes, h_data, &rawlen, h_segs, want_seg, &nseg)) return MJX_ERR_BAD_ARG;
+    if(nseg != want_seg || rawlen == 0) return MJX_ERR_BAD_ARG;
+    const size_t upload_bytes = ((rawlen + 3) & ~(size_t)3) + (size_t)(kChunkWords + 1) * 4;
+    memset(h_data + rawlen, 0, upload_bytes - rawlen);
+    memcpy(arena->pin + pin_tables, B->lut, (size_t)S.ntab << (kLutBits + 2));
+    memcpy(arena->pin + pin_tables + ((size_t)S.ntab << (kLutBits + 2)), B->sub, (size_t)S.nsub << (kSubBits + 2));
     DecChunk *hc = reinterpret_cast<DecChunk *>(arena->pin + pin_chunks);
-    {
-        long long n = 0;
-        for(int g = 0; g < nseg; ++g) {
-            const unsigned long long b0 = (scan->segment_offsets ? scan->segment_offsets[g] : 0) * 8ull;
-            const unsigned long long b1 = (g + 1 < nseg ? scan->segment_offsets[g + 1] : (unsigned long long)scan->nbytes) * 8ull;
-            for(unsigned long long b = b0; b < b1; b += kChunkBits, ++n) {
-                hc[n].start = b;
-                hc[n].end = b + kChunkBits < b1 ? b + kChunkBits : b1;
-                hc[n].seg = g;
-                hc[n].flags = (b == b0 ? 1 : 0) | (b + kChunkBits >= b1 ? 2 : 0);
-            }
+    long long nchunks = 0;
+    for(long long g = 0; g < nseg; ++g) {
+        const unsigned long long b0 = h_segs[g] * 8ull, b1 = (g + 1 < nseg ? h_segs[g + 1] : (unsigned long long)rawlen) * 8ull;
+        if(b0 >= b1) return MJX_ERR_BAD_ARG; // every segment holds at least one byte
+        for(unsigned long long b = b0; b < b1 && nchunks < max_chunks; b += kChunkBits, ++nchunks) {
+            hc[nchunks].start = b;
+            hc[nchunks].end = b + kChunkBits < b1 ? b + kChunkBits : b1;
+            hc[nchunks].seg = (int)g;
+            hc[nchunks].flags = (b == b0 ? 1 : 0) | (b + kChunkBits >= b1 ? 2 : 0);
         }
     }
-    MJX_HIP(hipMemcpyAsync(base + o_tables, ht, sizeof(DecTables), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipMemcpyAsync(base + o_tables, arena->pin + pin_tables, table_words * 4, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
     MJX_HIP(hipMemcpyAsync(base + o_chunks, hc, (size_t)nchunks * sizeof(DecChunk), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-    MJX_HIP(hipMemsetAsync(base + o_misc, 0, up256(64 + sizeof(int) * (kMaxRounds + 1)), s), MJX_ERR_LAUNCH);
-    MJX_HIP(hipMemsetAsync(base + o_words + (scan->nbytes & ~(size_t)3), 0, data_words * 4 - (scan->nbytes & ~(size_t)3), s), MJX_ERR_LAUNCH);
-    MJX_HIP(hipMemcpyAsync(base + o_words, scan->data, scan->nbytes, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-    MJX_HIP(hipMemsetAsync(base + o_planes, 0, planes_total, s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipMemcpyAsync(base + o_words, h_data, upload_bytes, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipMemsetAsync(base + o_totals, 0, 256, s), MJX_ERR_LAUNCH);
     {
         size_t po = o_planes;
         for(int c = 0; c < S.ncomp; ++c) {
-            S.c[c].plane = reinterpret_cast<int16_t *>(base + po);
-            po += up256(plane_bytes[c]);
+            if(on_device) {
+                S.c[c].plane = scan->comp[c].plane;
+                req.plane_ptr[c] = reinterpret_cast<char *>(scan->comp[c].plane);
+            }
+            else {
+                S.c[c].plane = reinterpret_cast<int16_t *>(base + po);
+                req.plane_ptr[c] = base + po;
+                po += up256(plane_bytes[c]);
+            }
+            req.plane_len[c] = plane_bytes[c];
+            MJX_HIP(hipMemsetAsync(req.plane_ptr[c], 0, plane_bytes[c], s), MJX_ERR_LAUNCH);
         }
     }
+    MJX_HIP(hipEventRecord(arena->staged, s), MJX_ERR_LAUNCH);
+    DecJob &J = req.job;
+    J.tables = reinterpret_cast<const unsigned *>(base + o_tables);
+    J.words = reinterpret_cast<const unsigned *>(base + o_words);
+    J.chunks = reinterpret_cast<const DecChunk *>(base + o_chunks);
+    J.exits = reinterpret_cast<unsigned long long *>(base + o_exit);
+    J.seen = reinterpret_cast<unsigned long long *>(base + o_seen);
+    J.nblk = reinterpret_cast<unsigned *>(base + o_nblk);
+    J.cpre = reinterpret_cast<unsigned *>(base + o_cpre);
+    J.ctot = reinterpret_cast<unsigned long long *>(base + o_ctot);
+    J.diff = reinterpret_cast<unsigned *>(base + o_diff);
+    J.dpre = reinterpret_cast<unsigned *>(base + o_dpre);
+    J.dtot = reinterpret_cast<unsigned long long *>(base + o_dtot);
+    J.totals = reinterpret_cast<unsigned long long *>(base + o_totals);
+    J.ndc = ndc;
+    J.nchunks = (int)nchunks;
+    J.chunk_groups = (int)((nchunks + kScanItems - 1) / kScanItems);
+    J.dc_groups = (int)gd;
+    req.arena = arena.a;
+    req.lds_bytes = lds_bytes;
+    req.chunk_wgs = (unsigned)((nchunks + kDecThreads - 1) / kDecThreads);
+    req.dc_wgs = (unsigned)((ndc + 255) / 256);
+    req.o_batch = o_batch;
+    req.pin_batch = pin_batch;
+    mark(1);
 
-    const DecTables    *d_tables = reinterpret_cast<const DecTables *>(base + o_tables);
-    const DecChunk     *d_chunks = reinterpret_cast<const DecChunk *>(base + o_chunks);
-    unsigned long long *d_misc = reinterpret_cast<unsigned long long *>(base + o_misc);
-    int                *d_error = reinterpret_cast<int *>(base + o_misc + 16);
-    int                *d_changed = reinterpret_cast<int *>(base + o_misc + 64);
-    const unsigned     *d_words = reinterpret_cast<const unsigned *>(base + o_words);
-    unsigned long long *d_exit = reinterpret_cast<unsigned long long *>(base + o_exit), *d_seen = reinterpret_cast<unsigned long long *>(base + o_seen);
-    unsigned           *d_nblk = reinterpret_cast<unsigned *>(base + o_nblk), *d_cpre = reinterpret_cast<unsigned *>(base + o_cpre);
-    unsigned long long *d_ctot = reinterpret_cast<unsigned long long *>(base + o_ctot);
-    unsigned           *d_diff = reinterpret_cast<unsigned *>(base + o_diff), *d_dpre = reinterpret_cast<unsigned *>(base + o_dpre);
-    unsigned long long *d_dtot = reinterpret_cast<unsigned long long *>(base + o_dtot);
-
-    // 1. synchronisation rounds
-    const unsigned cb = (unsigned)((nchunks + kDecThreads - 1) / kDecThreads);
-    int           *h_changed = reinterpret_cast<int *>(arena->pin + pin_misc);
-    bool           converged = nchunks == 1;
-    int            round = 0;
-    if(converged) {
-        hipLaunchKernelGGL(huffdec_sync_kernel, dim3(cb), dim3(kDecThreads), 0, s, S, d_tables, d_words, d_chunks, (int)nchunks, d_exit, d_seen, d_nblk, d_changed, 0);
-    }
-    while(!converged && round < kMaxRounds) {
-        const int first = round;
-        for(int r = 0; r < kRoundsPerCheck && round < kMaxRounds; ++r, ++round)
-            hipLaunchKernelGGL(huffdec_sync_kernel, dim3(cb), dim3(kDecThreads), 0, s, S, d_tables, d_words, d_chunks, (int)nchunks, d_exit, d_seen, d_nblk, d_changed,
-                               round);
-        MJX_HIP(hipGetLastError(), MJX_ERR_LAUNCH);
-        MJX_HIP(hipMemcpyAsync(h_changed, d_changed, sizeof(int) * (size_t)kMaxRounds, hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
+    // 1.-4. on the GPU, together with whoever else is decoding right now
+    submit(&req);
+    mark(2);
+    if(debug) fprintf(stderr, "mjx_huff_decode_host: %lld chunks, %d sync rounds launched, result %d\n", nchunks, req.rounds, req.result);
+    if(req.result != MJX_OK) return req.result;
+    if(!on_device) {
+        for(int c = 0; c < S.ncomp; ++c) MJX_HIP(hipMemcpyAsync(scan->comp[c].plane, S.c[c].plane, plane_bytes[c], hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
         MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
-        for(int r = first > 1 ? first : 1; r < round; ++r)
-            if(h_changed[r] == 0) converged = true;
     }
-    static const bool debug = getenv("MJX_HUFFDEC_DEBUG") != nullptr;
-    if(debug) fprintf(stderr, "mjx_huff_decode_host: %lld chunks, %d sync rounds launched, %s\n", nchunks, round, converged ? "settled" : "NOT settled");
-    if(!converged) return MJX_ERR_BAD_ARG; // did not settle: leave it to the sequential decoder
-
-    // 2.-4. block offsets, coefficients, DC values
-    const unsigned db = (unsigned)((ndc + 255) / 256);
-    launch_scan_exclusive(d_nblk, d_cpre, d_ctot, nchunks, d_misc + 0, s);
-    hipLaunchKernelGGL(huffdec_store_kernel, dim3(cb), dim3(kDecThreads), 0, s, S, d_tables, d_words, d_chunks, (int)nchunks, d_exit, d_cpre, d_ctot, scan_group_items(),
-                       d_misc + 0, d_error);
-    hipLaunchKernelGGL(huffdec_dc_gather_kernel, dim3(db), dim3(256), 0, s, S, ndc, d_diff);
-    launch_scan_exclusive(d_diff, d_dpre, d_dtot, ndc, d_misc + 1, s);
-    hipLaunchKernelGGL(huffdec_dc_finish_kernel, dim3(db), dim3(256), 0, s, S, ndc, d_diff, d_dpre, d_dtot, scan_group_items(), d_error);
-    MJX_HIP(hipGetLastError(), MJX_ERR_LAUNCH);
-
-    int *h_error = reinterpret_cast<int *>(arena->pin + pin_misc + 256);
-    MJX_HIP(hipMemcpyAsync(h_error, d_error, sizeof(int), hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
-    MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
-    if(debug && *h_error != 0) fprintf(stderr, "mjx_huff_decode_host: stream refused (flags %d)\n", *h_error);
-    if(*h_error != 0) return MJX_ERR_BAD_ARG;
-    for(int c = 0; c < S.ncomp; ++c) MJX_HIP(hipMemcpyAsync(scan->comp[c].plane, S.c[c].plane, plane_bytes[c], hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
-    MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
+    mark(3);
+    if(debug)
+        fprintf(stderr, "mjx_huff_decode_host: %zu bytes of scan data, unstuff+stage %.3f ms, batch %.3f ms, download %.3f ms (%zu bytes)\n", rawlen, t_mark[1] - t_mark[0],
+                t_mark[2] - t_mark[1], t_mark[3] - t_mark[2], planes_total);
     return MJX_OK;
 }

@@ -17,6 +17,7 @@
 // output); they exist to take the 11 ms per image of host Huffman coding off the critical path and
 // to shrink the D2H transfer from 6.3 MB of coefficients to the compressed bytes.
 #include "mjx_internal.hpp"
+#include "mjx_scan.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -205,61 +206,14 @@ __global__ __launch_bounds__(kHuffThreads) void huff_emit_kernel(HuffScan S, con
     if(nacc > 0) atomicOr(&words[widx], (unsigned)(acc << (32 - nacc)));
 }
 
-// ---- exclusive prefix sums -------------------------------------------------------------
-// scan_groups: every workgroup scans kScanItems consecutive elements (exclusive, relative to the
-// group start) and stores the group total; scan_totals: one workgroup turns the totals into
-// exclusive prefixes (in place) and stores the grand total.
-constexpr int kScanThreads = 256, kScanPerThread = 8, kScanItems = kScanThreads * kScanPerThread;
-
+// ---- exclusive prefix sums (bodies in mjx_scan.hpp, shared with the decoder) -------------
 __global__ __launch_bounds__(kScanThreads) void scan_groups_kernel(const unsigned *__restrict__ in, unsigned *__restrict__ out, unsigned long long *__restrict__ totals,
                                                                     long long n) {
-    __shared__ unsigned part[kScanThreads];
-    const long long     base = (long long)blockIdx.x * kScanItems + (long long)threadIdx.x * kScanPerThread;
-    unsigned            v[kScanPerThread], sum = 0;
-#pragma unroll
-    for(int i = 0; i < kScanPerThread; ++i) {
-        v[i] = (base + i < n) ? in[base + i] : 0u;
-        sum += v[i];
-    }
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for(int d = 1; d < kScanThreads; d <<= 1) { // Hillis-Steele inclusive scan of the thread sums
-        const unsigned add = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
-    }
-    unsigned run = part[threadIdx.x] - sum;
-#pragma unroll
-    for(int i = 0; i < kScanPerThread; ++i) {
-        if(base + i < n) out[base + i] = run;
-        run += v[i];
-    }
-    if(threadIdx.x == kScanThreads - 1) totals[blockIdx.x] = part[threadIdx.x];
+    scan_groups_body(in, out, totals, n, blockIdx.x);
 }
 
 __global__ __launch_bounds__(kScanThreads) void scan_totals_kernel(unsigned long long *__restrict__ totals, long long ngroups, unsigned long long *__restrict__ grand) {
-    __shared__ unsigned long long part[kScanThreads];
-    __shared__ unsigned long long carry;
-    if(threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for(long long base = 0; base < ngroups; base += kScanThreads) {
-        const long long          i = base + threadIdx.x;
-        const unsigned long long v = i < ngroups ? totals[i] : 0ull;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for(int d = 1; d < kScanThreads; d <<= 1) {
-            const unsigned long long add = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0ull;
-            __syncthreads();
-            part[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if(i < ngroups) totals[i] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if(threadIdx.x == kScanThreads - 1) carry += part[threadIdx.x];
-        __syncthreads();
-    }
-    if(threadIdx.x == 0) *grand = carry;
+    scan_totals_body(totals, ngroups, grand);
 }
 
 // exclusive scan of n unsigned values: out[i] (relative to its group of kScanItems) + totals[i / kScanItems]
@@ -334,7 +288,8 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
     S.mcus_x = scan->mcus_x;
     S.mcus_y = scan->mcus_y;
     S.max_coef_bits = scan->max_coef_bits > 0 ? scan->max_coef_bits : 10;
-    size_t plane_bytes[4] = {0, 0, 0, 0}, planes_total = 0;
+    size_t     plane_bytes[4] = {0, 0, 0, 0}, planes_total = 0;
+    const bool on_device = (scan->flags & MJX_HUFF_PLANES_ON_DEVICE) != 0;
     for(int c = 0; c < S.ncomp; ++c) {
         const mjx_huff_component_t &h = scan->comp[c];
         if(h.plane == nullptr) return MJX_ERR_NULL_DATA;
@@ -362,7 +317,7 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
                 S.bpm++;
             }
         plane_bytes[c] = (size_t)h.height_in_blocks * (size_t)h.blocks_per_row * 128;
-        planes_total += up256(plane_bytes[c]);
+        if(!on_device) planes_total += up256(plane_bytes[c]);
     }
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
 
@@ -409,6 +364,10 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
 
     size_t po = o_planes;
     for(int c = 0; c < S.ncomp; ++c) {
+        if(on_device) {
+            S.c[c].plane = scan->comp[c].plane;
+            continue;
+        }
         MJX_HIP(hipMemcpyAsync(base + po, scan->comp[c].plane, plane_bytes[c], hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
         S.c[c].plane = reinterpret_cast<const int16_t *>(base + po);
         po += up256(plane_bytes[c]);

@@ -64,6 +64,7 @@ struct Arena {
     char       *pin = nullptr;
     size_t      pin_cap = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t  staged = nullptr; // recorded by a caller whose uploads another stream must wait for
     void        release();
     int         prepare(size_t dev_bytes, size_t pin_bytes);
 };

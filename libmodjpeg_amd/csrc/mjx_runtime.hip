@@ -286,8 +286,9 @@ namespace mjx {
 void Arena::release() {
         if(dev) (void)hipFree(dev);
         if(pin) (void)hipHostFree(pin);
+        if(staged) (void)hipEventDestroy(staged);
         if(stream) (void)hipStreamDestroy(stream);
-        dev = nullptr; pin = nullptr; stream = nullptr; dev_cap = pin_cap = 0; device = -1;
+        dev = nullptr; pin = nullptr; stream = nullptr; staged = nullptr; dev_cap = pin_cap = 0; device = -1;
 }
 
 int Arena::prepare(size_t dev_bytes, size_t pin_bytes) {
@@ -299,6 +300,9 @@ int Arena::prepare(size_t dev_bytes, size_t pin_bytes) {
         }
         if(stream == nullptr) {
             if(int e = check_hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate", MJX_ERR_LAUNCH)) return e;
+        }
+        if(staged == nullptr) {
+            if(int e = check_hip(hipEventCreateWithFlags(&staged, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH)) return e;
         }
         if(dev_bytes > dev_cap) {
             if(dev) (void)hipFree(dev);
@@ -322,7 +326,7 @@ int Arena::prepare(size_t dev_bytes, size_t pin_bytes) {
 // millisecond out of the ~17 ms a thread spends on one 1080p image (entropy decode/encode on the
 // host), so a handful of arenas serves any number of threads; creating one per thread instead
 // costs ~6 ms of serialised driver work per thread (measured with the batch CLI at 64 threads).
-constexpr int   kMaxArenas = 8;
+constexpr int   kMaxArenas = 32;
 Arena           g_pool[kMaxArenas];
 bool            g_busy[kMaxArenas];
 pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -330,7 +334,19 @@ pthread_cond_t  g_pool_free = PTHREAD_COND_INITIALIZER;
 
 // borrow an arena that already lives on the calling thread's device if there is one, else an
 // unused slot; blocks while all slots are busy
+// arenas in use at most (MJX_ARENAS, default 16): each owns a stream, and more streams than
+// hardware queues buy no further overlap
+int arena_limit() {
+        static const int n = [] {
+            const char *e = getenv("MJX_ARENAS");
+            const int   v = e ? atoi(e) : 16;
+            return v < 1 ? 1 : (v > kMaxArenas ? kMaxArenas : v);
+        }();
+        return n;
+}
+
 ArenaLease::ArenaLease() {
+        const int kMaxArenas = arena_limit();
         int cur = 0;
         (void)hipGetDevice(&cur);
         pthread_mutex_lock(&g_pool_lock);
@@ -416,7 +432,7 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     for(int i = 0; i < n; ++i) {
         const mjx_host_rect_t &r = rects[i];
         if(r.rows == 0 || r.cols == 0) continue;
-        data_bytes += round256((size_t)r.rows * r.blocks_per_row * 128);
+        if(!(r.flags & MJX_RECT_ROWS_ON_DEVICE)) data_bytes += round256((size_t)r.rows * r.blocks_per_row * 128);
         if(!(r.flags & MJX_RECT_TILES_ON_DEVICE)) data_bytes += 2 * round256((size_t)r.rows * r.cols * 256);
     }
     // upper bound of the packet: jobs may be split (never for real JPEG sizes) -> size after build
@@ -455,10 +471,16 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         if(r.rows == 0 || r.cols == 0) continue;
         const size_t cb = (size_t)r.rows * r.blocks_per_row * 128, tb = (size_t)r.rows * r.cols * 256;
         mjx_rect_job_t &j = jobs[k++];
-        j.coef = reinterpret_cast<int16_t *>(base + off);
-        coef_off.push_back(off);
-        MJX_HIP(hipMemcpyAsync(base + off, r.rows_ptr, cb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-        off += round256(cb);
+        if(r.flags & MJX_RECT_ROWS_ON_DEVICE) {
+            j.coef = r.rows_ptr;
+            coef_off.push_back(0);
+        }
+        else {
+            j.coef = reinterpret_cast<int16_t *>(base + off);
+            coef_off.push_back(off);
+            MJX_HIP(hipMemcpyAsync(base + off, r.rows_ptr, cb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+            off += round256(cb);
+        }
         if(r.flags & MJX_RECT_TILES_ON_DEVICE) {
             j.tile = r.tile;
             j.alpha = r.alpha;
@@ -493,8 +515,10 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         for(int i = 0; i < n && err == MJX_OK; ++i) {
             const mjx_host_rect_t &r = rects[i];
             if(r.rows == 0 || r.cols == 0) continue;
-            err = check_hip(hipMemcpyAsync(r.rows_ptr, base + coef_off[k++], (size_t)r.rows * r.blocks_per_row * 128, hipMemcpyDeviceToHost, s),
-                            "hipMemcpyAsync(D2H)", MJX_ERR_LAUNCH);
+            const size_t at = coef_off[k++];
+            if(r.flags & MJX_RECT_ROWS_ON_DEVICE) continue;
+            err = check_hip(hipMemcpyAsync(r.rows_ptr, base + at, (size_t)r.rows * r.blocks_per_row * 128, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H)",
+                            MJX_ERR_LAUNCH);
         }
     }
     const int serr = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
@@ -660,6 +684,46 @@ int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols,
     if(err != MJX_OK) return err;
     MJX_HIP(hipMemcpyAsync(plane, arena->dev, bytes, hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
     MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
+    return MJX_OK;
+}
+
+// the effects on a plane that already lives on the device: one launch on a pooled stream
+int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value) {
+    if(rows < 0 || cols < 0 || blocks_per_row < cols) return MJX_ERR_BAD_ARG;
+    if(rows == 0 || cols == 0) return MJX_OK;
+    if(plane == nullptr) return MJX_ERR_NULL_DATA;
+    if(q0 == 0 || (int64_t)rows * cols > 0x7FFFFFFFll) return MJX_ERR_BAD_ARG;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    ArenaLease arena;
+    int        err = arena->prepare(256, 256);
+    if(err != MJX_OK) return err;
+    DevDcJob *j = reinterpret_cast<DevDcJob *>(arena->pin);
+    j->coef = plane;
+    j->bpr = blocks_per_row;
+    j->rows = rows;
+    j->cols = cols;
+    j->value = value;
+    j->q0 = q0;
+    j->rq0 = rq_of(q0);
+    hipStream_t s = arena->stream;
+    MJX_HIP(hipMemcpyAsync(arena->dev, j, sizeof(DevDcJob), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    err = launch_effect_dc(reinterpret_cast<const DevDcJob *>(arena->dev), 1, (int64_t)rows * cols, s);
+    if(err != MJX_OK) return err;
+    MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
+    return MJX_OK;
+}
+
+int mjx_effect_zero_device(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc) {
+    if(rows < 0 || cols < 0 || blocks_per_row < cols) return MJX_ERR_BAD_ARG;
+    if(rows == 0 || cols == 0) return MJX_OK;
+    if(plane == nullptr) return MJX_ERR_NULL_DATA;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    ArenaLease arena;
+    int        err = arena->prepare(256, 256);
+    if(err != MJX_OK) return err;
+    err = launch_effect_zero(plane, blocks_per_row, rows, cols, keep_dc ? 1 : 0, arena->stream);
+    if(err != MJX_OK) return err;
+    MJX_HIP(hipStreamSynchronize(arena->stream), MJX_ERR_LAUNCH);
     return MJX_OK;
 }
 

@@ -118,6 +118,7 @@ static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int til
     int16_t        *staged[MAXC] = {NULL, NULL, NULL, NULL};
     int             row0[MAXC];
     int             c, i, rv = MJ_OK;
+    mjh_shadow_t   *shadow = mjh_shadow_of(m);
 
     if(n > MAXC || n > m->cinfo.num_components) return MJ_ERR_DROPON_DIMENSIONS;
     memset(rect, 0, sizeof(rect));
@@ -149,7 +150,14 @@ static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int til
         rect[c].q = q[c];
         rect[c].tile = ct[c].tile;
         rect[c].alpha = ct[c].alpha;
-        plane = mjh_plane_direct(m, c, &bpr); /* bpr becomes the array pitch (whole MCUs) */
+        if(shadow != NULL) { /* device-resident image: blend in place, nothing but descriptors moves */
+            plane = shadow->plane[c];
+            bpr = shadow->pitch[c];
+            rect[c].flags |= MJX_RECT_ROWS_ON_DEVICE;
+        }
+        else {
+            plane = mjh_plane_direct(m, c, &bpr); /* bpr becomes the array pitch (whole MCUs) */
+        }
         rect[c].blocks_per_row = bpr;
         if(plane != NULL) {
             rect[c].rows_ptr = plane + (size_t)row0[c] * (size_t)bpr * 64;

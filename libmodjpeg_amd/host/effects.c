@@ -10,6 +10,9 @@
 /* run `op` on the true width_in_blocks x height_in_blocks area of component c */
 typedef int (*plane_op_t)(int16_t *plane, int bpr, int rows, int cols, const jpeg_component_info *ci, int arg);
 
+static int op_dc(int16_t *plane, int bpr, int rows, int cols, const jpeg_component_info *ci, int value);
+static int op_zero(int16_t *plane, int bpr, int rows, int cols, const jpeg_component_info *ci, int keep_dc);
+
 static int on_component(mj_jpeg_t *m, int c, plane_op_t op, int arg) {
     jpeg_component_info *ci = &m->cinfo.comp_info[c];
     const int            rows = (int)ci->height_in_blocks, cols = (int)ci->width_in_blocks;
@@ -17,6 +20,12 @@ static int on_component(mj_jpeg_t *m, int c, plane_op_t op, int arg) {
     int                  rv;
 
     if(rows == 0 || cols == 0) return MJ_OK;
+    if(mjh_shadow_of(m) != NULL) { /* device-resident image: one launch on the plane where it is */
+        mjh_shadow_t *s = mjh_shadow_of(m);
+        if(op == op_zero) return mjh_from_mjx(mjx_effect_zero_device(s->plane[c], s->pitch[c], rows, cols, arg));
+        if(ci->quant_table == NULL || ci->quant_table->quantval[0] == 0) return MJ_ERR_NULL_DATA;
+        return mjh_from_mjx(mjx_effect_dc_device(s->plane[c], s->pitch[c], rows, cols, ci->quant_table->quantval[0], arg));
+    }
     {
         int pitch = 0; /* libjpeg keeps a plane of this size in one chunk: work on it in place */
         plane = mjh_plane_direct(m, c, &pitch);

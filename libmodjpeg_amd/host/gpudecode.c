@@ -8,8 +8,8 @@
  * memory: the coefficient arrays are requested from its memory manager exactly as jdcoefct.c
  * does for a transcoding read (whole MCUs, pre-zeroed, JPOOL_IMAGE), so everything downstream —
  * mj_compose, the effects, jpeg_write_coefficients, mj_free_jpeg — sees the same object it would
- * after jpeg_read_coefficients().  Here the scan data is located in the source buffer, the
- * 0xFF00 stuffing and the RSTn markers are removed, and mjx_huff_decode_host() fills the arrays;
+ * after jpeg_read_coefficients().  The scan data is handed to mjx_huff_decode_host() where it
+ * lies in the source buffer, and the decoded planes land in those arrays;
  * tests/test_dropin_shim.py compares them with libjpeg's for every sampling and odd size.
  */
 #include "mjhost.h"
@@ -19,6 +19,13 @@
 
 int mjh_gpu_decode_count = 0; /* how many files went through the GPU entropy decoder (tests) */
 
+#include <time.h>
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
 #define BAIL(code, why)                                                                              \
     do {                                                                                             \
         if(getenv("MJ_DEBUG") != NULL) fprintf(stderr, "gpudecode: fall back to libjpeg: %s\n", why); \
@@ -26,54 +33,16 @@ int mjh_gpu_decode_count = 0; /* how many files went through the GPU entropy dec
         goto done;                                                                                   \
     } while(0)
 
-/* scan data -> bytes without stuffing, restart segments split; returns 0 when the data is not a
- * plain run of [segment RSTn]* segment EOI */
-static int unstuff(const unsigned char *src, size_t n, unsigned char *dst, size_t *outlen, uint64_t *segs, int max_segs, int *nsegs) {
-    size_t i = 0, o = 0;
-    int    ns = 1, expect = 0;
-    segs[0] = 0;
-    for(;;) {
-        const unsigned char *ff = (const unsigned char *)memchr(src + i, 0xFF, n - i);
-        size_t               run;
-        unsigned char        marker;
-        if(ff == NULL) return 0; /* ran off the buffer without EOI: libjpeg's business */
-        run = (size_t)(ff - (src + i));
-        memcpy(dst + o, src + i, run);
-        o += run;
-        i += run;
-        if(i + 1 >= n) return 0;
-        marker = src[i + 1];
-        if(marker == 0x00) {
-            dst[o++] = 0xFF;
-        }
-        else if(marker >= 0xD0 && marker <= 0xD7) {
-            if(marker != 0xD0 + expect || ns >= max_segs) return 0; /* out of sequence: libjpeg resynchronises */
-            expect = (expect + 1) & 7;
-            segs[ns++] = (uint64_t)o;
-        }
-        else if(marker == 0xD9) {
-            *outlen = o;
-            *nsegs = ns;
-            return 1;
-        }
-        else {
-            return 0; /* fill bytes, DNL, another scan ... */
-        }
-        i += 2;
-    }
-}
-
 int mjh_read_gpu_entropy(mj_jpeg_t *m) {
     struct jpeg_decompress_struct *d = &m->cinfo;
     mjx_huff_dscan_t               sc;
     mjx_huff_spec_t                specs[8];
     jvirt_barray_ptr              *arrays;
-    unsigned char                 *raw = NULL;
-    uint64_t                      *segs = NULL;
     int16_t                       *staged[4] = {NULL, NULL, NULL, NULL};
-    size_t                         rawlen = 0, avail;
+    mjh_shadow_t                  *shadow = NULL;
     long long                      nmcu;
-    int                            c, i, rv = MJH_DECODE_UNSUPPORTED, nsegs = 0, max_segs, blocks_in_mcu = 0;
+    double                         t1 = 0, t2 = 0;
+    int                            c, i, rv = MJH_DECODE_UNSUPPORTED, blocks_in_mcu = 0;
 
     /* ---- what this path decodes (nothing has been touched yet: "clean" bail-outs) ---- */
     {
@@ -116,8 +85,7 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
     }
     nmcu = (long long)sc.mcus_x * sc.mcus_y;
     sc.restart_interval = (int)d->restart_interval;
-    max_segs = d->restart_interval ? (int)((nmcu + d->restart_interval - 1) / d->restart_interval) : 1;
-    if(d->restart_interval && (nmcu + d->restart_interval - 1) / d->restart_interval > 0x7FFFFFF) BAIL(MJH_DECODE_UNSUPPORTED, "too many restart segments");
+    if(d->restart_interval > 0x7FFFFFFF || nmcu > 0x7FFFFFFF) BAIL(MJH_DECODE_UNSUPPORTED, "image too large");
 
     /* Huffman tables as the file defined them */
     for(i = 0; i < 4; i++) {
@@ -133,20 +101,11 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
         }
     }
 
-    /* scan data: from the byte after the SOS header to EOI */
-    avail = d->src->bytes_in_buffer;
-    raw = (unsigned char *)malloc(avail + 8);
-    segs = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(max_segs + 1));
-    if(raw == NULL || segs == NULL) BAIL(MJH_DECODE_UNSUPPORTED, "out of memory");
-    if(!unstuff(d->src->next_input_byte, avail, raw, &rawlen, segs, max_segs, &nsegs)) BAIL(MJH_DECODE_UNSUPPORTED, "scan data is not a plain segment list");
-    if(nsegs != max_segs || rawlen == 0) BAIL(MJH_DECODE_UNSUPPORTED, "restart segment count");
-    sc.data = raw;
-    sc.nbytes = rawlen;
-    if(d->restart_interval) {
-        sc.segment_offsets = segs;
-        sc.nsegments = nsegs;
-    }
-
+    /* scan data: from the byte after the SOS header, as it stands in the file (the decoder removes
+     * the stuffing and splits the restart segments while it stages the bytes) */
+    sc.data = d->src->next_input_byte;
+    sc.nbytes = d->src->bytes_in_buffer;
+    t1 = now_ms();
     /* ---- from here on the object is modified: failures are "dirty" ---- */
     /* what transdecode_master_selection() computes before the coefficient controller starts;
      * jpeg_copy_critical_parameters() reads output_width/height and min_DCT_*_scaled_size */
@@ -160,25 +119,46 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
         memcpy(q, d->quant_tbl_ptrs[ci->quant_tbl_no], sizeof(JQUANT_TBL));
         ci->quant_table = q;
     }
-    /* jdcoefct.c jinit_d_coef_controller(need_full_buffer): whole-MCU arrays, pre-zeroed */
+    /* jdcoefct.c jinit_d_coef_controller(need_full_buffer): whole-MCU arrays.  libjpeg asks for them
+     * pre-zeroed because its decoder only stores non-zero coefficients; here every row of the MCU
+     * grid is written whole by the device copy, so the zeroing pass (a memset of the full image)
+     * is only requested when the array has rows beyond that grid. */
     arrays = (jvirt_barray_ptr *)(*d->mem->alloc_small)((j_common_ptr)d, JPOOL_IMAGE, sizeof(jvirt_barray_ptr) * MAX_COMPONENTS);
     memset(arrays, 0, sizeof(jvirt_barray_ptr) * MAX_COMPONENTS);
     for(c = 0; c < d->num_components; c++) {
         const jpeg_component_info *ci = &d->comp_info[c];
-        arrays[c] = (*d->mem->request_virt_barray)((j_common_ptr)d, JPOOL_IMAGE, TRUE, (JDIMENSION)mjh_row_pitch(m, c), (JDIMENSION)mjh_row_count(m, c),
+        const int                  vs = d->num_components == 1 ? 1 : ci->v_samp_factor;
+        const boolean              pre_zero = mjh_row_count(m, c) != sc.mcus_y * vs ? TRUE : FALSE;
+        arrays[c] = (*d->mem->request_virt_barray)((j_common_ptr)d, JPOOL_IMAGE, pre_zero, (JDIMENSION)mjh_row_pitch(m, c), (JDIMENSION)mjh_row_count(m, c),
                                                    (JDIMENSION)ci->v_samp_factor);
     }
     (*d->mem->realize_virt_arrays)((j_common_ptr)d);
     m->coef = arrays;
     rv = MJH_DECODE_FAILED;
+    t2 = now_ms();
 
+    /* device-resident mode: the planes stay on the device as the image's shadow and the arrays
+     * above stay unfilled until somebody needs them (shadow.c) */
+    if(mjh_device_resident()) {
+        int fits = 1;
+        for(c = 0; c < d->num_components; c++) {
+            const int vs = d->num_components == 1 ? 1 : d->comp_info[c].v_samp_factor;
+            if(mjh_row_count(m, c) != sc.mcus_y * vs) fits = 0; /* rows beyond the MCU grid would need zeroing */
+        }
+        if(fits) shadow = mjh_shadow_create(m);
+    }
     for(c = 0; c < d->num_components; c++) {
         const jpeg_component_info *ci = &d->comp_info[c];
         const int                  hs = d->num_components == 1 ? 1 : ci->h_samp_factor, vs = d->num_components == 1 ? 1 : ci->v_samp_factor;
         int                        pitch = 0;
         int16_t                   *plane = NULL;
+        if(shadow != NULL) {
+            plane = shadow->plane[c];
+            pitch = shadow->pitch[c];
+            sc.flags = MJX_HUFF_PLANES_ON_DEVICE;
+        }
         /* decode straight into libjpeg's array when it is one piece and exactly the MCU grid */
-        if(mjh_row_count(m, c) == sc.mcus_y * vs) plane = mjh_plane_direct(m, c, &pitch);
+        else if(mjh_row_count(m, c) == sc.mcus_y * vs) plane = mjh_plane_direct(m, c, &pitch);
         if(plane == NULL) {
             pitch = mjh_row_pitch(m, c);
             staged[c] = (int16_t *)malloc((size_t)sc.mcus_y * (size_t)vs * (size_t)pitch * sizeof(JBLOCK));
@@ -201,11 +181,14 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
         if(staged[c] != NULL) mjh_rows_scatter(m, c, 0, sc.mcus_y * sc.comp[c].v_samp, staged[c]);
     __sync_fetch_and_add(&mjh_gpu_decode_count, 1);
     rv = MJ_OK;
+    if(getenv("MJ_DEBUG") != NULL)
+        fprintf(stderr, "gpudecode: arrays %.3f ms, decode %.3f ms\n", t2 - t1, now_ms() - t2);
 
 done:
     for(c = 0; c < 4; c++) free(staged[c]);
-    free(raw);
-    free(segs);
-    if(rv != MJ_OK) m->coef = NULL;
+    if(rv != MJ_OK) {
+        if(shadow != NULL) mjh_shadow_drop(m);
+        m->coef = NULL;
+    }
     return rv;
 }

@@ -102,6 +102,7 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len) {
     mjx_huff_scan_t  sc;
     int16_t         *gathered[4] = {NULL, NULL, NULL, NULL};
     int              c, i, rv, ns = 0, sel[4], td[4], ta[4];
+    mjh_shadow_t    *shadow = mjh_shadow_of(m);
 
     if(m->cinfo.num_components < 1 || m->cinfo.num_components > 4 || m->cinfo.data_precision != 8) return MJH_ENCODE_UNSUPPORTED;
     rv = tiny_jpeg(m, &hdr, &hdrlen);
@@ -177,7 +178,14 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len) {
             if(m->cinfo.comp_info[c].component_id == sel[i]) ci = &m->cinfo.comp_info[c];
         if(ci == NULL || td[i] > 3 || ta[i] > 3 || !have_dc[td[i]] || !have_ac[ta[i]]) BAIL("component/table lookup");
         c = (int)(ci - m->cinfo.comp_info);
-        plane = mjh_plane_direct(m, c, &pitch);
+        if(shadow != NULL) { /* device-resident image: the encoder reads the planes where they are */
+            plane = shadow->plane[c];
+            pitch = shadow->pitch[c];
+            sc.flags = MJX_HUFF_PLANES_ON_DEVICE;
+        }
+        else {
+            plane = mjh_plane_direct(m, c, &pitch);
+        }
         if(plane == NULL) {
             pitch = mjh_row_pitch(m, c);
             gathered[i] = (int16_t *)malloc((size_t)ci->height_in_blocks * (size_t)pitch * sizeof(JBLOCK));

@@ -78,6 +78,7 @@ void mj_init_jpeg(mj_jpeg_t *m) {
 
 void mj_free_jpeg(mj_jpeg_t *m) {
     if(m == NULL) return;
+    mjh_shadow_drop(m);
     /* a zeroed cinfo has mem == NULL, which jpeg_destroy tolerates */
     jpeg_destroy_decompress(&m->cinfo);
     mj_init_jpeg(m);
@@ -182,6 +183,10 @@ int mj_write_jpeg_to_memory(mj_jpeg_t *m, unsigned char **memory, size_t *len, i
     if(options == MJ_OPTION_NONE && !(getenv("MJ_GPU_ENCODE") != NULL && getenv("MJ_GPU_ENCODE")[0] == '0')) {
         const int rv = mjh_write_gpu_entropy(m, memory, len);
         if(rv != MJH_ENCODE_UNSUPPORTED) return rv;
+    }
+    { /* libjpeg encodes from its own arrays: a device-resident image comes down first */
+        const int rv = mjh_host_sync(m);
+        if(rv != MJ_OK) return rv;
     }
 
     mjh_trap_install(&trap, (j_common_ptr)&out);
@@ -339,6 +344,7 @@ static JBLOCKROW coef_row(mj_jpeg_t *m, int c, int row, boolean writable) {
 
 int16_t *mjh_plane_direct(mj_jpeg_t *m, int c, int *pitch) {
     const jpeg_component_info *ci = &m->cinfo.comp_info[c];
+    if(mjh_host_sync(m) != MJ_OK) return NULL; /* (a device-resident image becomes a host image here) */
     /* what jdcoefct.c asked the memory manager for: rows of whole MCUs */
     const size_t row_blocks = (size_t)mjh_row_pitch(m, c);
     JBLOCKROW    first, prev;
@@ -367,12 +373,14 @@ int mjh_row_count(const mj_jpeg_t *m, int c) {
 }
 
 void mjh_rows_gather(mj_jpeg_t *m, int c, int row0, int nrows, int16_t *dst) {
+    (void)mjh_host_sync(m);
     const size_t row_bytes = (size_t)mjh_row_pitch(m, c) * sizeof(JBLOCK);
     int          r;
     for(r = 0; r < nrows; r++) memcpy((char *)dst + (size_t)r * row_bytes, coef_row(m, c, row0 + r, FALSE), row_bytes);
 }
 
 void mjh_rows_scatter(mj_jpeg_t *m, int c, int row0, int nrows, const int16_t *src) {
+    (void)mjh_host_sync(m);
     const size_t row_bytes = (size_t)mjh_row_pitch(m, c) * sizeof(JBLOCK);
     int          r;
     for(r = 0; r < nrows; r++) memcpy(coef_row(m, c, row0 + r, TRUE), (const char *)src + (size_t)r * row_bytes, row_bytes);

@@ -9,6 +9,7 @@
  *      tiles.c    overlay -> DCT-domain tiles ("compiled dropon")      (dropon.c:325-576, :606-)
  *      compose.c  placement geometry + masked compose on the GPU       (compose.c, convolve.c)
  *      effects.c  per-block effects on the GPU                         (effect.c)
+ *      shadow.c   device-resident images for the batch pipeline        (no counterpart)
  */
 #ifndef MJHOST_H_
 #define MJHOST_H_
@@ -66,6 +67,24 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len);
 #define MJH_DECODE_UNSUPPORTED (-1)
 #define MJH_DECODE_FAILED      (-2)
 int mjh_read_gpu_entropy(mj_jpeg_t *m);
+
+/* device-resident images (shadow.c): in this opt-in mode the planes the GPU decoder produced stay
+ * on the device as the image's "shadow" (kept in cinfo.client_data), compose/effects/encode work
+ * on them there and libjpeg's host arrays stay unfilled until mjh_host_sync() downloads them. */
+typedef struct mjh_shadow {
+    uint32_t magic;
+    int      ncomp;
+    int16_t *plane[4]; /* DEVICE: rows[c] x pitch[c] blocks, the geometry of libjpeg's array */
+    int      pitch[4], rows[4];
+    void    *buffer;
+    size_t   bytes;
+} mjh_shadow_t;
+void          mjh_set_device_resident(int on);
+int           mjh_device_resident(void);
+mjh_shadow_t *mjh_shadow_of(const mj_jpeg_t *m); /* NULL: an ordinary host image */
+mjh_shadow_t *mjh_shadow_create(mj_jpeg_t *m);
+void          mjh_shadow_drop(mj_jpeg_t *m);
+int           mjh_host_sync(mj_jpeg_t *m);
 
 /* prepared tiles resident on the device, cached across mj_compose calls (tilecache.c).
  * acquire() sets *out = NULL (and returns MJ_OK) when the cache is disabled or full of busy

@@ -10,9 +10,12 @@
  *
  * where list.txt names one input JPEG per line ("-" = stdin).  Every file is read, run through
  * the script (all options except -i/-o, in order) and written to <outdir>/<basename>.  N host
- * threads work on different files: entropy decode/encode (libjpeg) runs on the host cores, the
- * block loops of every thread go to the GPU through the thread's own stream and staging arena,
- * and the prepared dropon tiles are shared by all of them (device-resident tile cache).
+ * threads work on different files.  An image is decoded on the GPU and STAYS there (shadow.c):
+ * compose and the effects run in place, the encoder reads the planes where they are, and only
+ * compressed bytes cross PCIe in either direction; concurrent decodes are launched as one batch.
+ * Files the GPU entropy coder declines (progressive, arithmetic, -O/-P/-A output) go through
+ * libjpeg as in the reference.  The prepared dropon tiles are shared by all threads
+ * (device-resident tile cache).
  */
 #include <libmodjpeg.h>
 
@@ -134,8 +137,15 @@ static int run_action(state_t *s, const action_t *a) {
 }
 
 /* ---- batch mode ---------------------------------------------------------------------- */
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
 typedef struct {
     char          **files;
+    double          t_read, t_script, t_write; /* summed over the workers (MJ_CLI_TIMING) */
     int             nfiles, next, failed;
     const action_t *script;
     int             nscript;
@@ -150,6 +160,7 @@ static void *batch_worker(void *arg) {
         action_t io;
         char     out[4096];
         int      k, i, bad = 0;
+        double   t0, t1, t2, t3;
 
         pthread_mutex_lock(&b->lock);
         k = b->next++;
@@ -157,12 +168,15 @@ static void *batch_worker(void *arg) {
         if(k >= b->nfiles) return NULL;
 
         state_init(&s);
+        t0 = now_ms();
         io.code = 'i';
         io.arg = b->files[k];
         bad = run_action(&s, &io);
+        t1 = now_ms();
         for(i = 0; i < b->nscript && !bad; i++) {
             if(b->script[i].code != 'i' && b->script[i].code != 'o') bad = run_action(&s, &b->script[i]);
         }
+        t2 = now_ms();
         if(!bad) {
             const char *base = strrchr(b->files[k], '/');
             snprintf(out, sizeof(out), "%s/%s", b->outdir, base != NULL ? base + 1 : b->files[k]);
@@ -171,13 +185,19 @@ static void *batch_worker(void *arg) {
             bad = run_action(&s, &io);
         }
         state_free(&s);
-        if(bad) {
-            pthread_mutex_lock(&b->lock);
-            b->failed++;
-            pthread_mutex_unlock(&b->lock);
-        }
+        t3 = now_ms();
+        pthread_mutex_lock(&b->lock);
+        if(bad) b->failed++;
+        b->t_read += t1 - t0;
+        b->t_script += t2 - t1;
+        b->t_write += t3 - t2;
+        pthread_mutex_unlock(&b->lock);
     }
 }
+
+/* drop-in internal (shadow.c): images stay on the device between read and write.  Safe here
+ * because this program only ever touches an image through the mj_* functions. */
+void mjh_set_device_resident(int on);
 
 static int run_batch(const char *list, const char *outdir, int jobs, const action_t *script, int nscript) {
     batch_t    b;
@@ -191,6 +211,7 @@ static int run_batch(const char *list, const char *outdir, int jobs, const actio
         fprintf(stderr, "Can't read the batch list '%s'\n", list);
         return 1;
     }
+    if(getenv("MJ_DEVICE_RESIDENT") == NULL) mjh_set_device_resident(1); /* MJ_DEVICE_RESIDENT=0 keeps the host arrays authoritative */
     memset(&b, 0, sizeof(b));
     while(fgets(line, sizeof(line), f) != NULL) {
         size_t n = strlen(line);
@@ -218,6 +239,12 @@ static int run_batch(const char *list, const char *outdir, int jobs, const actio
     {
         const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
         fprintf(stderr, "modjpeg: %d files, %d failed, %d threads, %.3f s, %.1f images/s\n", b.nfiles, b.failed, jobs, sec, sec > 0 ? b.nfiles / sec : 0.0);
+        if(getenv("MJ_CLI_TIMING") != NULL && b.nfiles > 0) {
+            extern int mjh_shadow_count, mjh_gpu_decode_count, mjh_gpu_encode_count;
+            fprintf(stderr, "modjpeg: per file, in the worker that had it: read %.3f ms, script %.3f ms, write+free %.3f ms\n", b.t_read / b.nfiles, b.t_script / b.nfiles,
+                    b.t_write / b.nfiles);
+            fprintf(stderr, "modjpeg: %d GPU entropy decodes, %d kept on the device, %d GPU entropy encodes\n", mjh_gpu_decode_count, mjh_shadow_count, mjh_gpu_encode_count);
+        }
     }
     free(th);
     for(t = 0; t < b.nfiles; t++) free(b.files[t]);

@@ -76,3 +76,43 @@ def test_batch_mode_equals_one_by_one(cli, tmp_path):
     want = ref.read_bytes()
     for k in range(12):
         assert (out / f"img{k:02d}.jpg").read_bytes() == want, k
+
+
+BATCH_SCRIPTS = [
+    ["-p", "br", "-m", "-10,-10", "-d", PNG, "-y", "20"],        # compose + luminance, GPU encoder
+    ["-x", "-p", "tr", "-d", PNG],                                # pixelate, then logo
+    ["-g", "-b", "-25", "-r", "15", "-y", "-30"],                 # grayscale, tint (no-ops on zeroed chroma DCs aside), luminance
+    ["-p", "cc", "-d", JPG, "-O"],                                # optimised output: libjpeg writes, the image comes down first
+    ["-y", "10", "-P"],                                           # progressive output
+]
+
+
+@pytest.mark.parametrize("sampling", ["420", "444", "gray"])
+@pytest.mark.parametrize("script", BATCH_SCRIPTS, ids=[str(i) for i in range(len(BATCH_SCRIPTS))])
+def test_batch_pipeline_keeps_images_on_the_device_and_matches_the_reference(cli, tmp_path, script, sampling):
+    """batch mode decodes on the GPU and leaves the planes there (shadow.c): compose, effects and the
+    encoder work on the device copy, libjpeg's host arrays are only filled when libjpeg itself has
+    to write.  Every output must equal what the reference CLI writes for the same file and script."""
+    if sampling == "gray" and "-d" in script:
+        pytest.skip("the reference cannot prepare a colour dropon for a gray image")
+    src = tmp_path / "in"
+    src.mkdir()
+    names = []
+    for k in range(6):
+        p = src / f"img{k}.jpg"
+        env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DUMP_INPUT=str(p), BENCH_QUALITY=str(60 + 7 * k), MJ_GPU_DECODE="0", MJ_GPU_ENCODE="0")
+        subprocess.check_output([os.path.join(HOST, "bench_dropin"), os.path.join(HOST, "libmodjpeg.so.1"), str(400 + 33 * k), str(300 + 17 * k), "16", "16", "1"], env=env)
+        names.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    res = subprocess.run([cli, "--batch", str(tmp_path / "list.txt"), "--outdir", str(out), "--jobs", "3"] + script, capture_output=True, text=True,
+                         env=dict(os.environ, MJ_CLI_TIMING="1", MJ_GPU_DECODE_MIN_BYTES="0"))
+    assert res.returncode == 0, res.stderr[-500:]
+    import re
+    kept = re.search(r"(\d+) kept on the device", res.stderr)
+    assert kept and int(kept.group(1)) >= 6, res.stderr[-500:]  # (the dropon's own tiles are read back through the same path)
+    for k, name in enumerate(names):
+        ref = tmp_path / f"ref{k}.jpg"
+        subprocess.run([REF_CLI, "-i", name] + script + ["-o", str(ref)], check=True, capture_output=True)
+        assert (out / f"img{k}.jpg").read_bytes() == ref.read_bytes(), k

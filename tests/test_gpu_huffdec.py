@@ -24,7 +24,7 @@ class DComponent(ctypes.Structure):
 class DScan(ctypes.Structure):
     _fields_ = [("ncomp", ctypes.c_int32), ("mcus_x", ctypes.c_int32), ("mcus_y", ctypes.c_int32), ("comp", DComponent * 4),
                 ("dc", ctypes.POINTER(HuffSpec) * 4), ("ac", ctypes.POINTER(HuffSpec) * 4), ("data", ctypes.c_void_p), ("nbytes", ctypes.c_size_t),
-                ("restart_interval", ctypes.c_int32), ("segment_offsets", ctypes.c_void_p), ("nsegments", ctypes.c_int32)]
+                ("restart_interval", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 def spec(bits, vals):
@@ -36,27 +36,11 @@ def spec(bits, vals):
     return s
 
 
-def unstuff(data):
-    """stuffed scan data -> (unstuffed bytes, segment offsets); RSTn markers split segments"""
-    out, segs, i = bytearray(), [0], 0
-    while i < len(data):
-        b = data[i]
-        if b == 0xFF:
-            nxt = data[i + 1]
-            if nxt == 0:
-                out.append(0xFF)
-            else:
-                assert 0xD0 <= nxt <= 0xD7
-                segs.append(len(out))
-            i += 2
-        else:
-            out.append(b)
-            i += 1
-    return bytes(out), segs
+EOI = b"\xff\xd9"
 
 
-def gpu_decode(data, segs, geom, mcus_x, mcus_y, restart=0, pitch_extra=0, tables=None):
-    """geom[c] = (hs, vs); returns rc, planes[c] int16[mcus_y*vs, bpr, 64]"""
+def gpu_decode(data, geom, mcus_x, mcus_y, restart=0, pitch_extra=0, tables=None):
+    """data: scan data as in a file (stuffed, RSTn, EOI); geom[c] = (hs, vs); returns rc, planes[c] int16[mcus_y*vs, bpr, 64]"""
     import torch  # noqa: F401
     from libmodjpeg_amd._lib import lib
     sc = DScan()
@@ -70,9 +54,6 @@ def gpu_decode(data, segs, geom, mcus_x, mcus_y, restart=0, pitch_extra=0, table
     sc.dc[0], sc.ac[0] = ctypes.pointer(dc), ctypes.pointer(ac)
     buf = np.frombuffer(data, np.uint8).copy()
     sc.data, sc.nbytes = buf.ctypes.data, len(data)
-    offs = np.asarray(segs, np.uint64)
-    if len(segs) > 1 or restart:
-        sc.segment_offsets, sc.nsegments = offs.ctypes.data, len(segs)
     rc = lib().mjx_huff_decode_host(ctypes.byref(sc))
     return rc, planes
 
@@ -98,8 +79,7 @@ def test_round_trip_with_the_gpu_encoder_420(mcus, density):
     egeom = [(p.shape[1], p.shape[0], hs, vs) for p, (hs, vs) in zip(planes, geom)]
     rc, data = gpu_encode(planes, egeom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS))
     assert rc == 0
-    raw, segs = unstuff(data)
-    rc, got = gpu_decode(raw, segs, geom, mcus_x, mcus_y, pitch_extra=3)
+    rc, got = gpu_decode(data + EOI + b"trailing bytes are not looked at", geom, mcus_x, mcus_y, pitch_extra=3)
     assert rc == 0
     for c in range(3):
         assert np.array_equal(got[c][:, :planes[c].shape[1]], planes[c]), c
@@ -174,9 +154,8 @@ def test_against_the_python_encoder_with_restart_segments(restart, geom):
     rng = np.random.default_rng(restart * 10 + len(geom))
     planes = random_planes(rng, geom, mcus_x, mcus_y, 0.15, 300)
     data = py_encode_restart(planes, geom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS), restart)
-    raw, segs = unstuff(data)
-    assert len(segs) == (-(-mcus_x * mcus_y // restart) if restart else 1)
-    rc, got = gpu_decode(raw, segs, geom, mcus_x, mcus_y, restart=restart)
+    assert data.count(b"\xff\xd0") + data.count(b"\xff\xd1") >= (1 if restart else 0)
+    rc, got = gpu_decode(data + EOI, geom, mcus_x, mcus_y, restart=restart)
     assert rc == 0
     for c in range(len(geom)):
         assert np.array_equal(got[c], planes[c]), c
@@ -189,8 +168,7 @@ def test_dc_wraps_like_a_jcoef_and_long_zero_runs():
     p[0, ::3, 63] = -1                                              # 62 zeros then a value: three ZRLs
     p[0, 1::3, 33] = 1023
     data = py_encode_restart([p], geom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS), 0)
-    raw, segs = unstuff(data)
-    rc, got = gpu_decode(raw, segs, geom, mcus_x, mcus_y)
+    rc, got = gpu_decode(data + EOI, geom, mcus_x, mcus_y)
     assert rc == 0 and np.array_equal(got[0], p)
 
 
@@ -199,14 +177,62 @@ def test_corrupt_or_mismatched_streams_are_refused_not_decoded():
     rng = np.random.default_rng(5)
     planes = random_planes(rng, geom, mcus_x, mcus_y, 0.2, 200)
     data = py_encode_restart(planes, geom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS), 0)
-    raw, segs = unstuff(data)
-    assert gpu_decode(raw, segs, geom, mcus_x, mcus_y)[0] == 0
-    assert gpu_decode(raw[:len(raw) // 2], segs, geom, mcus_x, mcus_y)[0] == 4       # truncated
-    assert gpu_decode(raw, segs, geom, mcus_x, mcus_y + 1)[0] == 4                    # more MCUs than the data holds
-    assert gpu_decode(raw, segs, geom, mcus_x, mcus_y - 1)[0] == 4                    # fewer
-    assert gpu_decode(raw, [0, 10], geom, mcus_x, mcus_y, restart=0)[0] == 4         # segment table without restarts
-    bad = spec([0, 3] + [0] * 14, [0, 1, 2])                                          # three codes of length 2 and nothing else is fine; 5 of length 2 is not
-    bad.bits[1] = 5
-    assert gpu_decode(raw, segs, geom, mcus_x, mcus_y, tables=(bad, spec(AC_BITS, AC_VALS)))[0] == 4
-    noise = bytes(rng.integers(0, 256, len(raw), dtype=np.uint8))
-    assert gpu_decode(noise, [0], geom, mcus_x, mcus_y)[0] == 4
+    ok = data + EOI
+    assert gpu_decode(ok, geom, mcus_x, mcus_y)[0] == 0
+    assert gpu_decode(data, geom, mcus_x, mcus_y)[0] == 4                                  # no EOI
+    assert gpu_decode(data[:len(data) // 2] + EOI, geom, mcus_x, mcus_y)[0] == 4           # truncated
+    assert gpu_decode(ok, geom, mcus_x, mcus_y + 1)[0] == 4                                # more MCUs than the data holds
+    assert gpu_decode(ok, geom, mcus_x, mcus_y - 1)[0] == 4                                # fewer
+    assert gpu_decode(ok, geom, mcus_x, mcus_y, restart=50)[0] == 4                        # restart segments promised, none there
+    assert gpu_decode(data[:100] + b"\xff\xd0" + data[100:] + EOI, geom, mcus_x, mcus_y)[0] == 4  # a restart marker nobody announced
+    assert gpu_decode(data[:100] + b"\xff\xff" + data[100:] + EOI, geom, mcus_x, mcus_y)[0] == 4  # fill bytes: libjpeg's business
+    with_rst = py_encode_restart(planes, geom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS), 50)
+    assert gpu_decode(with_rst + EOI, geom, mcus_x, mcus_y, restart=50)[0] == 0
+    assert gpu_decode(with_rst.replace(b"\xff\xd1", b"\xff\xd2") + EOI, geom, mcus_x, mcus_y, restart=50)[0] == 4  # out of sequence
+    bad = spec([0, 5] + [0] * 14, [0, 1, 2, 3, 4])                                          # five codes of length 2 are not a prefix code
+    assert gpu_decode(ok, geom, mcus_x, mcus_y, tables=(bad, spec(AC_BITS, AC_VALS)))[0] == 4
+    noise = bytes(b if b != 0xFF else 0xFE for b in rng.integers(0, 256, len(data), dtype=np.uint8))
+    assert gpu_decode(noise + EOI, geom, mcus_x, mcus_y)[0] == 4
+
+
+def test_decode_and_encode_on_planes_that_stay_on_the_device():
+    """MJX_HUFF_PLANES_ON_DEVICE on both entropy coders: scan data -> device planes -> scan data, and
+    the planes read back equal the ones the stream was made from (the batch pipeline's data path)"""
+    import torch  # noqa: F401
+    from libmodjpeg_amd._lib import lib
+    from tests.test_gpu_huffman import HuffComponent, HuffScan
+    L = lib()
+    geom, mcus_x, mcus_y = [(2, 2), (1, 1), (1, 1)], 60, 34
+    rng = np.random.default_rng(11)
+    planes = random_planes(rng, geom, mcus_x, mcus_y, 0.1, 500)
+    data = py_encode_restart(planes, geom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS), 0)
+    dev = []
+    for p in planes:
+        d = ctypes.c_void_p()
+        assert L.mjx_malloc(ctypes.byref(d), p.nbytes) == 0
+        dev.append(d)
+    sc = DScan()
+    sc.ncomp, sc.mcus_x, sc.mcus_y, sc.flags = 3, mcus_x, mcus_y, 1
+    for c, (hs, vs) in enumerate(geom):
+        sc.comp[c] = DComponent(dev[c].value, planes[c].shape[1], hs, vs, 0, 0)
+    dc, ac = spec(DC_BITS, DC_VALS), spec(AC_BITS, AC_VALS)
+    sc.dc[0], sc.ac[0] = ctypes.pointer(dc), ctypes.pointer(ac)
+    buf = np.frombuffer(data + EOI, np.uint8).copy()
+    sc.data, sc.nbytes = buf.ctypes.data, buf.size
+    assert L.mjx_huff_decode_host(ctypes.byref(sc)) == 0
+    for c, p in enumerate(planes):
+        back = np.empty_like(p)
+        assert L.mjx_memcpy_d2h(back.ctypes.data, dev[c], p.nbytes, None) == 0
+        assert np.array_equal(back, p), c
+    es = HuffScan()
+    es.ncomp, es.mcus_x, es.mcus_y, es.max_coef_bits, es.flags = 3, mcus_x, mcus_y, 10, 1
+    for c, (hs, vs) in enumerate(geom):
+        es.comp[c] = HuffComponent(dev[c].value, planes[c].shape[1], planes[c].shape[1], planes[c].shape[0], hs, vs, 0, 0)
+    edc, eac = derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS)
+    es.dc[0], es.ac[0] = ctypes.pointer(edc), ctypes.pointer(eac)
+    out, n = ctypes.c_void_p(), ctypes.c_size_t()
+    assert L.mjx_huff_encode_host(ctypes.byref(es), ctypes.byref(out), ctypes.byref(n)) == 0
+    assert ctypes.string_at(out, n.value) == data
+    ctypes.CDLL(None).free(out)
+    for d in dev:
+        L.mjx_free(d)
