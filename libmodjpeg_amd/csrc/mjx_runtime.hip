@@ -456,8 +456,10 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         qt.insert(qt.end(), r.q, r.q + 64);
     }
     const int    nq = (int)jobs.size();
-    const size_t packet_cap = round256(2 * jobs.size() * sizeof(DevJob)) + round256((size_t)nq * 64 * 6) +
-                              round256(((size_t)data_bytes / (kWaveBlocks * 128 * 2) + 4 * jobs.size() + 16) * sizeof(Run));
+    // runs hold at least two octets of 8 blocks each, plus a ragged one per (possibly split) job
+    size_t max_runs = 16;
+    for(const mjx_rect_job_t &j : jobs) max_runs += (size_t)j.rows * (size_t)j.cols / (kWaveBlocks * 2) + 4;
+    const size_t packet_cap = round256(2 * jobs.size() * sizeof(DevJob)) + round256((size_t)nq * 64 * 6) + round256(max_runs * sizeof(Run));
     ArenaLease arena;
     int        err = arena->prepare(packet_cap + data_bytes, packet_cap);
     if(err != MJX_OK) return err;

@@ -9,11 +9,11 @@ for i in $(seq 1 $n); do echo $work/in/img$(( (i % 16) + 1 )).jpg >> $work/list.
 cp tests/golden/images/dropon.png $work/logo.png
 nproc
 for jobs in 1 4 8 16 32; do
-  MJ_CLI_TIMING=1 $H/modjpeg --batch $work/list.txt --outdir $work/out --jobs $jobs -p br -m -10,-10 -d $work/logo.png -y 10 2>&1 | tail -2
+  MJ_CLI_TIMING=1 $H/modjpeg --batch $work/list.txt --outdir $work/out --jobs $jobs -p br -m -10,-10 -d $work/logo.png -y 10 2>&1 | tail -3
 done
 echo "== outputs to /dev/shm"
 mkdir -p /dev/shm/mjq_out
 for jobs in 8 16; do
-  MJ_CLI_TIMING=1 $H/modjpeg --batch $work/list.txt --outdir /dev/shm/mjq_out --jobs $jobs -p br -m -10,-10 -d $work/logo.png -y 10 2>&1 | tail -2
+  MJ_CLI_TIMING=1 $H/modjpeg --batch $work/list.txt --outdir /dev/shm/mjq_out --jobs $jobs -p br -m -10,-10 -d $work/logo.png -y 10 2>&1 | tail -3
 done
 rm -rf /dev/shm/mjq_out $work

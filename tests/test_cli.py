@@ -84,6 +84,7 @@ BATCH_SCRIPTS = [
     ["-g", "-b", "-25", "-r", "15", "-y", "-30"],                 # grayscale, tint (no-ops on zeroed chroma DCs aside), luminance
     ["-p", "cc", "-d", JPG, "-O"],                                # optimised output: libjpeg writes, the image comes down first
     ["-y", "10", "-P"],                                           # progressive output
+    ["-p", "cc", "-m", "5,-3", "-d", os.path.join(IMAGES, "image_dropon.jpg"), "-d", PNG],  # a 256x256 dropon (thousands of blocks per launch), then a small one
 ]
 
 
