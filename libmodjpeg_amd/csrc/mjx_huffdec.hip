@@ -579,7 +579,11 @@ void submit(Request *req) {
         Request *batch[kMaxBatch];
         int      n = 0;
         bool     mine = false;
-        for(int i = 0; i < g_queued && n < kMaxBatch; ++i) mine |= g_queue[i] == req, batch[n++] = g_queue[i];
+        for(int i = 0; i < g_queued && n < kMaxBatch; ++i) {
+            if(g_queue[i]->arena->device != req->arena->device) continue; // a batch is one launch set on one GPU
+            mine |= g_queue[i] == req;
+            batch[n++] = g_queue[i];
+        }
         if(!mine) batch[n - 1] = req; // more queued than a batch takes: make sure the leader's own image is in it
         int left = 0;
         for(int i = 0; i < g_queued; ++i) {

@@ -240,11 +240,22 @@ def test_dropon_colour_spaces_match_reference(shim, sampling, dropon):
 
 
 @pytest.mark.gpu
-def test_concurrent_compose_with_cache_evictions(shim):
+@pytest.mark.parametrize("mode", ["host", "gpu-decode", "device-resident"])
+def test_concurrent_compose_with_cache_evictions(shim, tmp_path, mode):
     """16 threads, 12 overlay placements (> 8 cache slots), shared arenas: every result equals the
-    single-threaded one for the same placement"""
-    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "stress", os.path.join(IMAGES, "image.jpg"), os.path.join(IMAGES, "dropon.png"), "16", "40"],
-                         capture_output=True, text=True)
+    single-threaded one for the same placement.  gpu-decode: every read goes through the batched GPU
+    entropy decoder (concurrent callers share one launch set); device-resident: the images also stay
+    on the device between read and write."""
+    image = os.path.join(IMAGES, "image.jpg")
+    env = dict(os.environ)
+    if mode != "host":
+        image = str(tmp_path / "big.jpg")
+        _make_input(image, ("800", "600"), "420")
+        env["MJ_GPU_DECODE_MIN_BYTES"] = "0"
+    if mode == "device-resident":
+        env["MJ_DEVICE_RESIDENT"] = "1"
+    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "stress", image, os.path.join(IMAGES, "dropon.png"), "16", "40"], capture_output=True, text=True,
+                         env=env)
     assert res.returncode == 0 and res.stdout.strip() == "ok", (res.stdout, res.stderr[-500:])
 
 
