@@ -25,15 +25,12 @@
 // raises an error flag; the caller then decodes with libjpeg, which owns the error semantics.
 //
 // The rounds are latency chains that occupy a sliver of the GPU, so concurrent callers are
-// combined: every caller stages its own image (own arena, own stream), then the first one to
-// arrive while no batch is in flight launches ONE set of kernels over all images staged at that
-// moment (blockIdx.y = image) and the others wait for it.  A lone caller is a batch of one and
-// waits for nobody.
+// combined into one launch set (mjx_combiner.hpp; blockIdx.y = image).
+#include "mjx_combiner.hpp"
 #include "mjx_internal.hpp"
 #include "mjx_scan.hpp"
 
 #include <new>
-#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -481,17 +478,25 @@ struct Request {
     unsigned chunk_wgs, dc_wgs;
     size_t   o_batch, pin_batch; // where a leader keeps the batch's descriptors and flags in this request's arena
     int      result, rounds;
-    bool     done;
+    bool     taken, done; // in a batch that is in flight / finished
 };
 
 constexpr size_t kBatchBytes = ((sizeof(DecJob) * kMaxBatch + 255) & ~(size_t)255) + (((size_t)kFlagInts * 4 * kMaxBatch + 255) & ~(size_t)255);
 constexpr size_t kBatchFlagsAt = (sizeof(DecJob) * kMaxBatch + 255) & ~(size_t)255;
 
-pthread_mutex_t g_batch_lock = PTHREAD_MUTEX_INITIALIZER;
-pthread_cond_t  g_batch_done = PTHREAD_COND_INITIALIZER;
-Request        *g_queue[256];
-int             g_queued = 0;
-bool            g_leader_active = false;
+Combiner<Request, kMaxBatch> g_combiner;
+
+// batches that may be in flight at once (MJX_DECODE_BATCHES).  One: measured with the batch CLI at
+// 8..48 threads, a second or third concurrent batch only makes all of them smaller
+// (profiles/r01_final/batch_cli_decode_batches.log).
+int max_leaders() {
+    static const int n = [] {
+        const char *e = getenv("MJX_DECODE_BATCHES");
+        const int   v = e ? atoi(e) : 1;
+        return v < 1 ? 1 : (v > 8 ? 8 : v);
+    }();
+    return n;
+}
 
 // the leader's part: one set of kernels over all images of the batch, on the leader's stream
 void run_batch(Request *lead, Request **batch, int n) {
@@ -565,42 +570,6 @@ void run_batch(Request *lead, Request **batch, int n) {
         }
         npending = keep;
     }
-}
-
-// joins the queue; whoever finds no batch in flight leads one over everything queued at that moment
-void submit(Request *req) {
-    pthread_mutex_lock(&g_batch_lock);
-    g_queue[g_queued++] = req; // the queue holds at most one request per arena
-    while(!req->done) {
-        if(g_leader_active) {
-            pthread_cond_wait(&g_batch_done, &g_batch_lock);
-            continue;
-        }
-        Request *batch[kMaxBatch];
-        int      n = 0;
-        bool     mine = false;
-        for(int i = 0; i < g_queued && n < kMaxBatch; ++i) {
-            if(g_queue[i]->arena->device != req->arena->device) continue; // a batch is one launch set on one GPU
-            mine |= g_queue[i] == req;
-            batch[n++] = g_queue[i];
-        }
-        if(!mine) batch[n - 1] = req; // more queued than a batch takes: make sure the leader's own image is in it
-        int left = 0;
-        for(int i = 0; i < g_queued; ++i) {
-            bool taken = false;
-            for(int k = 0; k < n; ++k) taken |= batch[k] == g_queue[i];
-            if(!taken) g_queue[left++] = g_queue[i];
-        }
-        g_queued = left;
-        g_leader_active = true;
-        pthread_mutex_unlock(&g_batch_lock);
-        run_batch(req, batch, n);
-        pthread_mutex_lock(&g_batch_lock);
-        for(int k = 0; k < n; ++k) batch[k]->done = true;
-        g_leader_active = false;
-        pthread_cond_broadcast(&g_batch_done);
-    }
-    pthread_mutex_unlock(&g_batch_lock);
 }
 
 } // namespace
@@ -796,7 +765,7 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     mark(1);
 
     // 1.-4. on the GPU, together with whoever else is decoding right now
-    submit(&req);
+    g_combiner.submit(&req, max_leaders(), run_batch);
     mark(2);
     if(debug) fprintf(stderr, "mjx_huff_decode_host: %lld chunks, %d sync rounds launched, result %d\n", nchunks, req.rounds, req.result);
     if(req.result != MJX_OK) return req.result;

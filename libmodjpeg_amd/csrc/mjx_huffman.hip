@@ -15,7 +15,10 @@
 //                           -> bytes with 0x00 after every 0xFF; the last byte is padded with 1-bits
 // All passes are tiny next to the compose kernel (a 1080p image is 48 960 slots, ~0.6 MB of
 // output); they exist to take the 11 ms per image of host Huffman coding off the critical path and
-// to shrink the D2H transfer from 6.3 MB of coefficients to the compressed bytes.
+// to shrink the D2H transfer from 6.3 MB of coefficients to the compressed bytes.  Eight small
+// launches per image is a latency chain, so concurrent callers are combined into one launch set
+// (mjx_combiner.hpp; blockIdx.y = image).
+#include "mjx_combiner.hpp"
 #include "mjx_internal.hpp"
 #include "mjx_scan.hpp"
 
@@ -40,6 +43,20 @@ struct HuffScan {
 struct HuffTables { // 0..3 DC, 4..7 AC
     uint32_t code[8][256];
     uint8_t  size[8][256];
+};
+
+// one image of a batch, as the kernels see it (device copies live in the leader's arena)
+struct EncJob {
+    HuffScan            S;
+    const HuffTables   *tables;
+    unsigned           *len, *lpre;
+    unsigned long long *gtot;
+    unsigned           *words, *cnt, *cpre;
+    unsigned long long *ctot;
+    unsigned char      *out;
+    unsigned long long *misc; // [0] total bits, [1] stuffed zeros, [2] error flag (int); in the leader's arena
+    long long           nslots, words_cap;
+    int                 groups1, groups2;
 };
 
 // zigzag position -> natural index (jpeg_natural_order)
@@ -165,36 +182,36 @@ __device__ __forceinline__ void stage_block(const HuffScan &S, const Slot &sl, s
 
 constexpr int kHuffThreads = 128; // 128 x 128 B of LDS staging
 
-__global__ __launch_bounds__(kHuffThreads) void huff_length_kernel(HuffScan S, const HuffTables *__restrict__ T, long long nslots, unsigned *__restrict__ lengths,
-                                                                    int *__restrict__ error) {
+__global__ __launch_bounds__(kHuffThreads) void huff_length_kernel(const EncJob *__restrict__ jobs) {
     __shared__ __attribute__((aligned(16))) short stage[kHuffThreads][64];
+    const EncJob   &J = jobs[blockIdx.y];
     const long long t = (long long)blockIdx.x * kHuffThreads + threadIdx.x;
-    if(t >= nslots) return;
-    const Slot sl = decode_slot(S, t);
-    stage_block(S, sl, stage[threadIdx.x]);
+    if(t >= J.nslots) return;
+    const Slot sl = decode_slot(J.S, t);
+    stage_block(J.S, sl, stage[threadIdx.x]);
     unsigned   bits = 0;
-    const bool ok = encode_block(S, *T, t, stage[threadIdx.x], sl.real, sl.comp, [&](unsigned, int size) { bits += (unsigned)size; });
-    lengths[t] = bits;
-    if(!ok) atomicOr(error, 1);
+    const bool ok = encode_block(J.S, *J.tables, t, stage[threadIdx.x], sl.real, sl.comp, [&](unsigned, int size) { bits += (unsigned)size; });
+    J.len[t] = bits;
+    if(!ok) atomicOr(reinterpret_cast<int *>(J.misc + 2), 1);
 }
 
-__global__ __launch_bounds__(kHuffThreads) void huff_emit_kernel(HuffScan S, const HuffTables *__restrict__ T, long long nslots, const unsigned *__restrict__ local_prefix,
-                                                                  const unsigned long long *__restrict__ group_prefix, int group_items, unsigned *__restrict__ words,
-                                                                  const int *__restrict__ error) {
+__global__ __launch_bounds__(kHuffThreads) void huff_emit_kernel(const EncJob *__restrict__ jobs) {
     __shared__ __attribute__((aligned(16))) short stage[kHuffThreads][64];
+    const EncJob   &J = jobs[blockIdx.y];
     const long long t = (long long)blockIdx.x * kHuffThreads + threadIdx.x;
-    if(t >= nslots) return;
+    if(t >= J.nslots) return;
     // a coefficient outside the JPEG alphabet was seen by the length pass: the host reports the
     // error, and nothing may be written (such symbols can exceed the per-block bit budget)
-    if(*error != 0) return;
-    const Slot sl = decode_slot(S, t);
-    stage_block(S, sl, stage[threadIdx.x]);
+    if(*reinterpret_cast<const int *>(J.misc + 2) != 0) return;
+    const Slot sl = decode_slot(J.S, t);
+    stage_block(J.S, sl, stage[threadIdx.x]);
 
-    const unsigned long long bit0 = group_prefix[t / group_items] + local_prefix[t];
+    unsigned                *words = J.words;
+    const unsigned long long bit0 = J.gtot[t / kScanItems] + J.lpre[t];
     unsigned long long       widx = bit0 >> 5;
     unsigned long long       acc = 0; // the low `nacc` bits are pending; the first word starts with bit0 % 32 foreign bits
     int                      nacc = (int)(bit0 & 31);
-    encode_block(S, *T, t, stage[threadIdx.x], sl.real, sl.comp, [&](unsigned code, int size) {
+    encode_block(J.S, *J.tables, t, stage[threadIdx.x], sl.real, sl.comp, [&](unsigned code, int size) {
         acc = (acc << size) | (unsigned long long)code;
         nacc += size;
         if(nacc >= 32) {
@@ -206,24 +223,19 @@ __global__ __launch_bounds__(kHuffThreads) void huff_emit_kernel(HuffScan S, con
     if(nacc > 0) atomicOr(&words[widx], (unsigned)(acc << (32 - nacc)));
 }
 
-// ---- exclusive prefix sums (bodies in mjx_scan.hpp, shared with the decoder) -------------
-__global__ __launch_bounds__(kScanThreads) void scan_groups_kernel(const unsigned *__restrict__ in, unsigned *__restrict__ out, unsigned long long *__restrict__ totals,
-                                                                    long long n) {
-    scan_groups_body(in, out, totals, n, blockIdx.x);
+// ---- exclusive prefix sums over every image of the batch (bodies in mjx_scan.hpp) -------
+// which = 0: code lengths of the block slots -> bit offsets, 1: 0xFF counts of the words -> byte offsets
+__global__ __launch_bounds__(kScanThreads) void huff_scan_groups_kernel(const EncJob *__restrict__ jobs, int which) {
+    const EncJob &J = jobs[blockIdx.y];
+    if((int)blockIdx.x >= (which == 0 ? J.groups1 : J.groups2)) return;
+    if(which == 0) scan_groups_body(J.len, J.lpre, J.gtot, J.nslots, blockIdx.x);
+    else scan_groups_body(J.cnt, J.cpre, J.ctot, J.words_cap, blockIdx.x);
 }
 
-__global__ __launch_bounds__(kScanThreads) void scan_totals_kernel(unsigned long long *__restrict__ totals, long long ngroups, unsigned long long *__restrict__ grand) {
-    scan_totals_body(totals, ngroups, grand);
-}
-
-// exclusive scan of n unsigned values: out[i] (relative to its group of kScanItems) + totals[i / kScanItems]
-// is the exclusive prefix of element i; *grand receives the sum.  totals needs scan_group_count(n) slots.
-int        scan_group_items() { return kScanItems; }
-long long  scan_group_count(long long n) { return (n + kScanItems - 1) / kScanItems; }
-void       launch_scan_exclusive(const unsigned *in, unsigned *out, unsigned long long *totals, long long n, unsigned long long *grand, hipStream_t s) {
-    const long long g = scan_group_count(n);
-    hipLaunchKernelGGL(scan_groups_kernel, dim3((unsigned)g), dim3(kScanThreads), 0, s, in, out, totals, n);
-    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, g, grand);
+__global__ __launch_bounds__(kScanThreads) void huff_scan_totals_kernel(const EncJob *__restrict__ jobs, int which) {
+    const EncJob &J = jobs[blockIdx.y];
+    if(which == 0) scan_totals_body(J.gtot, J.groups1, J.misc + 0);
+    else scan_totals_body(J.ctot, J.groups2, J.misc + 1);
 }
 
 // ---- byte stuffing ---------------------------------------------------------------------
@@ -241,26 +253,26 @@ __device__ __forceinline__ unsigned padded_word(const unsigned *words, unsigned 
     return v;
 }
 
-__global__ __launch_bounds__(256) void stuff_count_kernel(const unsigned *__restrict__ words, const unsigned long long *__restrict__ total_bits_p, long long nwords_cap,
-                                                           unsigned *__restrict__ counts) {
+__global__ __launch_bounds__(256) void stuff_count_kernel(const EncJob *__restrict__ jobs) {
+    const EncJob   &J = jobs[blockIdx.y];
     const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
-    if(w >= nwords_cap) return;
+    if(w >= J.words_cap) return;
     int            nb;
-    const unsigned v = padded_word(words, (unsigned long long)w, *total_bits_p, nb);
+    const unsigned v = padded_word(J.words, (unsigned long long)w, J.misc[0], nb);
     unsigned       c = 0;
     for(int i = 0; i < nb; ++i) c += ((v >> (24 - 8 * i)) & 0xFFu) == 0xFFu;
-    counts[w] = c;
+    J.cnt[w] = c;
 }
 
-__global__ __launch_bounds__(256) void stuff_write_kernel(const unsigned *__restrict__ words, const unsigned long long *__restrict__ total_bits_p, long long nwords_cap,
-                                                           const unsigned *__restrict__ local_prefix, const unsigned long long *__restrict__ group_prefix,
-                                                           unsigned char *__restrict__ out) {
+__global__ __launch_bounds__(256) void stuff_write_kernel(const EncJob *__restrict__ jobs) {
+    const EncJob   &J = jobs[blockIdx.y];
     const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
-    if(w >= nwords_cap) return;
+    if(w >= J.words_cap) return;
     int            nb;
-    const unsigned v = padded_word(words, (unsigned long long)w, *total_bits_p, nb);
+    const unsigned v = padded_word(J.words, (unsigned long long)w, J.misc[0], nb);
     if(nb == 0) return;
-    unsigned long long o = (unsigned long long)w * 4 + group_prefix[w / kScanItems] + local_prefix[w];
+    unsigned char     *out = J.out;
+    unsigned long long o = (unsigned long long)w * 4 + J.ctot[w / kScanItems] + J.cpre[w];
     for(int i = 0; i < nb; ++i) {
         const unsigned char b = (unsigned char)(v >> (24 - 8 * i));
         out[o++] = b;
@@ -273,7 +285,77 @@ __global__ __launch_bounds__(256) void stuff_write_kernel(const unsigned *__rest
 using namespace mjx;
 
 namespace {
+
 size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+constexpr int    kMaxBatch = 32;
+constexpr size_t kMiscAt = (sizeof(EncJob) * kMaxBatch + 255) & ~(size_t)255;
+constexpr size_t kBatchBytes = kMiscAt + ((sizeof(unsigned long long) * 4 * kMaxBatch + 255) & ~(size_t)255);
+
+struct Request {
+    EncJob   job;   // misc is filled in by the batch leader
+    Arena   *arena; // the caller's staging arena: its buffers stay valid while the request is pending
+    unsigned slot_wgs, word_wgs;
+    size_t   o_batch, pin_batch; // where a leader keeps the batch's descriptors and counters in this request's arena
+    unsigned long long total_bits, stuffed;
+    int      result;
+    bool     taken, done;
+};
+
+Combiner<Request, kMaxBatch> g_combiner;
+
+// batches that may be in flight at once (MJX_ENCODE_BATCHES)
+int max_leaders() {
+    static const int n = [] {
+        const char *e = getenv("MJX_ENCODE_BATCHES");
+        const int   v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : (v > 32 ? 32 : v);
+    }();
+    return n;
+}
+
+// the leader's part: one set of kernels over all images of the batch, on the leader's stream
+void run_batch(Request *lead, Request **batch, int n) {
+    hipStream_t         s = lead->arena->stream;
+    char               *dev = lead->arena->dev + lead->o_batch, *pin = lead->arena->pin + lead->pin_batch;
+    EncJob             *h_jobs = reinterpret_cast<EncJob *>(pin), *d_jobs = reinterpret_cast<EncJob *>(dev);
+    unsigned long long *h_misc = reinterpret_cast<unsigned long long *>(pin + kMiscAt), *d_misc = reinterpret_cast<unsigned long long *>(dev + kMiscAt);
+    auto                fail_all = [&](int code) {
+        for(int i = 0; i < n; ++i) batch[i]->result = code;
+    };
+    unsigned hb = 1, wb = 1, g1 = 1, g2 = 1;
+    for(int i = 0; i < n; ++i) {
+        Request *r = batch[i];
+        r->job.misc = d_misc + (size_t)i * 4;
+        h_jobs[i] = r->job;
+        if(r->slot_wgs > hb) hb = r->slot_wgs;
+        if(r->word_wgs > wb) wb = r->word_wgs;
+        if((unsigned)r->job.groups1 > g1) g1 = (unsigned)r->job.groups1;
+        if((unsigned)r->job.groups2 > g2) g2 = (unsigned)r->job.groups2;
+        if(r != lead && hipStreamWaitEvent(s, r->arena->staged, 0) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+    }
+    const unsigned m = (unsigned)n;
+    if(hipMemsetAsync(d_misc, 0, sizeof(unsigned long long) * 4 * (size_t)n, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+    if(hipMemcpyAsync(d_jobs, h_jobs, sizeof(EncJob) * (size_t)n, hipMemcpyHostToDevice, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+    hipLaunchKernelGGL(huff_length_kernel, dim3(hb, m), dim3(kHuffThreads), 0, s, d_jobs);
+    hipLaunchKernelGGL(huff_scan_groups_kernel, dim3(g1, m), dim3(kScanThreads), 0, s, d_jobs, 0);
+    hipLaunchKernelGGL(huff_scan_totals_kernel, dim3(1, m), dim3(kScanThreads), 0, s, d_jobs, 0);
+    hipLaunchKernelGGL(huff_emit_kernel, dim3(hb, m), dim3(kHuffThreads), 0, s, d_jobs);
+    hipLaunchKernelGGL(stuff_count_kernel, dim3(wb, m), dim3(256), 0, s, d_jobs);
+    hipLaunchKernelGGL(huff_scan_groups_kernel, dim3(g2, m), dim3(kScanThreads), 0, s, d_jobs, 1);
+    hipLaunchKernelGGL(huff_scan_totals_kernel, dim3(1, m), dim3(kScanThreads), 0, s, d_jobs, 1);
+    hipLaunchKernelGGL(stuff_write_kernel, dim3(wb, m), dim3(256), 0, s, d_jobs);
+    if(hipGetLastError() != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+    if(hipMemcpyAsync(h_misc, d_misc, sizeof(unsigned long long) * 4 * (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+    if(hipStreamSynchronize(s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+    for(int i = 0; i < n; ++i) {
+        Request *r = batch[i];
+        r->total_bits = h_misc[(size_t)i * 4 + 0];
+        r->stuffed = h_misc[(size_t)i * 4 + 1];
+        r->result = (int)(h_misc[(size_t)i * 4 + 2] & 0xFFFFFFFFull) != 0 ? MJX_ERR_BAD_ARG : MJX_OK; // coefficient outside the JPEG alphabet
+    }
+}
+
 } // namespace
 
 extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char **out, size_t *outlen) {
@@ -282,8 +364,9 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
     *outlen = 0;
     if(scan->ncomp < 1 || scan->ncomp > 4 || scan->mcus_x <= 0 || scan->mcus_y <= 0) return MJX_ERR_BAD_ARG;
 
-    HuffScan S;
-    memset(&S, 0, sizeof(S));
+    Request req;
+    memset(&req, 0, sizeof(req));
+    HuffScan &S = req.job.S;
     S.ncomp = scan->ncomp;
     S.mcus_x = scan->mcus_x;
     S.mcus_y = scan->mcus_y;
@@ -325,11 +408,12 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
     // upper bound of the unstuffed stream: 27 bits of DC + 63 x 26 bits of AC per block
     const long long words_cap = (nslots * 1665 + 31) / 32 + 2;
     const long long g1 = (nslots + kScanItems - 1) / kScanItems, g2 = (words_cap + kScanItems - 1) / kScanItems;
+    if(g1 > 0x7FFFFFFF || g2 > 0x7FFFFFFF) return MJX_ERR_BAD_ARG;
 
     // device layout inside one staging buffer
     size_t       off = 0;
     const size_t o_tables = off; off += up256(sizeof(HuffTables));
-    const size_t o_misc = off;   off += 256; // [0] total bits (u64), [1] stuffed zeros (u64), [2] error (int)
+    const size_t o_batch = off;  off += kBatchBytes;
     const size_t o_planes = off; off += planes_total;
     const size_t o_len = off;    off += up256((size_t)nslots * 4);
     const size_t o_lpre = off;   off += up256((size_t)nslots * 4);
@@ -342,8 +426,9 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
 
     // staging arena from the shared pool: no allocation in steady state, own stream (the NULL
     // stream would serialise the host threads of a batch against each other)
-    ArenaLease arena;
-    int        err = arena->prepare(off, up256(sizeof(HuffTables)) + 256);
+    const size_t pin_batch = up256(sizeof(HuffTables));
+    ArenaLease   arena;
+    int          err = arena->prepare(off, pin_batch + kBatchBytes);
     if(err != MJX_OK) return err;
     char       *base = arena->dev;
     hipStream_t s = arena->stream;
@@ -372,38 +457,37 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
         S.c[c].plane = reinterpret_cast<const int16_t *>(base + po);
         po += up256(plane_bytes[c]);
     }
-    MJX_HIP(hipMemsetAsync(base + o_misc, 0, 256, s), MJX_ERR_LAUNCH);
     MJX_HIP(hipMemsetAsync(base + o_words, 0, (size_t)words_cap * 4, s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipEventRecord(arena->staged, s), MJX_ERR_LAUNCH);
 
-    const HuffTables   *d_tables = reinterpret_cast<const HuffTables *>(base + o_tables);
-    unsigned long long *d_misc = reinterpret_cast<unsigned long long *>(base + o_misc);
-    int                *d_error = reinterpret_cast<int *>(base + o_misc + 16);
-    unsigned           *d_len = reinterpret_cast<unsigned *>(base + o_len), *d_lpre = reinterpret_cast<unsigned *>(base + o_lpre);
-    unsigned long long *d_gtot = reinterpret_cast<unsigned long long *>(base + o_gtot);
-    unsigned           *d_words = reinterpret_cast<unsigned *>(base + o_words);
-    unsigned           *d_cnt = reinterpret_cast<unsigned *>(base + o_cnt), *d_cpre = reinterpret_cast<unsigned *>(base + o_cpre);
-    unsigned long long *d_ctot = reinterpret_cast<unsigned long long *>(base + o_ctot);
-    unsigned char      *d_out = reinterpret_cast<unsigned char *>(base + o_out);
+    EncJob &J = req.job;
+    J.tables = reinterpret_cast<const HuffTables *>(base + o_tables);
+    J.len = reinterpret_cast<unsigned *>(base + o_len);
+    J.lpre = reinterpret_cast<unsigned *>(base + o_lpre);
+    J.gtot = reinterpret_cast<unsigned long long *>(base + o_gtot);
+    J.words = reinterpret_cast<unsigned *>(base + o_words);
+    J.cnt = reinterpret_cast<unsigned *>(base + o_cnt);
+    J.cpre = reinterpret_cast<unsigned *>(base + o_cpre);
+    J.ctot = reinterpret_cast<unsigned long long *>(base + o_ctot);
+    J.out = reinterpret_cast<unsigned char *>(base + o_out);
+    J.nslots = nslots;
+    J.words_cap = words_cap;
+    J.groups1 = (int)g1;
+    J.groups2 = (int)g2;
+    req.arena = arena.a;
+    req.slot_wgs = (unsigned)((nslots + kHuffThreads - 1) / kHuffThreads);
+    req.word_wgs = (unsigned)((words_cap + 255) / 256);
+    req.o_batch = o_batch;
+    req.pin_batch = pin_batch;
 
-    const unsigned hb = (unsigned)((nslots + kHuffThreads - 1) / kHuffThreads), wb = (unsigned)((words_cap + 255) / 256);
-    hipLaunchKernelGGL(huff_length_kernel, dim3(hb), dim3(kHuffThreads), 0, s, S, d_tables, nslots, d_len, d_error);
-    hipLaunchKernelGGL(scan_groups_kernel, dim3((unsigned)g1), dim3(kScanThreads), 0, s, d_len, d_lpre, d_gtot, nslots);
-    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, d_gtot, g1, d_misc + 0);
-    hipLaunchKernelGGL(huff_emit_kernel, dim3(hb), dim3(kHuffThreads), 0, s, S, d_tables, nslots, d_lpre, d_gtot, (int)kScanItems, d_words, d_error);
-    hipLaunchKernelGGL(stuff_count_kernel, dim3(wb), dim3(256), 0, s, d_words, d_misc + 0, words_cap, d_cnt);
-    hipLaunchKernelGGL(scan_groups_kernel, dim3((unsigned)g2), dim3(kScanThreads), 0, s, d_cnt, d_cpre, d_ctot, words_cap);
-    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, d_ctot, g2, d_misc + 1);
-    hipLaunchKernelGGL(stuff_write_kernel, dim3(wb), dim3(256), 0, s, d_words, d_misc + 0, words_cap, d_cpre, d_ctot, d_out);
-    MJX_HIP(hipGetLastError(), MJX_ERR_LAUNCH);
+    // the kernels, together with whoever else is encoding right now
+    g_combiner.submit(&req, max_leaders(), run_batch);
+    if(req.result != MJX_OK) return req.result;
 
-    unsigned long long *misc = reinterpret_cast<unsigned long long *>(arena->pin + up256(sizeof(HuffTables)));
-    MJX_HIP(hipMemcpyAsync(misc, d_misc, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
-    MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
-    if((int)(misc[2] & 0xFFFFFFFFull) != 0) return MJX_ERR_BAD_ARG; // coefficient outside the JPEG alphabet
-    const size_t nbytes = (size_t)((misc[0] + 7) >> 3) + (size_t)misc[1];
+    const size_t   nbytes = (size_t)((req.total_bits + 7) >> 3) + (size_t)req.stuffed;
     unsigned char *buf = static_cast<unsigned char *>(malloc(nbytes ? nbytes : 1));
     if(buf == nullptr) return MJX_ERR_MEMORY;
-    err = check_hip(hipMemcpyAsync(buf, d_out, nbytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(scan data)", MJX_ERR_LAUNCH);
+    err = check_hip(hipMemcpyAsync(buf, J.out, nbytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(scan data)", MJX_ERR_LAUNCH);
     if(err == MJX_OK) err = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
     if(err != MJX_OK) {
         free(buf);

@@ -91,9 +91,4 @@ int launch_synth_coef(int16_t *dst, uint64_t image, uint32_t comp, uint64_t firs
 int launch_synth_tile(float *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, hipStream_t s);
 int launch_synth_alpha(float *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, int regime, hipStream_t s);
 
-// exclusive prefix sums (mjx_huffman.hip)
-int       scan_group_items();
-long long scan_group_count(long long n);
-void      launch_scan_exclusive(const unsigned *in, unsigned *out, unsigned long long *totals, long long n, unsigned long long *grand, hipStream_t s);
-
 } // namespace mjx

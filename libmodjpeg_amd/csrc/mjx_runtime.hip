@@ -29,6 +29,12 @@ bool ensure_device() {
         int        n = 0;
         hipError_t e = hipGetDeviceCount(&n);
         s = (e == hipSuccess && n > 0) ? 1 : -1;
+        // MJX_WAIT=block: host threads sleep in hipStreamSynchronize instead of spinning (many
+        // threads on few cores); must be set before the device is first used by this process
+        if(s > 0) {
+            const char *w = getenv("MJX_WAIT");
+            if(w != nullptr && w[0] == 'b') (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+        }
         if(s < 0) {
             fprintf(stderr, "libmjx_hip: no usable HIP device (%s); this library has no CPU fallback\n",
                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
