@@ -6,6 +6,7 @@ Layers (DESIGN.md):
     api.py       Python mirror of the reference's operator interface for this path
                  (mj_compose_with_mask, mj_convolve, mj_effect_*), used by tests and bench
     batch.py     batches of independent images (device-resident planes, launch plans, sharding)
+    entropy.py   ctypes mirror of the baseline Huffman coders (scan data <-> coefficient planes)
 """
 from . import _lib  # noqa: F401
 from .api import (MJ_OK, MJ_ERR_MEMORY, MJ_ERR_NULL_DATA, MJ_ERR_UNSUPPORTED_COLORSPACE,  # noqa: F401

@@ -12,6 +12,9 @@ the oracle on sampled images:
     runs (run length 1, 5, 16 octets) -- the LDS-DMA / vmcnt bookkeeping of the pipelined kernel
     would show up here as a data race
   * sampled images (first, last, middle of the batch) bit-equal to the oracle
+  * entropy coders (row f-4): composed 1080p / 4K images -> scan data -> planes, everything on
+    the device, is the identity on the real blocks, and libjpeg's edge dummy blocks come back in
+    the MCU padding
 """
 import ctypes
 import os
@@ -185,3 +188,37 @@ def test_compose_inside_a_hip_graph(torch_mod):
     torch.cuda.synchronize()
     for c in range(3):
         assert torch.equal(a.coef[c], b.coef[c]), c
+
+
+@pytest.mark.parametrize("size,n", [((1920, 1080), 48), ((3840, 2160), 4)])
+def test_entropy_round_trip_of_composed_images_on_the_device(torch_mod, size, n):
+    """encode -> decode of whole composed images with the planes resident on the device
+    (MJX_HUFF_PLANES_ON_DEVICE): what comes back equals what went in on every real block; in the MCU
+    padding (1080 = 67.5 MCU rows) it is what libjpeg's encoder put there: DC of the block before it
+    in the MCU, AC zero (jctrans.c compress_output)"""
+    torch = torch_mod
+    from libmodjpeg_amd import entropy as E
+    from libmodjpeg_amd.batch import ComposeBatch
+    b = ComposeBatch(n, size[0], size[1], 256, 256, 52, 26, 2)
+    b.fill_synthetic()
+    b.build_plan().run()
+    torch.cuda.synchronize()
+    g = b.geo
+    total = 0
+    for i in range(n):
+        planes = [b.coef[c][i] for c in range(3)]
+        data = E.encode_scan(planes, g.true_dims, g.samp, g.mcus_x, g.mcus_y)
+        total += len(data)
+        back = [torch.full_like(p, 0x5555) for p in planes]
+        E.decode_scan(data + E.EOI, back, g.samp, g.mcus_x, g.mcus_y)
+        for c in range(3):
+            w, h = g.true_dims[c]
+            assert torch.equal(back[c][:h, :w], planes[c][:h, :w]), (i, c)
+            if h < planes[c].shape[0]:  # dummy rows below the image: AC zero, DC carried inside the MCU
+                pad = back[c][h:, :w]
+                assert int(pad[..., 1:].abs().max()) == 0
+                assert g.samp[c] == (2, 2)  # (chroma arrays of these sizes have no padding rows)
+                # 2x2 blocks per MCU: slot 2 (row h, even column) follows slot 1 (row h-1, odd column), slot 3 follows slot 2
+                assert torch.equal(pad[0, 0::2, 0], planes[c][h - 1, 1:w:2, 0])
+                assert torch.equal(pad[0, 1::2, 0], pad[0, 0::2, 0])
+    assert total > n * 100000  # real amounts of scan data
