@@ -30,6 +30,7 @@
 #include "mjx_internal.hpp"
 #include "mjx_scan.hpp"
 
+#include <math.h>
 #include <new>
 #include <stdlib.h>
 #include <string.h>
@@ -70,7 +71,7 @@ struct DecChunk {
     int                flags;      // 1: first chunk of its segment, 2: last
 };
 
-constexpr int kMaxRounds = 192, kFirstRounds = 12, kMoreRounds = 12;
+constexpr int kMaxRounds = 192, kMoreRounds = 12;
 constexpr int kFlagInts = kMaxRounds + 2; // per image: [0] error, [1 + r] round r changed something
 constexpr int kMaxBatch = 32;
 
@@ -478,8 +479,9 @@ struct Request {
     char    *plane_ptr[4]; // device
     size_t   plane_len[4];
     unsigned chunk_wgs, dc_wgs;
+    int      first_rounds; // rounds queued before the flags are first looked at
     size_t   o_batch, pin_batch; // where a leader keeps the batch's descriptors and flags in this request's arena
-    int      result, rounds;
+    int      result, rounds, settled_at;
     bool     taken, done; // in a batch that is in flight / finished
 };
 
@@ -520,12 +522,14 @@ void run_batch(Request *lead, Request **batch, int n) {
     int pending[kMaxBatch], npending = n, round = 0;
     for(int i = 0; i < n; ++i) pending[i] = i;
     while(npending > 0) {
-        const int first = round, nrounds = round == 0 ? kFirstRounds : kMoreRounds;
+        const int first = round;
+        int       nrounds = round == 0 ? 2 : kMoreRounds;
         unsigned  cbx = 1, dbx = 1, gcx = 1, gdx = 1;
         size_t    lds = 0;
         for(int k = 0; k < npending; ++k) {
             const Request *r = batch[pending[k]];
             h_jobs[k] = r->job;
+            if(round == 0 && r->first_rounds > nrounds) nrounds = r->first_rounds;
             if(r->chunk_wgs > cbx) cbx = r->chunk_wgs;
             if(r->dc_wgs > dbx) dbx = r->dc_wgs;
             if((unsigned)r->job.chunk_groups > gcx) gcx = (unsigned)r->job.chunk_groups;
@@ -555,7 +559,7 @@ void run_batch(Request *lead, Request **batch, int n) {
             Request   *r = batch[pending[k]];
             const int *f = h_flags + (size_t)pending[k] * kFlagInts;
             bool       settled = r->job.nchunks == 1;
-            for(int q = first > 1 ? first : 1; q < round && !settled; ++q) settled = f[1 + q] == 0;
+            for(int q = first > 1 ? first : 1; q < round && !settled; ++q) settled = f[1 + q] == 0, r->settled_at = q;
             r->rounds = round;
             if(settled) {
                 r->result = f[0] != 0 ? MJX_ERR_BAD_ARG : MJX_OK;
@@ -764,6 +768,17 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     req.lds_bytes = lds_bytes;
     req.chunk_wgs = (unsigned)((nchunks + kDecThreads - 1) / kDecThreads);
     req.dc_wgs = (unsigned)((ndc + 255) / 256);
+    {
+        // Rounds to queue before the first look at the flags: what streams of this density needed when
+        // measured (qualities 50..100, four samplings: scripts/decode_rounds.sh,
+        // profiles/r01_final/decode_rounds.log) plus a margin.  Long blocks are slow to fall into step
+        // with: at quality 100 hardly any block ends with an EOB, a walker's zigzag position only snaps
+        // to the true one by chance, and every false block end moves its MCU phase.  A surplus round
+        // costs a launch that returns at once, a missing one a second pass over everything.
+        const double bits_per_block = (double)rawlen * 8.0 / (double)S.nslots;
+        const double est = S.period >= 5 ? 11.0 + pow(bits_per_block / 58.0, 2.4) : (S.period >= 2 ? 8.0 + pow(bits_per_block / 55.0, 2.4) : 6.5 + bits_per_block / 20.0);
+        req.first_rounds = est > 72.0 ? 72 : (int)est;
+    }
     req.o_batch = o_batch;
     req.pin_batch = pin_batch;
     mark(1);
@@ -771,7 +786,9 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     // 1.-4. on the GPU, together with whoever else is decoding right now
     g_combiner.submit(&req, max_leaders(), run_batch);
     mark(2);
-    if(debug) fprintf(stderr, "mjx_huff_decode_host: %lld chunks, %d sync rounds launched, result %d\n", nchunks, req.rounds, req.result);
+    if(debug)
+        fprintf(stderr, "mjx_huff_decode_host: %lld chunks, table period %d, %.0f bits per block, %d sync rounds launched (%d before the first check), first unchanged round %d, result %d\n",
+                nchunks, S.period, (double)rawlen * 8.0 / (double)S.nslots, req.rounds, req.first_rounds, req.settled_at, req.result);
     if(req.result != MJX_OK) return req.result;
     if(!on_device) {
         for(int c = 0; c < S.ncomp; ++c) MJX_HIP(hipMemcpyAsync(scan->comp[c].plane, S.c[c].plane, plane_bytes[c], hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
