@@ -147,11 +147,15 @@ template <bool STORE>
 __device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack, unsigned long long acpack, unsigned long long base_bit, unsigned long long &p,
                                      unsigned long long p_end, int &slot, int wrap, int &k, unsigned &nblocks, long long &t, long long t_stop, int &err) {
     const unsigned *cw = L.words + threadIdx.x;
-    // bit window: the next `navail` (>= 32) bits of the stream, left-aligned
-    const int          rel = (int)(p - base_bit);
-    int                widx = (rel >> 5) + 2;
-    unsigned long long win = ((((unsigned long long)cw[(rel >> 5) * kDecThreads]) << 32) | cw[((rel >> 5) + 1) * kDecThreads]) << (rel & 31);
-    int                navail = 64 - (rel & 31);
+    // bit window: two consecutive words {hi, lo} of which the first `sh` (< 32) bits of hi are used
+    // up, and the word after them fetched ahead; the next 32 bits of the stream are one funnel shift
+    int      rel = (int)(p - base_bit);
+    const int rel_end = (int)(p_end - base_bit);
+    int      widx = (rel >> 5) + 3;
+    unsigned hi = cw[(rel >> 5) * kDecThreads], lo = cw[((rel >> 5) + 1) * kDecThreads], nxt = cw[((rel >> 5) + 2) * kDecThreads];
+    int      sh = rel & 31;
+    // LDS offsets of the current slot's DC and AC tables
+    unsigned dc_at = ((unsigned)(dcpack >> (4 * slot)) & 15u) << kLutBits, ac_at = ((unsigned)(acpack >> (4 * slot)) & 15u) << kLutBits;
 
     // where the current block goes (STORE)
     const DecScan &S = *L.scan;
@@ -169,13 +173,14 @@ __device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack,
         locate();
     }
 
-    while(p < p_end && (!STORE || t < t_stop)) {
-        const unsigned tbl = (unsigned)((k == 0 ? dcpack : acpack) >> (4 * slot)) & 15u;
-        unsigned       e = L.lut[(tbl << kLutBits) + (unsigned)(win >> (64 - kLutBits))];
-        if(e & kEntryLink) e = L.sub[(e & 0xFFFFu) + ((unsigned)(win >> (64 - 16)) & ((1u << kSubBits) - 1u))];
+    while(rel < rel_end && (!STORE || t < t_stop)) {
+        const unsigned peek = (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (32 - sh)); // (sh == 0: hi)
+        const unsigned cand = cw[(widx < kChunkWords ? widx : kChunkWords - 1) * kDecThreads];  // the word after nxt, should this symbol use up hi
+        unsigned       e = L.lut[(k == 0 ? dc_at : ac_at) + (peek >> (32 - kLutBits))];
+        if(e & kEntryLink) e = L.sub[(e & 0xFFFFu) + ((peek >> 16) & ((1u << kSubBits) - 1u))];
         if(e == 0) { // not a code: the padding at the end of a segment, or a wrong guess
             if(STORE) err = 1;
-            p = p_end;
+            rel = rel_end;
             break;
         }
         const int total = (int)((e >> 16) & 63u), kinc = (int)((e >> 22) & 127u);
@@ -183,27 +188,29 @@ __device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack,
             const int len = (int)(e & 31u), s = (int)((e >> 8) & 15u);
             if(e & kEntryBad) err = 1;
             if(s) {
-                const unsigned extra = ((unsigned)(win >> 32) << len) >> (32 - s);
+                const unsigned extra = (peek << len) >> (32 - s);
                 const int      value = extra < (1u << (s - 1)) ? (int)extra - (1 << s) + 1 : (int)extra; // HUFF_EXTEND
                 const int      at = k + kinc - 1; // DC: 0 (the difference; the DC pass integrates); AC: k + run
                 if(at > 63) err = 1;
                 else blk[kDecZigzag[at]] = (int16_t)value;
             }
         }
-        p += (unsigned)total;
-        win <<= total;
-        navail -= total;
-        if(navail < 32) {
-            win |= ((unsigned long long)cw[(widx < kChunkWords ? widx : kChunkWords - 1) * kDecThreads]) << (32 - navail);
-            navail += 32;
-            widx++;
-        }
+        rel += total;
+        sh += total; // total <= 31: at most one word is used up
+        const bool used_up = sh >= 32;
+        hi = used_up ? lo : hi;
+        lo = used_up ? nxt : lo;
+        nxt = used_up ? cand : nxt;
+        widx += used_up ? 1 : 0;
+        sh &= 31;
         k += kinc;
         if(k >= 64) { // EOB, or the 63rd coefficient
             if(STORE && k > 64 && kinc != 64) err = 1;
             k = 0;
             nblocks++;
             slot = slot + 1 == wrap ? 0 : slot + 1;
+            dc_at = ((unsigned)(dcpack >> (4 * slot)) & 15u) << kLutBits;
+            ac_at = ((unsigned)(acpack >> (4 * slot)) & 15u) << kLutBits;
             if(STORE) {
                 t++;
                 if(slot == 0) {
@@ -217,6 +224,7 @@ __device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack,
             }
         }
     }
+    p = base_bit + (unsigned long long)(unsigned)rel;
 }
 
 // one synchronisation round (in place: a lane may see its neighbour's old or new exit state; the
