@@ -169,7 +169,8 @@ int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols,
 int mjx_effect_zero_device(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc);
 
 /* ---- baseline Huffman entropy encoder (write side) ------------------
- * Encodes the entropy-coded segment of ONE sequential (baseline) JPEG scan - all components
+ * Replaces, for fixed tables, what the reference gets from libjpeg at image.c:194-196
+ * (jpeg_write_coefficients + jpeg_finish_compress).  Encodes the entropy-coded segment of ONE sequential (baseline) JPEG scan - all components
  * interleaved, or the single component of a grayscale image - exactly as libjpeg's
  * jpeg_write_coefficients() does with fixed Huffman tables (jctrans.c compress_output +
  * jchuff.c encode_mcu_huff): MCU order, dummy blocks at the right/bottom edge (AC zero, DC of
@@ -208,7 +209,8 @@ typedef struct mjx_huff_scan {
 int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char **out, size_t *outlen);
 
 /* ---- baseline Huffman entropy decoder (row f-4, read side) --------------------------------
- * Decodes the entropy-coded segment of one sequential interleaved (or single-component) scan into
+ * Replaces, for sequential Huffman files, what the reference gets from libjpeg at image.c:79
+ * (jpeg_read_coefficients).  Decodes the entropy-coded segment of one sequential interleaved (or single-component) scan into
  * coefficient planes, as libjpeg's jpeg_read_coefficients() does (jdhuff.c decode_mcu): every block
  * slot of every MCU is stored, including the padding blocks of partial MCUs, into arrays of
  * mcus_x*h_samp by mcus_y*v_samp blocks.  The bitstream is sequential; it is cut into fixed-size

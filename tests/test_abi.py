@@ -35,6 +35,72 @@ def test_struct_layouts_match_header(hiplib):
     assert ctypes.sizeof(hiplib.DcJob) == 32
 
 
+def test_ctypes_mirrors_have_the_c_layout(hiplib, tmp_path):
+    """sizeof / offsetof of every struct of include/mjx.h as gcc sees them == the ctypes mirrors"""
+    import os
+    import subprocess
+    from libmodjpeg_amd import entropy as E
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mirrors = {
+        "mjx_rect_job_t": (hiplib.RectJob, ["coef", "blocks_per_row", "qtable"]),
+        "mjx_host_rect_t": (hiplib.HostRect, ["rows_ptr", "q", "blocks_per_row", "flags"]),
+        "mjx_dc_job_t": (hiplib.DcJob, ["coef", "value", "q0"]),
+        "mjx_huff_table_t": (E.HuffTable, ["code", "size"]),
+        "mjx_huff_component_t": (E.HuffComponent, ["plane", "blocks_per_row", "h_samp", "ac_tbl"]),
+        "mjx_huff_scan_t": (E.HuffScan, ["ncomp", "comp", "dc", "ac", "max_coef_bits", "flags"]),
+        "mjx_huff_spec_t": (E.HuffSpec, ["bits", "vals"]),
+        "mjx_huff_dcomponent_t": (E.HuffDComponent, ["plane", "blocks_per_row", "ac_tbl"]),
+        "mjx_huff_dscan_t": (E.HuffDScan, ["ncomp", "comp", "dc", "ac", "data", "nbytes", "restart_interval", "flags"]),
+    }
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "mjx.h"', 'int main(void) {']
+    for name, (_, fields) in mirrors.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for f in fields:
+            lines.append(f'printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, (mirror, fields) in mirrors.items():
+        assert int(got[name]) == ctypes.sizeof(mirror), name
+        for f in fields:
+            assert int(got[f"{name}.{f}"]) == getattr(mirror, f).offset, (name, f)
+
+
+def test_entropy_coders_validate_on_the_host_and_have_no_cpu_path(hiplib):
+    """argument errors are reported before the device is touched; valid input without a device is
+    MJX_ERR_NO_DEVICE (there is no CPU implementation of either coder in the library)"""
+    import torch
+    from libmodjpeg_amd import entropy as E
+    L = hiplib.lib()
+    assert L.mjx_huff_decode_host(None) == hiplib.MJX_ERR_NULL_DATA
+    assert L.mjx_huff_encode_host(None, None, None) == hiplib.MJX_ERR_NULL_DATA
+    plane = np.zeros((2, 2, 64), np.int16)
+    data = np.frombuffer(b"\x00" * 64 + E.EOI, np.uint8).copy()
+    sc = E.HuffDScan()
+    sc.ncomp, sc.mcus_x, sc.mcus_y = 1, 2, 2
+    sc.comp[0] = E.HuffDComponent(plane.ctypes.data, 2, 1, 1, 0, 0)
+    dc, ac = E.spec(E.STD_DC_LUMA), E.spec(E.STD_AC_LUMA)
+    sc.dc[0], sc.ac[0] = ctypes.pointer(dc), ctypes.pointer(ac)
+    sc.data, sc.nbytes = data.ctypes.data, data.size
+    sc.comp[0].blocks_per_row = 1  # narrower than the MCU grid
+    assert L.mjx_huff_decode_host(ctypes.byref(sc)) == hiplib.MJX_ERR_BAD_ARG
+    sc.comp[0].blocks_per_row = 2
+    sc.comp[0].ac_tbl = 2  # no such table
+    assert L.mjx_huff_decode_host(ctypes.byref(sc)) == hiplib.MJX_ERR_BAD_ARG
+    sc.comp[0].ac_tbl = 0
+    bad = E.spec(([0, 5] + [0] * 14, [0, 1, 2, 3, 4]))  # five codes of length 2
+    sc.dc[0] = ctypes.pointer(bad)
+    assert L.mjx_huff_decode_host(ctypes.byref(sc)) == hiplib.MJX_ERR_BAD_ARG
+    sc.dc[0] = ctypes.pointer(dc)
+    if not torch.cuda.is_available():
+        assert L.mjx_huff_decode_host(ctypes.byref(sc)) == hiplib.MJX_ERR_NO_DEVICE
+        with pytest.raises(hiplib.MjxError):
+            E.encode_scan([plane], [(2, 2)], [(1, 1)], 2, 2)
+
+
 def test_no_cpu_fallback_without_device(hiplib):
     import torch
     if torch.cuda.is_available():
