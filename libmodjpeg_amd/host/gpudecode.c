@@ -14,6 +14,7 @@
  */
 #include "mjhost.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -46,12 +47,7 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
 
     /* ---- what this path decodes (nothing has been touched yet: "clean" bail-outs) ---- */
     {
-        /* below this much scan data libjpeg's serial decoder is faster than the round trips to
-         * the device (MJ_GPU_DECODE_MIN_BYTES overrides; the result is the same either way) */
-        static long min_bytes = -1;
-        static int  have_device = -1;
-        if(min_bytes < 0) min_bytes = getenv("MJ_GPU_DECODE_MIN_BYTES") != NULL ? atol(getenv("MJ_GPU_DECODE_MIN_BYTES")) : 16384;
-        if(d->src != NULL && (long)d->src->bytes_in_buffer < min_bytes) BAIL(MJH_DECODE_UNSUPPORTED, "small file");
+        static int have_device = -1;
         if(have_device < 0) have_device = mjx_device_count() > 0;
         if(!have_device) BAIL(MJH_DECODE_UNSUPPORTED, "no device");
     }
@@ -86,6 +82,23 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
     nmcu = (long long)sc.mcus_x * sc.mcus_y;
     sc.restart_interval = (int)d->restart_interval;
     if(d->restart_interval > 0x7FFFFFFF || nmcu > 0x7FFFFFFF) BAIL(MJH_DECODE_UNSUPPORTED, "image too large");
+
+    {
+        /* Is the device worth it for this file?  libjpeg decodes ~100 MB/s of scan data on one core;
+         * the GPU path costs ~0.35 ms of fixed round trips, ~55 us per synchronisation round and a
+         * little per byte, and the rounds grow steeply with the bits per block (a
+         * quality-100 overlay of 127 KB needs 54 rounds, 3.4 ms, against 1.3 ms in libjpeg).  The
+         * result is the same either way.  MJ_GPU_DECODE_MIN_BYTES replaces the model by a plain size
+         * threshold (0: always the device). */
+        static long   min_bytes = -2;
+        const double  nbytes = (double)d->src->bytes_in_buffer;
+        const double  bits_per_block = nbytes * 8.0 / ((double)nmcu * blocks_in_mcu);
+        const int     period_like = d->num_components == 1 ? 1 : blocks_in_mcu;
+        const double  rounds = period_like >= 5 ? 11.0 + pow(bits_per_block / 58.0, 2.4) : (period_like >= 2 ? 8.0 + pow(bits_per_block / 55.0, 2.4) : 6.5 + bits_per_block / 20.0);
+        const double  gpu_ms = 0.35 + 0.055 * rounds + nbytes * 0.6e-6, cpu_ms = nbytes * 1.0e-5;
+        if(min_bytes == -2) min_bytes = getenv("MJ_GPU_DECODE_MIN_BYTES") != NULL ? atol(getenv("MJ_GPU_DECODE_MIN_BYTES")) : -1;
+        if(min_bytes >= 0 ? nbytes < (double)min_bytes : gpu_ms >= cpu_ms) BAIL(MJH_DECODE_UNSUPPORTED, "libjpeg is faster for this one");
+    }
 
     /* Huffman tables as the file defined them */
     for(i = 0; i < 4; i++) {
