@@ -96,9 +96,10 @@ int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan);
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream);
 
 /* Per-image callers (the libmodjpeg.h shim) hold everything in HOST memory.  One call = one
- * staging allocation, asynchronous H2D of every rectangle's plane rows and tiles, ONE launch over
- * all rectangles, D2H of the rows.  `rows_ptr` points at the first plane row the rectangle touches
- * (rows * blocks_per_row blocks, updated in place): only those rows travel over PCIe. */
+ * staging allocation, asynchronous H2D of every rectangle's blocks and tiles, ONE launch over all
+ * rectangles, D2H of the blocks.  `rows_ptr` points at the first plane row the rectangle touches
+ * (rows * blocks_per_row blocks, updated in place); a rectangle much narrower than the plane travels
+ * alone (gathered into, and scattered back from, pinned memory), a wide one as whole rows. */
 typedef struct mjx_host_rect {
     int16_t        *rows_ptr;       /* HOST, in/out */
     const float    *tile;           /* HOST, rows*cols blocks */

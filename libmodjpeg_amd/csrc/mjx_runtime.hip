@@ -434,11 +434,22 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     std::vector<mjx_rect_job_t> jobs;
     std::vector<uint16_t>       qt;
     std::vector<size_t>         coef_off;
-    size_t                      data_bytes = 0;
+    size_t                      data_bytes = 0, stage_bytes = 0;
+    // a rectangle much narrower than the plane travels alone, gathered into pinned memory (a 256x256
+    // overlay on a 1080p image: 0.2 MB instead of 1.5 MB of whole rows each way, 0.17 instead of
+    // 0.28 ms per call); a wide one goes as whole rows straight out of the caller's buffer (the CPU
+    // copies would cost more than the extra PCIe bytes: 4K full frame 8.8 ms against 10.5 ms)
+    auto compact = [](const mjx_host_rect_t &r) { return !(r.flags & MJX_RECT_ROWS_ON_DEVICE) && (int64_t)r.cols * 3 <= r.blocks_per_row; };
     for(int i = 0; i < n; ++i) {
         const mjx_host_rect_t &r = rects[i];
         if(r.rows == 0 || r.cols == 0) continue;
-        if(!(r.flags & MJX_RECT_ROWS_ON_DEVICE)) data_bytes += round256((size_t)r.rows * r.blocks_per_row * 128);
+        if(compact(r)) {
+            data_bytes += round256((size_t)r.rows * r.cols * 128);
+            stage_bytes += round256((size_t)r.rows * r.cols * 128);
+        }
+        else if(!(r.flags & MJX_RECT_ROWS_ON_DEVICE)) {
+            data_bytes += round256((size_t)r.rows * r.blocks_per_row * 128);
+        }
         if(!(r.flags & MJX_RECT_TILES_ON_DEVICE)) data_bytes += 2 * round256((size_t)r.rows * r.cols * 256);
     }
     // upper bound of the packet: jobs may be split (never for real JPEG sizes) -> size after build
@@ -451,10 +462,10 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         j.coef = reinterpret_cast<int16_t *>(uintptr_t(16)); // patched below
         j.tile = reinterpret_cast<const float *>(uintptr_t(16));
         j.alpha = reinterpret_cast<const float *>(uintptr_t(16));
-        j.blocks_per_row = r.blocks_per_row;
+        j.blocks_per_row = compact(r) ? r.cols : r.blocks_per_row; // the staged copy is the rectangle alone
         j.plane_rows = r.rows;
         j.row0 = 0;
-        j.col0 = r.col0;
+        j.col0 = compact(r) ? 0 : r.col0;
         j.rows = r.rows;
         j.cols = r.cols;
         j.qtable = (int)jobs.size();
@@ -467,27 +478,41 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     for(const mjx_rect_job_t &j : jobs) max_runs += (size_t)j.rows * (size_t)j.cols / (kWaveBlocks * 2) + 4;
     const size_t packet_cap = round256(2 * jobs.size() * sizeof(DevJob)) + round256((size_t)nq * 64 * 6) + round256(max_runs * sizeof(Run));
     ArenaLease arena;
-    int        err = arena->prepare(packet_cap + data_bytes, packet_cap);
+    int        err = arena->prepare(packet_cap + data_bytes, packet_cap + stage_bytes);
     if(err != MJX_OK) return err;
     hipStream_t s = arena->stream;
     char       *base = arena->dev;
 
     // second pass: real device addresses, uploads
-    size_t off = packet_cap, k = 0;
+    size_t off = packet_cap, k = 0, stage = packet_cap;
+    std::vector<size_t> stage_off;
     for(int i = 0; i < n; ++i) {
         const mjx_host_rect_t &r = rects[i];
         if(r.rows == 0 || r.cols == 0) continue;
-        const size_t cb = (size_t)r.rows * r.blocks_per_row * 128, tb = (size_t)r.rows * r.cols * 256;
+        const size_t cb = (size_t)r.rows * r.cols * 128, tb = (size_t)r.rows * r.cols * 256;
         mjx_rect_job_t &j = jobs[k++];
         if(r.flags & MJX_RECT_ROWS_ON_DEVICE) {
             j.coef = r.rows_ptr;
             coef_off.push_back(0);
+            stage_off.push_back(0);
+        }
+        else if(!compact(r)) {
+            const size_t wb = (size_t)r.rows * r.blocks_per_row * 128;
+            j.coef = reinterpret_cast<int16_t *>(base + off);
+            coef_off.push_back(off);
+            stage_off.push_back(0);
+            MJX_HIP(hipMemcpyAsync(base + off, r.rows_ptr, wb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+            off += round256(wb);
         }
         else {
             j.coef = reinterpret_cast<int16_t *>(base + off);
             coef_off.push_back(off);
-            MJX_HIP(hipMemcpyAsync(base + off, r.rows_ptr, cb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+            stage_off.push_back(stage);
+            for(int row = 0; row < r.rows; ++row)
+                memcpy(arena->pin + stage + (size_t)row * r.cols * 128, r.rows_ptr + ((size_t)row * r.blocks_per_row + r.col0) * 64, (size_t)r.cols * 128);
+            MJX_HIP(hipMemcpyAsync(base + off, arena->pin + stage, cb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
             off += round256(cb);
+            stage += round256(cb);
         }
         if(r.flags & MJX_RECT_TILES_ON_DEVICE) {
             j.tile = r.tile;
@@ -523,13 +548,25 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         for(int i = 0; i < n && err == MJX_OK; ++i) {
             const mjx_host_rect_t &r = rects[i];
             if(r.rows == 0 || r.cols == 0) continue;
-            const size_t at = coef_off[k++];
+            const size_t at = coef_off[k], st = stage_off[k];
+            ++k;
             if(r.flags & MJX_RECT_ROWS_ON_DEVICE) continue;
-            err = check_hip(hipMemcpyAsync(r.rows_ptr, base + at, (size_t)r.rows * r.blocks_per_row * 128, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H)",
-                            MJX_ERR_LAUNCH);
+            if(compact(r)) err = check_hip(hipMemcpyAsync(arena->pin + st, base + at, (size_t)r.rows * r.cols * 128, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H)", MJX_ERR_LAUNCH);
+            else err = check_hip(hipMemcpyAsync(r.rows_ptr, base + at, (size_t)r.rows * r.blocks_per_row * 128, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H)", MJX_ERR_LAUNCH);
         }
     }
     const int serr = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
+    if(err == MJX_OK && serr == MJX_OK) { // scatter the blended rectangles back into the caller's rows
+        k = 0;
+        for(int i = 0; i < n; ++i) {
+            const mjx_host_rect_t &r = rects[i];
+            if(r.rows == 0 || r.cols == 0) continue;
+            const size_t st = stage_off[k++];
+            if(!compact(r)) continue;
+            for(int row = 0; row < r.rows; ++row)
+                memcpy(r.rows_ptr + ((size_t)row * r.blocks_per_row + r.col0) * 64, arena->pin + st + (size_t)row * r.cols * 128, (size_t)r.cols * 128);
+        }
+    }
     return err != MJX_OK ? err : serr;
 }
 
