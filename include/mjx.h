@@ -200,14 +200,28 @@ typedef struct mjx_huff_scan {
     const mjx_huff_table_t *ac[4];
     int32_t                 max_coef_bits;  /* 10 for 8-bit JPEG: larger categories are an error as in libjpeg */
     int32_t                 flags;          /* MJX_HUFF_* */
+    struct mjx_huff_spec   *optimal_dc[4];  /* MJX_HUFF_OPTIMIZE: out, the tables that were built and used ... */
+    struct mjx_huff_spec   *optimal_ac[4];  /* ... for every table index a component refers to (caller's storage) */
 } mjx_huff_scan_t;
 /* the component planes are DEVICE pointers (an image decoded on the device and kept there): no
  * coefficient crosses PCIe, only the compressed bytes come back */
 #define MJX_HUFF_PLANES_ON_DEVICE 1
+/* libjpeg's optimize_coding (the reference's MJ_OPTION_OPTIMIZE, image.c:170): dc[]/ac[] are ignored,
+ * the symbol statistics of this image are gathered on the device, the optimal tables are built as
+ * libjpeg 9d builds them (mjx_huff_optimal_table) and returned through optimal_dc[]/optimal_ac[] for
+ * the caller's DHT segments, and the scan is encoded with them */
+#define MJX_HUFF_OPTIMIZE 2
 
 /* *out is malloc()ed (caller free()s); returns MJX_ERR_BAD_ARG when a coefficient does not fit
  * the JPEG symbol alphabet (libjpeg: JERR_BAD_DCT_COEF) or a needed symbol has no code. */
 int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char **out, size_t *outlen);
+
+/* Optimal Huffman table for a symbol histogram, as libjpeg 9d's jpeg_gen_optimal_table builds it for
+ * optimize_coding (jchuff.c; ITU-T T.81 K.2 with code lengths limited to 16 bits, the all-ones code
+ * reserved, symbols of equal length ordered by falling frequency).  Pure host code, no device.
+ * freq[s] = occurrences of symbol s (0..255); returns MJX_ERR_BAD_ARG when no symbol occurs. */
+typedef struct mjx_huff_spec mjx_huff_spec_t;
+int mjx_huff_optimal_table(const uint32_t freq[256], mjx_huff_spec_t *table);
 
 /* ---- baseline Huffman entropy decoder (row f-4, read side) --------------------------------
  * Replaces, for sequential Huffman files, what the reference gets from libjpeg at image.c:79
@@ -219,10 +233,10 @@ int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char **out, size_
  * exactly where its predecessor ended (self-synchronisation of Huffman codes), then decoded once
  * more for real.  `data` points at the first byte after the SOS header, as in the file: 0xFF00
  * stuffing and RSTn markers included; the scan must end with EOI inside `nbytes`. */
-typedef struct mjx_huff_spec {
+struct mjx_huff_spec {
     uint8_t bits[16];  /* number of codes of length 1..16 (DHT) */
     uint8_t vals[256]; /* symbols in code order */
-} mjx_huff_spec_t;
+};
 
 typedef struct mjx_huff_dcomponent {
     int16_t *plane;          /* HOST (DEVICE with the flag), out: int16[mcus_y*v_samp][blocks_per_row][64], written whole (pitch padding = 0) */

@@ -109,12 +109,14 @@ __device__ __forceinline__ int effective_dc(const HuffScan &S, long long t) {
 
 __device__ __forceinline__ int bit_length(int v) { return 32 - __clz(v); } // v >= 0; 0 -> 0
 
-// symbol stream of one block; EMIT(code, size) is called for every code and every bit field
-template <class EMIT> __device__ __forceinline__ bool encode_block(const HuffScan &S, const HuffTables &T, long long t, const short *blk /* LDS, 64 coefs; unused for dummies */,
-                                                                   bool real, int comp, EMIT &&emit) {
+// symbol stream of one block (jchuff.c encode_one_block / htest_one_block): SYM(table, symbol, bits,
+// nbits) is called for every Huffman symbol with the raw bits that follow it; table = dc_tbl for
+// the DC difference, 4 + ac_tbl for run/size symbols, ZRL and EOB.  false: a value outside the alphabet.
+template <class SYM> __device__ __forceinline__ bool symbolize(const HuffScan &S, long long t, const short *blk /* LDS, 64 coefs; unused for dummies */, bool real,
+                                                              int comp, SYM &&sym) {
     const HuffComp &c = S.c[comp];
     bool            ok = true;
-    // DC (jchuff.c encode_one_block): difference to the previous block of this component
+    // DC: difference to the previous block of this component
     const long long p = prev_in_component(S, t);
     const int       pred = p >= 0 ? effective_dc(S, p) : 0;
     const int       dc = real ? (int)blk[0] : pred;
@@ -125,12 +127,7 @@ template <class EMIT> __device__ __forceinline__ bool encode_block(const HuffSca
     }
     int nbits = bit_length(temp);
     if(nbits > S.max_coef_bits + 1) ok = false;
-    {
-        const int sz = T.size[c.dc_tbl][nbits & 255];
-        if(sz == 0) ok = false;
-        emit(T.code[c.dc_tbl][nbits & 255], sz);
-        if(nbits) emit((unsigned)temp2 & ((1u << nbits) - 1u), nbits);
-    }
+    sym(c.dc_tbl, nbits & 255, (unsigned)temp2 & ((1u << nbits) - 1u), nbits);
     // AC: run lengths of zeros in zigzag order
     const int at = 4 + c.ac_tbl;
     int       r = 0;
@@ -142,8 +139,7 @@ template <class EMIT> __device__ __forceinline__ bool encode_block(const HuffSca
                 continue;
             }
             while(r > 15) {
-                if(T.size[at][0xF0] == 0) ok = false;
-                emit(T.code[at][0xF0], T.size[at][0xF0]); // ZRL
+                sym(at, 0xF0, 0u, 0); // ZRL
                 r -= 16;
             }
             int v2 = v;
@@ -153,21 +149,27 @@ template <class EMIT> __device__ __forceinline__ bool encode_block(const HuffSca
             }
             nbits = bit_length(v);
             if(nbits > S.max_coef_bits) ok = false;
-            const int sym = ((r << 4) + nbits) & 255;
-            if(T.size[at][sym] == 0) ok = false;
-            emit(T.code[at][sym], T.size[at][sym]);
-            emit((unsigned)v2 & ((1u << nbits) - 1u), nbits);
+            sym(at, ((r << 4) + nbits) & 255, (unsigned)v2 & ((1u << nbits) - 1u), nbits);
             r = 0;
         }
     }
     else {
         r = 63;
     }
-    if(r > 0) {
-        if(T.size[at][0] == 0) ok = false;
-        emit(T.code[at][0], T.size[at][0]); // EOB
-    }
+    if(r > 0) sym(at, 0, 0u, 0); // EOB
     return ok;
+}
+
+// the same stream as codes: EMIT(code, size) is called for every code and every bit field
+template <class EMIT> __device__ __forceinline__ bool encode_block(const HuffScan &S, const HuffTables &T, long long t, const short *blk, bool real, int comp, EMIT &&emit) {
+    bool coded = true;
+    const bool ok = symbolize(S, t, blk, real, comp, [&](int table, int symbol, unsigned bits, int nbits) {
+        const int sz = T.size[table][symbol];
+        if(sz == 0) coded = false; // a symbol the table has no code for
+        emit(T.code[table][symbol], sz);
+        if(nbits) emit(bits, nbits);
+    });
+    return ok && coded;
 }
 
 // stage this lane's block (128 B) in LDS so that the zigzag walk is an LDS lookup
@@ -221,6 +223,25 @@ __global__ __launch_bounds__(kHuffThreads) void huff_emit_kernel(const EncJob *_
         }
     });
     if(nacc > 0) atomicOr(&words[widx], (unsigned)(acc << (32 - nacc)));
+}
+
+// symbol statistics for optimised tables (jchuff.c encode_mcu_gather): hist[table][symbol], tables
+// 0..3 DC, 4..7 AC; counted in LDS per workgroup, then added to the global histogram
+__global__ __launch_bounds__(kHuffThreads) void huff_histogram_kernel(HuffScan S, long long nslots, unsigned *__restrict__ hist, int *__restrict__ error) {
+    __shared__ __attribute__((aligned(16))) short stage[kHuffThreads][64];
+    __shared__ unsigned                          local[8 * 256];
+    for(int i = threadIdx.x; i < 8 * 256; i += kHuffThreads) local[i] = 0;
+    __syncthreads();
+    const long long t = (long long)blockIdx.x * kHuffThreads + threadIdx.x;
+    if(t < nslots) {
+        const Slot sl = decode_slot(S, t);
+        stage_block(S, sl, stage[threadIdx.x]);
+        const bool ok = symbolize(S, t, stage[threadIdx.x], sl.real, sl.comp, [&](int table, int symbol, unsigned, int) { atomicAdd(&local[table * 256 + symbol], 1u); });
+        if(!ok) atomicOr(error, 1);
+    }
+    __syncthreads();
+    for(int i = threadIdx.x; i < 8 * 256; i += kHuffThreads)
+        if(local[i]) atomicAdd(&hist[i], local[i]);
 }
 
 // ---- exclusive prefix sums over every image of the batch (bodies in mjx_scan.hpp) -------
@@ -358,6 +379,90 @@ void run_batch(Request *lead, Request **batch, int n) {
 
 } // namespace
 
+// Optimal table for a histogram: the procedure of ITU-T T.81 K.2 as libjpeg 9d runs it
+// (jchuff.c jpeg_gen_optimal_table): pseudo-symbol 256 with count 1 reserves the all-ones code,
+// ties in the two-smallest search go to the larger symbol, lengths above 16 are folded back, and
+// the symbol list is ordered by code length, then by falling frequency, then by symbol.
+extern "C" int mjx_huff_optimal_table(const uint32_t *freq_in, mjx_huff_spec_t *table) {
+    if(freq_in == nullptr || table == nullptr) return MJX_ERR_NULL_DATA;
+    long freq[257];
+    int  codesize[257], others[257], nonzero = 0;
+    for(int i = 0; i < 256; ++i) {
+        freq[i] = (long)freq_in[i];
+        nonzero += freq_in[i] != 0;
+    }
+    if(nonzero == 0) return MJX_ERR_BAD_ARG;
+    freq[256] = 1;
+    for(int i = 0; i < 257; ++i) {
+        codesize[i] = 0;
+        others[i] = -1;
+    }
+    for(;;) {
+        int  c1 = -1, c2 = -1;
+        long v = 0x7FFFFFFFFFFFL;
+        for(int i = 0; i <= 256; ++i)
+            if(freq[i] && freq[i] <= v) {
+                v = freq[i];
+                c1 = i;
+            }
+        v = 0x7FFFFFFFFFFFL;
+        for(int i = 0; i <= 256; ++i)
+            if(freq[i] && freq[i] <= v && i != c1) {
+                v = freq[i];
+                c2 = i;
+            }
+        if(c2 < 0) break;
+        freq[c1] += freq[c2];
+        freq[c2] = 0;
+        codesize[c1]++;
+        while(others[c1] >= 0) {
+            c1 = others[c1];
+            codesize[c1]++;
+        }
+        others[c1] = c2;
+        codesize[c2]++;
+        while(others[c2] >= 0) {
+            c2 = others[c2];
+            codesize[c2]++;
+        }
+    }
+    int bits[258];
+    memset(bits, 0, sizeof(bits));
+    for(int i = 0; i <= 256; ++i)
+        if(codesize[i]) bits[codesize[i]]++;
+    for(int i = 257; i > 16; --i) {
+        while(bits[i] > 0) {
+            int j = i - 2;
+            while(bits[j] == 0) j--;
+            bits[i] -= 2;
+            bits[i - 1]++;
+            bits[j + 1] += 2;
+            bits[j]--;
+        }
+    }
+    int top = 16;
+    while(bits[top] == 0) top--;
+    bits[top]--; // the reserved all-ones code
+    memset(table, 0, sizeof(*table));
+    for(int i = 1; i <= 16; ++i) table->bits[i - 1] = (uint8_t)bits[i];
+    int p = 0;
+    for(int len = 1; len <= 256; ++len) { // by code length, then falling frequency, then symbol
+        int first = p;
+        for(int s = 0; s < 256; ++s)
+            if(codesize[s] == len) table->vals[p++] = (uint8_t)s;
+        for(int a = first + 1; a < p; ++a) { // insertion sort, stable
+            const uint8_t sym = table->vals[a];
+            int           b = a;
+            while(b > first && freq_in[table->vals[b - 1]] < freq_in[sym]) {
+                table->vals[b] = table->vals[b - 1];
+                b--;
+            }
+            table->vals[b] = sym;
+        }
+    }
+    return MJX_OK;
+}
+
 extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char **out, size_t *outlen) {
     if(scan == nullptr || out == nullptr || outlen == nullptr) return MJX_ERR_NULL_DATA;
     *out = nullptr;
@@ -377,7 +482,7 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
         const mjx_huff_component_t &h = scan->comp[c];
         if(h.plane == nullptr) return MJX_ERR_NULL_DATA;
         if(h.h_samp < 1 || h.v_samp < 1 || h.width_in_blocks < 1 || h.height_in_blocks < 1 || h.blocks_per_row < h.width_in_blocks || h.dc_tbl < 0 ||
-           h.dc_tbl > 3 || h.ac_tbl < 0 || h.ac_tbl > 3 || scan->dc[h.dc_tbl] == nullptr || scan->ac[h.ac_tbl] == nullptr)
+           h.dc_tbl > 3 || h.ac_tbl < 0 || h.ac_tbl > 3 || (!(scan->flags & MJX_HUFF_OPTIMIZE) && (scan->dc[h.dc_tbl] == nullptr || scan->ac[h.ac_tbl] == nullptr)))
             return MJX_ERR_BAD_ARG;
         // every MCU must own at least its top-left block of every component
         if((long long)(S.mcus_x - 1) * h.h_samp >= h.width_in_blocks || (long long)(S.mcus_y - 1) * h.v_samp >= h.height_in_blocks) return MJX_ERR_BAD_ARG;
@@ -413,6 +518,7 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
     // device layout inside one staging buffer
     size_t       off = 0;
     const size_t o_tables = off; off += up256(sizeof(HuffTables));
+    const size_t o_hist = off;   off += up256(8 * 256 * 4 + 256); // symbol statistics + an error flag (optimised tables)
     const size_t o_batch = off;  off += kBatchBytes;
     const size_t o_planes = off; off += planes_total;
     const size_t o_len = off;    off += up256((size_t)nslots * 4);
@@ -426,26 +532,12 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
 
     // staging arena from the shared pool: no allocation in steady state, own stream (the NULL
     // stream would serialise the host threads of a batch against each other)
-    const size_t pin_batch = up256(sizeof(HuffTables));
+    const size_t pin_hist = up256(sizeof(HuffTables)), pin_batch = pin_hist + up256(8 * 256 * 4 + 256);
     ArenaLease   arena;
     int          err = arena->prepare(off, pin_batch + kBatchBytes);
     if(err != MJX_OK) return err;
     char       *base = arena->dev;
     hipStream_t s = arena->stream;
-
-    HuffTables *ht = reinterpret_cast<HuffTables *>(arena->pin);
-    memset(ht, 0, sizeof(HuffTables));
-    for(int i = 0; i < 4; ++i) {
-        if(scan->dc[i]) {
-            memcpy(ht->code[i], scan->dc[i]->code, sizeof(ht->code[i]));
-            memcpy(ht->size[i], scan->dc[i]->size, sizeof(ht->size[i]));
-        }
-        if(scan->ac[i]) {
-            memcpy(ht->code[4 + i], scan->ac[i]->code, sizeof(ht->code[i]));
-            memcpy(ht->size[4 + i], scan->ac[i]->size, sizeof(ht->size[i]));
-        }
-    }
-    MJX_HIP(hipMemcpyAsync(base + o_tables, ht, sizeof(HuffTables), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
 
     size_t po = o_planes;
     for(int c = 0; c < S.ncomp; ++c) {
@@ -457,6 +549,55 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
         S.c[c].plane = reinterpret_cast<const int16_t *>(base + po);
         po += up256(plane_bytes[c]);
     }
+
+    HuffTables *ht = reinterpret_cast<HuffTables *>(arena->pin);
+    memset(ht, 0, sizeof(HuffTables));
+    if(scan->flags & MJX_HUFF_OPTIMIZE) {
+        // libjpeg's optimize_coding: a first pass over the symbols gathers their statistics, the
+        // tables are built for exactly this image (mjx_huff_optimal_table), the second pass encodes
+        unsigned *d_hist = reinterpret_cast<unsigned *>(base + o_hist), *h_hist = reinterpret_cast<unsigned *>(arena->pin + pin_hist);
+        MJX_HIP(hipMemsetAsync(d_hist, 0, 8 * 256 * 4 + 256, s), MJX_ERR_LAUNCH);
+        hipLaunchKernelGGL(huff_histogram_kernel, dim3((unsigned)((nslots + kHuffThreads - 1) / kHuffThreads)), dim3(kHuffThreads), 0, s, S, nslots, d_hist,
+                           reinterpret_cast<int *>(d_hist + 8 * 256));
+        MJX_HIP(hipGetLastError(), MJX_ERR_LAUNCH);
+        MJX_HIP(hipMemcpyAsync(h_hist, d_hist, 8 * 256 * 4 + 256, hipMemcpyDeviceToHost, s), MJX_ERR_LAUNCH);
+        MJX_HIP(hipStreamSynchronize(s), MJX_ERR_LAUNCH);
+        if(h_hist[8 * 256] != 0) return MJX_ERR_BAD_ARG; // a coefficient outside the JPEG alphabet
+        bool done[8] = {false, false, false, false, false, false, false, false};
+        for(int c = 0; c < S.ncomp; ++c) {
+            const int which[2] = {S.c[c].dc_tbl, 4 + S.c[c].ac_tbl};
+            for(int w = 0; w < 2; ++w) {
+                const int tb = which[w];
+                if(done[tb]) continue;
+                done[tb] = true;
+                mjx_huff_spec_t *out_spec = tb < 4 ? scan->optimal_dc[tb] : scan->optimal_ac[tb - 4];
+                if(out_spec == nullptr) return MJX_ERR_NULL_DATA;
+                if(mjx_huff_optimal_table(h_hist + tb * 256, out_spec) != MJX_OK) return MJX_ERR_BAD_ARG;
+                unsigned code = 0; // derived (code, size) per symbol, JPEG Annex C
+                int      k = 0;
+                for(int len = 1; len <= 16; ++len) {
+                    for(int i = 0; i < out_spec->bits[len - 1]; ++i, ++k, ++code) {
+                        ht->code[tb][out_spec->vals[k]] = code;
+                        ht->size[tb][out_spec->vals[k]] = (uint8_t)len;
+                    }
+                    code <<= 1;
+                }
+            }
+        }
+    }
+    else {
+        for(int i = 0; i < 4; ++i) {
+            if(scan->dc[i]) {
+                memcpy(ht->code[i], scan->dc[i]->code, sizeof(ht->code[i]));
+                memcpy(ht->size[i], scan->dc[i]->size, sizeof(ht->size[i]));
+            }
+            if(scan->ac[i]) {
+                memcpy(ht->code[4 + i], scan->ac[i]->code, sizeof(ht->code[i]));
+                memcpy(ht->size[4 + i], scan->ac[i]->size, sizeof(ht->size[i]));
+            }
+        }
+    }
+    MJX_HIP(hipMemcpyAsync(base + o_tables, ht, sizeof(HuffTables), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
     MJX_HIP(hipMemsetAsync(base + o_words, 0, (size_t)words_cap * 4, s), MJX_ERR_LAUNCH);
     MJX_HIP(hipEventRecord(arena->staged, s), MJX_ERR_LAUNCH);
 

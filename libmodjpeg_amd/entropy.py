@@ -12,6 +12,7 @@ import numpy as np
 from ._lib import check, lib
 
 PLANES_ON_DEVICE = 1  # MJX_HUFF_PLANES_ON_DEVICE
+OPTIMIZE = 2          # MJX_HUFF_OPTIMIZE
 EOI = b"\xff\xd9"
 
 # ITU-T T.81 Annex K.3 (the tables libjpeg installs by default): (bits[16], values)
@@ -46,15 +47,16 @@ class HuffComponent(ctypes.Structure):
                 ("h_samp", ctypes.c_int32), ("v_samp", ctypes.c_int32), ("dc_tbl", ctypes.c_int32), ("ac_tbl", ctypes.c_int32)]
 
 
+class HuffSpec(ctypes.Structure):
+    """struct mjx_huff_spec: a DHT table as the file defines it (decoder input, optimised-table output)"""
+    _fields_ = [("bits", ctypes.c_uint8 * 16), ("vals", ctypes.c_uint8 * 256)]
+
+
 class HuffScan(ctypes.Structure):
     """struct mjx_huff_scan"""
     _fields_ = [("ncomp", ctypes.c_int32), ("mcus_x", ctypes.c_int32), ("mcus_y", ctypes.c_int32), ("comp", HuffComponent * 4),
-                ("dc", ctypes.POINTER(HuffTable) * 4), ("ac", ctypes.POINTER(HuffTable) * 4), ("max_coef_bits", ctypes.c_int32), ("flags", ctypes.c_int32)]
-
-
-class HuffSpec(ctypes.Structure):
-    """struct mjx_huff_spec: a DHT table as the file defines it, for the decoder"""
-    _fields_ = [("bits", ctypes.c_uint8 * 16), ("vals", ctypes.c_uint8 * 256)]
+                ("dc", ctypes.POINTER(HuffTable) * 4), ("ac", ctypes.POINTER(HuffTable) * 4), ("max_coef_bits", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("optimal_dc", ctypes.POINTER(HuffSpec) * 4), ("optimal_ac", ctypes.POINTER(HuffSpec) * 4)]
 
 
 class HuffDComponent(ctypes.Structure):
@@ -102,9 +104,10 @@ def _ptr(plane):
     return plane.data_ptr(), plane.is_cuda
 
 
-def encode_scan(planes, true_dims, samp, mcus_x, mcus_y, dc_tables=(STD_DC_LUMA, STD_DC_CHROMA), ac_tables=(STD_AC_LUMA, STD_AC_CHROMA)):
+def encode_scan(planes, true_dims, samp, mcus_x, mcus_y, dc_tables=(STD_DC_LUMA, STD_DC_CHROMA), ac_tables=(STD_AC_LUMA, STD_AC_CHROMA), optimize=False):
     """scan data (stuffed, without EOI) of one interleaved scan.  planes[c]: int16 [rows, blocks_per_row, 64];
-    true_dims[c] = (width_in_blocks, height_in_blocks); samp[c] = (h, v); component 0 uses table 0, the others table 1"""
+    true_dims[c] = (width_in_blocks, height_in_blocks); samp[c] = (h, v); component 0 uses table 0, the others table 1.
+    optimize=True: tables built for this image as libjpeg's optimize_coding does; returns (data, dc_tables, ac_tables)"""
     sc = HuffScan()
     sc.ncomp, sc.mcus_x, sc.mcus_y, sc.max_coef_bits = len(planes), mcus_x, mcus_y, 10
     on_dev = []
@@ -114,17 +117,27 @@ def encode_scan(planes, true_dims, samp, mcus_x, mcus_y, dc_tables=(STD_DC_LUMA,
         t = 0 if c == 0 else min(1, len(dc_tables) - 1)
         sc.comp[c] = HuffComponent(ptr, p.shape[1], true_dims[c][0], true_dims[c][1], samp[c][0], samp[c][1], t, t)
     assert all(on_dev) or not any(on_dev), "planes must all be on the host or all on the device"
-    sc.flags = PLANES_ON_DEVICE if on_dev[0] else 0
+    sc.flags = (PLANES_ON_DEVICE if on_dev[0] else 0) | (OPTIMIZE if optimize else 0)
     keep = [derived(t) for t in dc_tables], [derived(t) for t in ac_tables]
     for i, t in enumerate(keep[0]):
         sc.dc[i] = ctypes.pointer(t)
     for i, t in enumerate(keep[1]):
         sc.ac[i] = ctypes.pointer(t)
+    built = [HuffSpec() for _ in range(4)], [HuffSpec() for _ in range(4)]
+    for i in range(4):
+        sc.optimal_dc[i], sc.optimal_ac[i] = ctypes.pointer(built[0][i]), ctypes.pointer(built[1][i])
     out, n = ctypes.c_void_p(), ctypes.c_size_t()
     check(lib().mjx_huff_encode_host(ctypes.byref(sc), ctypes.byref(out), ctypes.byref(n)), "mjx_huff_encode_host")
     data = ctypes.string_at(out, n.value)
     ctypes.CDLL(None).free(out)
-    return data
+    if not optimize:
+        return data
+    ntab = 1 if len(planes) == 1 else 2
+
+    def as_table(sp):
+        bits = list(sp.bits)
+        return bits, list(sp.vals)[:sum(bits)]
+    return data, [as_table(built[0][i]) for i in range(ntab)], [as_table(built[1][i]) for i in range(ntab)]
 
 
 def decode_scan(data, planes, samp, mcus_x, mcus_y, restart_interval=0, dc_tables=(STD_DC_LUMA, STD_DC_CHROMA), ac_tables=(STD_AC_LUMA, STD_AC_CHROMA)):

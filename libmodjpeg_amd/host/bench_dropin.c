@@ -8,7 +8,7 @@
  *   bench_dropin <lib.so> <width> <height> <dropon_w> <dropon_h> <n_images> [lum cb cr]
  *
  * Synthetic inputs (deterministic): n JPEGs (quality 85, 4:2:0; BENCH_SAMPLING / BENCH_QUALITY /
- * BENCH_RESTART / BENCH_OPTIMIZE change that) of a gradient + hash noise picture
+ * BENCH_RESTART / BENCH_OPTIMIZE change that; BENCH_WRITE_OPTIONS = MJ_OPTION_* bits for the write) of a gradient + hash noise picture
  * that differs per image, one RGBA dropon with a soft radial alpha.  Per image: read, mj_compose at
  * an unaligned position, optional effects, write.  Prints per-stage times and an FNV-1a hash over
  * all output bytes.
@@ -172,7 +172,7 @@ int main(int argc, char **argv) {
         double         t3 = now_ms();
         unsigned char *out = NULL;
         size_t         outlen = 0;
-        if((rv = p_mj_write_jpeg_to_memory(&m, &out, &outlen, MJ_OPTION_NONE)) != MJ_OK) return 60 + rv;
+        if((rv = p_mj_write_jpeg_to_memory(&m, &out, &outlen, getenv("BENCH_WRITE_OPTIONS") != NULL ? atoi(getenv("BENCH_WRITE_OPTIONS")) : MJ_OPTION_NONE)) != MJ_OK) return 60 + rv;
         double t4 = now_ms();
         if(i >= 0) {
             size_t j;

@@ -1,7 +1,8 @@
 /*
  * gpuencode.c — mj_write_jpeg_to_memory() with the entropy-coded segment produced on the GPU
- * (write side).  Used for MJ_OPTION_NONE (fixed Huffman tables, sequential);
- * optimised, progressive and arithmetic output stays with libjpeg.
+ * (write side).  Used for MJ_OPTION_NONE (fixed Huffman tables) and for
+ * MJ_OPTION_OPTIMIZE (tables built for the image, from symbol statistics gathered on the device, as
+ * libjpeg's optimize_coding builds them); progressive and arithmetic output stays with libjpeg.
  *
  * The markers are still libjpeg's: a one-MCU image with the same parameters, tables and saved
  * markers is written with jpeg_write_coefficients()/jpeg_finish_compress(), its header (SOI ..
@@ -46,7 +47,7 @@ static void derive_table(mjx_huff_table_t *t, const unsigned char *counts, const
 }
 
 /* header of the real file: libjpeg writes a 1-MCU image with identical parameters */
-static int tiny_jpeg(mj_jpeg_t *m, unsigned char **buf, unsigned long *len) {
+static int tiny_jpeg(mj_jpeg_t *m, int optimize, unsigned char **buf, unsigned long *len) {
     struct jpeg_compress_struct enc;
     mjh_error_trap_t            trap;
     jvirt_barray_ptr            arrays[MAX_COMPONENTS];
@@ -78,7 +79,7 @@ static int tiny_jpeg(mj_jpeg_t *m, unsigned char **buf, unsigned long *len) {
     enc.jpeg_width = enc.image_width;
     enc.jpeg_height = enc.image_height;
 #endif
-    enc.optimize_coding = FALSE; /* the write options of MJ_OPTION_NONE (image.c:170-189) */
+    enc.optimize_coding = optimize ? TRUE : FALSE; /* MJ_OPTION_NONE / MJ_OPTION_OPTIMIZE (image.c:170-189) */
     enc.scan_info = NULL;
     enc.arith_code = FALSE;
     for(c = 0; c < enc.num_components; c++) {
@@ -93,10 +94,12 @@ static int tiny_jpeg(mj_jpeg_t *m, unsigned char **buf, unsigned long *len) {
     return MJ_OK;
 }
 
-int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len) {
+int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len, int optimize) {
     unsigned char   *hdr = NULL, *scan = NULL, *out;
     unsigned long    hdrlen = 0;
-    size_t           scanlen = 0, pos, header_end = 0, sof_dims = 0;
+    size_t           scanlen = 0, pos, header_end = 0, sof_dims = 0, first_dht = 0, sos_at = 0;
+    mjx_huff_spec_t  built_dc[4], built_ac[4];
+    int              dht_order[8], ndht = 0; /* (class << 4 | index) of the tables in the order libjpeg wrote them */
     mjx_huff_table_t dc[4], ac[4];
     int              have_dc[4] = {0, 0, 0, 0}, have_ac[4] = {0, 0, 0, 0};
     mjx_huff_scan_t  sc;
@@ -105,7 +108,7 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len) {
     mjh_shadow_t    *shadow = mjh_shadow_of(m);
 
     if(m->cinfo.num_components < 1 || m->cinfo.num_components > 4 || m->cinfo.data_precision != 8) return MJH_ENCODE_UNSUPPORTED;
-    rv = tiny_jpeg(m, &hdr, &hdrlen);
+    rv = tiny_jpeg(m, optimize, &hdr, &hdrlen);
     if(rv != MJ_OK) return MJH_ENCODE_UNSUPPORTED; /* let libjpeg report the error on the real file */
 
     /* walk the markers up to and including SOS */
@@ -129,6 +132,7 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len) {
         }
         else if(marker == 0xC4) {
             size_t p = body, end = pos + 2 + (size_t)seglen;
+            if(first_dht == 0) first_dht = pos;
             while(p + 17 <= end) {
                 const int tc = hdr[p] >> 4, th = hdr[p] & 15;
                 int       n = 0;
@@ -136,6 +140,7 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len) {
                 if(th > 3 || tc > 1 || p + 17 + (size_t)n > end) BAIL("bad DHT");
                 derive_table(tc == 0 ? &dc[th] : &ac[th], hdr + p + 1, hdr + p + 17);
                 (tc == 0 ? have_dc : have_ac)[th] = 1;
+                if(ndht < 8) dht_order[ndht++] = (tc << 4) | th;
                 p += 17 + (size_t)n;
             }
         }
@@ -153,6 +158,7 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len) {
             /* Ss, Se, Ah/Al of a sequential scan */
             if(hdr[body + 1 + 2 * ns] != 0 || hdr[body + 2 + 2 * ns] != 63 || hdr[body + 3 + 2 * ns] != 0) BAIL("not a full sequential scan");
             header_end = pos + 2 + (size_t)seglen;
+            sos_at = pos;
             break;
         }
         pos += 2 + (size_t)seglen;
@@ -208,6 +214,14 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len) {
     for(i = 0; i < 4; i++) {
         sc.dc[i] = have_dc[i] ? &dc[i] : NULL;
         sc.ac[i] = have_ac[i] ? &ac[i] : NULL;
+        sc.optimal_dc[i] = &built_dc[i];
+        sc.optimal_ac[i] = &built_ac[i];
+    }
+    if(optimize) {
+        /* the tables of the one-MCU header fit the one-MCU image: the real ones are built from this
+         * image's symbol statistics on the device and replace them below */
+        if(first_dht == 0 || first_dht >= sos_at) BAIL("no DHT before SOS");
+        sc.flags |= MJX_HUFF_OPTIMIZE;
     }
 
     {
@@ -220,6 +234,34 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len) {
             rv = mjh_from_mjx(e);
             goto done;
         }
+    }
+    if(optimize) { /* header = everything up to the first DHT + the tables just built, in libjpeg's order + SOS */
+        unsigned char *h2 = (unsigned char *)malloc(first_dht + (size_t)ndht * (2 + 2 + 1 + 16 + 256) + (header_end - sos_at));
+        size_t         o = first_dht;
+        if(h2 == NULL) {
+            rv = MJ_ERR_MEMORY;
+            goto done;
+        }
+        memcpy(h2, hdr, first_dht);
+        for(i = 0; i < ndht; i++) {
+            const mjx_huff_spec_t *t = (dht_order[i] >> 4) ? &built_ac[dht_order[i] & 15] : &built_dc[dht_order[i] & 15];
+            int                    n = 0, k;
+            for(k = 0; k < 16; k++) n += t->bits[k];
+            h2[o++] = 0xFF;
+            h2[o++] = 0xC4;
+            h2[o++] = (unsigned char)((2 + 1 + 16 + n) >> 8);
+            h2[o++] = (unsigned char)((2 + 1 + 16 + n) & 255);
+            h2[o++] = (unsigned char)dht_order[i];
+            memcpy(h2 + o, t->bits, 16);
+            o += 16;
+            memcpy(h2 + o, t->vals, (size_t)n);
+            o += (size_t)n;
+        }
+        memcpy(h2 + o, hdr + sos_at, header_end - sos_at);
+        o += header_end - sos_at;
+        free(hdr);
+        hdr = h2;
+        header_end = o; /* (the frame header lies before the tables: sof_dims is unchanged) */
     }
     out = (unsigned char *)malloc(header_end + scanlen + 2);
     if(out == NULL) {

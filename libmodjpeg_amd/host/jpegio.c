@@ -178,10 +178,10 @@ int mj_write_jpeg_to_memory(mj_jpeg_t *m, unsigned char **memory, size_t *len, i
     if(m == NULL || memory == NULL || len == NULL) return MJ_ERR_NULL_DATA;
     if(m->coef == NULL) return MJ_ERR_NULL_DATA;
 
-    /* fixed tables, sequential: the entropy-coded segment is produced on the GPU, byte-identical
-     * to libjpeg's (MJ_GPU_ENCODE=0 keeps everything in libjpeg) */
-    if(options == MJ_OPTION_NONE && !(getenv("MJ_GPU_ENCODE") != NULL && getenv("MJ_GPU_ENCODE")[0] == '0')) {
-        const int rv = mjh_write_gpu_entropy(m, memory, len);
+    /* sequential Huffman, fixed or optimised tables: the entropy-coded segment is produced on the
+     * GPU, byte-identical to libjpeg's (MJ_GPU_ENCODE=0 keeps everything in libjpeg) */
+    if((options == MJ_OPTION_NONE || options == MJ_OPTION_OPTIMIZE) && !(getenv("MJ_GPU_ENCODE") != NULL && getenv("MJ_GPU_ENCODE")[0] == '0')) {
+        const int rv = mjh_write_gpu_entropy(m, memory, len, options == MJ_OPTION_OPTIMIZE);
         if(rv != MJH_ENCODE_UNSUPPORTED) return rv;
     }
     { /* libjpeg encodes from its own arrays: a device-resident image comes down first */

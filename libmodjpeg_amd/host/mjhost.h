@@ -58,7 +58,7 @@ int16_t *mjh_plane_direct(mj_jpeg_t *m, int c, int *pitch);
 /* mj_write_jpeg_to_memory with the scan data encoded on the GPU (gpuencode.c); returns
  * MJH_ENCODE_UNSUPPORTED when the file needs libjpeg's own encoder */
 #define MJH_ENCODE_UNSUPPORTED (-1)
-int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len);
+int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len, int optimize);
 
 /* mj_read_jpeg_from_memory after jpeg_read_header(): the scan data decoded on the GPU into
  * arrays requested from libjpeg's memory manager (gpudecode.c).  MJ_OK: m->coef is set.

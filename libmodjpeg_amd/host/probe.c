@@ -23,10 +23,17 @@
  *        the same comparison on damaged copies of the file (flipped bits, random runs, truncation,
  *        stray restart markers): whatever libjpeg makes of a broken stream, the drop-in must
  *        return the same arrays or the same error.  Prints the tally.
+ *   mjhost_probe opttables <image.jpg> <mode> <seed>
+ *        (no GPU needed) fills the image's coefficient arrays with symbols drawn from a chosen
+ *        distribution (0: Fibonacci-like counts, code lengths beyond 16 bits; 1: many equal counts;
+ *        2: random), lets libjpeg write it with optimised Huffman tables and compares the DHT tables
+ *        in that file with mjx_huff_optimal_table() on the same symbol histograms.
  *   mjhost_probe nodevice <image.jpg>
  *        prints the return codes of mj_effect_luminance and mj_compose (expects MJ_ERR_MEMORY
  *        on a machine without a GPU: there is no CPU fallback).
  */
+#define _GNU_SOURCE
+#include <dlfcn.h>
 #include <libmodjpeg.h>
 
 #include <pthread.h>
@@ -150,6 +157,149 @@ out:
     mj_free_jpeg(&a);
     mj_free_jpeg(&b);
     return result;
+}
+
+/* ---- opttables ---- */
+static const unsigned char zigzag_order[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                               41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                               30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+static int bit_length(int v) {
+    int n = 0;
+    if(v < 0) v = -v;
+    while(v) {
+        n++;
+        v >>= 1;
+    }
+    return n;
+}
+
+/* what jchuff.c's statistics pass counts for one block (htest_one_block) */
+static void count_block(const JCOEF *b, int *last_dc, uint32_t *dc, uint32_t *ac) {
+    int k, r = 0;
+    dc[bit_length(b[0] - *last_dc)]++;
+    *last_dc = b[0];
+    for(k = 1; k < 64; k++) {
+        const int v = b[zigzag_order[k]];
+        if(v == 0) {
+            r++;
+            continue;
+        }
+        while(r > 15) {
+            ac[0xF0]++;
+            r -= 16;
+        }
+        ac[(r << 4) + bit_length(v)]++;
+        r = 0;
+    }
+    if(r > 0) ac[0]++;
+}
+
+static int opttables(const char *path, int mode, uint32_t seed) {
+    /* libmjx_hip.so comes in as a dependency of the drop-in: find the symbol in what is loaded */
+    int (*mjx_huff_optimal_table)(const uint32_t *, void *) = (int (*)(const uint32_t *, void *))dlsym(RTLD_DEFAULT, "mjx_huff_optimal_table");
+    mj_jpeg_t      m;
+    unsigned char *out = NULL;
+    size_t         len = 0, pos;
+    uint32_t       hist[2][2][256]; /* [dc/ac][table][symbol] */
+    uint32_t       rng = seed * 2654435761u + 12345u;
+    int            c, bad = 0, last[4] = {0, 0, 0, 0};
+    /* symbol alphabet the generator draws from: (run, size) pairs in a fixed order */
+    int            alphabet[160], nalpha = 0, weight[160], total = 0, i;
+    for(i = 0; i < 160; i++) {
+        const int run = i / 10, size = 1 + i % 10;
+        alphabet[nalpha++] = (run << 4) | size;
+    }
+    for(i = 0; i < nalpha; i++) {
+        if(mode == 0) { /* Fibonacci-like over the first 24 symbols: optimal lengths run past 16 bits */
+            static const int fib[24] = {1, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987, 1597, 2584, 4181, 6765, 10946, 17711, 28657, 46368};
+            weight[i] = i < 24 ? fib[i] : 0;
+        }
+        else if(mode == 1) weight[i] = i < 60 ? 50 : 0; /* equal counts: ties everywhere */
+        else weight[i] = 1 + (int)(xorshift(&rng) % 1000u) * (i % 7 == 0);
+        total += weight[i];
+    }
+    if(mjx_huff_optimal_table == NULL) return 9;
+    mj_init_jpeg(&m);
+    setenv("MJ_GPU_DECODE", "0", 1);
+    setenv("MJ_GPU_ENCODE", "0", 1);
+    if(mj_read_jpeg_from_file(&m, path, 0) != MJ_OK) return 10;
+    memset(hist, 0, sizeof(hist));
+    for(c = 0; c < m.cinfo.num_components; c++) {
+        jpeg_component_info *ci = &m.cinfo.comp_info[c];
+        JDIMENSION           r, x;
+        for(r = 0; r < ci->height_in_blocks; r++) {
+            JBLOCKARRAY a = (*m.cinfo.mem->access_virt_barray)((j_common_ptr)&m.cinfo, m.coef[c], r, 1, TRUE);
+            for(x = 0; x < ci->width_in_blocks; x++) {
+                JCOEF *b = a[0][x];
+                int    k = 1;
+                memset(b, 0, sizeof(JBLOCK));
+                b[0] = (JCOEF)((int)(xorshift(&rng) % 2001u) - 1000);
+                for(;;) { /* draw symbols until the block is full or the generator says stop */
+                    int pick = (int)(xorshift(&rng) % (uint32_t)total), sym, run, size;
+                    for(i = 0; pick >= weight[i]; i++) pick -= weight[i];
+                    sym = alphabet[i];
+                    run = sym >> 4;
+                    size = sym & 15;
+                    if(k + run > 63 || xorshift(&rng) % 12u == 0) break;
+                    k += run;
+                    b[zigzag_order[k]] = (JCOEF)((xorshift(&rng) & 1u) ? (1 << (size - 1)) : -(1 << (size - 1)));
+                    k++;
+                }
+            }
+        }
+    }
+    /* the statistics libjpeg will gather: MCU order matters only for the DC predictions */
+    {
+        const int mcus_x = m.cinfo.num_components == 1 ? (int)m.cinfo.comp_info[0].width_in_blocks : (m.width + m.sampling.h_factor - 1) / m.sampling.h_factor,
+                  mcus_y = m.cinfo.num_components == 1 ? (int)m.cinfo.comp_info[0].height_in_blocks : (m.height + m.sampling.v_factor - 1) / m.sampling.v_factor;
+        int       mx, my, x, y;
+        for(my = 0; my < mcus_y; my++)
+            for(mx = 0; mx < mcus_x; mx++)
+                for(c = 0; c < m.cinfo.num_components; c++) {
+                    jpeg_component_info *ci = &m.cinfo.comp_info[c];
+                    const int            hs = m.cinfo.num_components == 1 ? 1 : ci->h_samp_factor, vs = m.cinfo.num_components == 1 ? 1 : ci->v_samp_factor;
+                    for(y = 0; y < vs; y++)
+                        for(x = 0; x < hs; x++) {
+                            const int by = my * vs + y, bx = mx * hs + x;
+                            if(by < (int)ci->height_in_blocks && bx < (int)ci->width_in_blocks) {
+                                JBLOCKARRAY a = (*m.cinfo.mem->access_virt_barray)((j_common_ptr)&m.cinfo, m.coef[c], (JDIMENSION)by, 1, FALSE);
+                                count_block(a[0][bx], &last[c], hist[0][c == 0 ? 0 : 1], hist[1][c == 0 ? 0 : 1]);
+                            }
+                            else { /* jctrans.c: a dummy block repeats the DC of the block before it, AC zero */
+                                JBLOCK dummy;
+                                memset(dummy, 0, sizeof(dummy));
+                                dummy[0] = (JCOEF)last[c];
+                                count_block(dummy, &last[c], hist[0][c == 0 ? 0 : 1], hist[1][c == 0 ? 0 : 1]);
+                            }
+                        }
+                }
+    }
+    if(mj_write_jpeg_to_memory(&m, &out, &len, MJ_OPTION_OPTIMIZE) != MJ_OK) return 11;
+    for(pos = 2; pos + 4 <= len;) {
+        const int marker = out[pos + 1], seglen = (out[pos + 2] << 8) | out[pos + 3];
+        if(marker == 0xDA) break;
+        if(marker == 0xC4) {
+            size_t p = pos + 4, end = pos + 2 + (size_t)seglen;
+            while(p + 17 <= end) {
+                const int tc = out[p] >> 4, th = out[p] & 15;
+                struct {
+                    uint8_t bits[16], vals[256];
+                } mine;
+                int n = 0, same;
+                for(i = 0; i < 16; i++) n += out[p + 1 + i];
+                if(mjx_huff_optimal_table(hist[tc][th], &mine) != 0) return 12;
+                same = memcmp(mine.bits, out + p + 1, 16) == 0 && memcmp(mine.vals, out + p + 17, (size_t)n) == 0;
+                printf("%s table %d: %d symbols, longest code %d bits: %s\n", tc ? "AC" : "DC", th, n,
+                       (int)(out[p + 16] ? 16 : (out[p + 15] ? 15 : (out[p + 14] ? 14 : 0))), same ? "same" : "DIFFERENT");
+                bad += !same;
+                p += 17 + (size_t)n;
+            }
+        }
+        pos += 2 + (size_t)seglen;
+    }
+    free(out);
+    mj_free_jpeg(&m);
+    return bad ? 1 : 0;
 }
 
 int main(int argc, char **argv) {
@@ -286,6 +436,7 @@ int main(int argc, char **argv) {
         free(buf);
         return count[2] ? 1 : 0;
     }
+    if(argc == 5 && strcmp(argv[1], "opttables") == 0) return opttables(argv[2], atoi(argv[3]), (uint32_t)atoi(argv[4]));
     if(argc == 3 && strcmp(argv[1], "nodevice") == 0) {
         mj_jpeg_t     m;
         mj_dropon_t   d;

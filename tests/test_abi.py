@@ -47,7 +47,7 @@ def test_ctypes_mirrors_have_the_c_layout(hiplib, tmp_path):
         "mjx_dc_job_t": (hiplib.DcJob, ["coef", "value", "q0"]),
         "mjx_huff_table_t": (E.HuffTable, ["code", "size"]),
         "mjx_huff_component_t": (E.HuffComponent, ["plane", "blocks_per_row", "h_samp", "ac_tbl"]),
-        "mjx_huff_scan_t": (E.HuffScan, ["ncomp", "comp", "dc", "ac", "max_coef_bits", "flags"]),
+        "mjx_huff_scan_t": (E.HuffScan, ["ncomp", "comp", "dc", "ac", "max_coef_bits", "flags", "optimal_dc", "optimal_ac"]),
         "mjx_huff_spec_t": (E.HuffSpec, ["bits", "vals"]),
         "mjx_huff_dcomponent_t": (E.HuffDComponent, ["plane", "blocks_per_row", "ac_tbl"]),
         "mjx_huff_dscan_t": (E.HuffDScan, ["ncomp", "comp", "dc", "ac", "data", "nbytes", "restart_interval", "flags"]),

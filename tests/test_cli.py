@@ -82,7 +82,7 @@ BATCH_SCRIPTS = [
     ["-p", "br", "-m", "-10,-10", "-d", PNG, "-y", "20"],        # compose + luminance, GPU encoder
     ["-x", "-p", "tr", "-d", PNG],                                # pixelate, then logo
     ["-g", "-b", "-25", "-r", "15", "-y", "-30"],                 # grayscale, tint (no-ops on zeroed chroma DCs aside), luminance
-    ["-p", "cc", "-d", JPG, "-O"],                                # optimised output: libjpeg writes, the image comes down first
+    ["-p", "cc", "-d", JPG, "-O"],                                # optimised output: statistics and tables for the image, still on the device
     ["-y", "10", "-P"],                                           # progressive output
     ["-p", "cc", "-m", "5,-3", "-d", os.path.join(IMAGES, "image_dropon.jpg"), "-d", PNG],  # a 256x256 dropon (thousands of blocks per launch), then a small one
 ]

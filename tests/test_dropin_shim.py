@@ -201,6 +201,37 @@ def test_gpu_entropy_encoder_byte_identical(shim, size, sampling):
         assert gpu["fnv1a"] == r["fnv1a"]
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_optimal_huffman_tables_equal_libjpegs(shim, mode):
+    """MJ_OPTION_OPTIMIZE: the tables mjx_huff_optimal_table() builds from a symbol histogram are the
+    ones libjpeg 9d writes for the same coefficients (DHT segments compared) - Fibonacci-like counts
+    that push code lengths past 16 bits, equal counts (ties everywhere), random counts.  No GPU."""
+    for seed in ("1", "2", "3"):
+        res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "opttables", os.path.join(IMAGES, "image.jpg"), mode, seed], capture_output=True, text=True)
+        assert res.returncode == 0 and "DIFFERENT" not in res.stdout and res.stdout.count("same") == 4, (res.stdout, res.stderr[-300:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampling", ["420", "422", "440", "444", "gray"])
+@pytest.mark.parametrize("size", [("641", "479"), ("33", "17"), ("1000", "33"), ("1920", "1080")])
+def test_gpu_entropy_encoder_with_optimised_tables_byte_identical(shim, size, sampling):
+    """mj_write_jpeg_to_memory(MJ_OPTION_OPTIMIZE): symbol statistics gathered on the device, tables
+    built as libjpeg's optimize_coding builds them, DHT segments rewritten, scan encoded on the GPU:
+    the same bytes as libjpeg writing the file, and as the reference"""
+    import json
+    exe = os.path.join(HOST, "bench_dropin")
+    args = [*size, "16", "16", "2", "9", "-4", "6"]
+    env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_WRITE_OPTIONS="1")
+    gpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))
+    cpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=dict(env, MJ_GPU_ENCODE="0")))
+    assert gpu["gpu_encodes"] == 3 and cpu["gpu_encodes"] == 0
+    assert gpu["out_bytes"] == cpu["out_bytes"] and gpu["fnv1a"] == cpu["fnv1a"], (gpu, cpu)
+    ref = os.path.join(ROOT, "oracle", "_ref", "libmodjpeg_ref.so")
+    if os.path.exists(ref) and sampling != "gray":
+        r = json.loads(subprocess.check_output([exe, ref, *args], text=True, env=env))
+        assert gpu["fnv1a"] == r["fnv1a"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [("640", "480", "160", "96", "3"), ("1920", "1080", "256", "256", "2", "7", "5", "-3")])
 def test_written_jpegs_byte_identical_to_reference(shim, args):

@@ -35,7 +35,8 @@ class HuffComponent(ctypes.Structure):
 
 class HuffScan(ctypes.Structure):
     _fields_ = [("ncomp", ctypes.c_int32), ("mcus_x", ctypes.c_int32), ("mcus_y", ctypes.c_int32), ("comp", HuffComponent * 4),
-                ("dc", ctypes.POINTER(HuffTable) * 4), ("ac", ctypes.POINTER(HuffTable) * 4), ("max_coef_bits", ctypes.c_int32), ("flags", ctypes.c_int32)]
+                ("dc", ctypes.POINTER(HuffTable) * 4), ("ac", ctypes.POINTER(HuffTable) * 4), ("max_coef_bits", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("optimal_dc", ctypes.c_void_p * 4), ("optimal_ac", ctypes.c_void_p * 4)]
 
 
 def derive(bits, vals):
