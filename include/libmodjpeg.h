@@ -10,9 +10,9 @@
  * What is different is where the per-8x8-block work runs: mj_compose() and the mj_effect_*()
  * functions execute on the GPU through the C ABI of include/mjx.h (hand-written gfx950 HIP
  * kernels), bit-exact with the reference's CPU loops.  The scan data of sequential Huffman files is
- * decoded and (for MJ_OPTION_NONE) encoded on the GPU as well, with the same coefficients and the
+ * decoded and (for MJ_OPTION_NONE and MJ_OPTION_OPTIMIZE) encoded on the GPU as well, with the same coefficients and the
  * same bytes as libjpeg; libjpeg still parses and writes the markers, prepares the dropon tiles and
- * handles every file the GPU coders decline (progressive, arithmetic, optimised output, damaged
+ * handles every file the GPU coders decline (progressive, arithmetic, damaged
  * streams), exactly as in the reference.  There is no CPU implementation of the block loops in
  * this library: without a HIP device those calls return MJ_ERR_MEMORY and print a diagnostic
  * ("error mapping").

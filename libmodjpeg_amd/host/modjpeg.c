@@ -13,8 +13,8 @@
  * threads work on different files.  An image is decoded on the GPU and STAYS there (shadow.c):
  * compose and the effects run in place, the encoder reads the planes where they are, and only
  * compressed bytes cross PCIe in either direction; concurrent decodes are launched as one batch.
- * Files the GPU entropy coder declines (progressive, arithmetic, -O/-P/-A output) go through
- * libjpeg as in the reference.  The prepared dropon tiles are shared by all threads
+ * Files the GPU entropy coders decline (progressive, arithmetic, -P/-A output) go through libjpeg
+ * as in the reference.  The prepared dropon tiles are shared by all threads
  * (device-resident tile cache).
  */
 #include <libmodjpeg.h>

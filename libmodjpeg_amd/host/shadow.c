@@ -12,7 +12,7 @@
  * sound when nothing but this library looks at them, so the mode is opt-in: the batch CLI turns it
  * on for its workers (mjh_set_device_resident), a program that sticks to the mj_* functions can do
  * the same with MJ_DEVICE_RESIDENT=1.  Whenever the library itself needs the host copy (a write
- * libjpeg has to do: -O/-P/-A, restart intervals; the tile preparation's read-back) it downloads
+ * libjpeg has to do: -P/-A, restart intervals; the tile preparation's read-back) it downloads
  * the shadow first and drops it (mjh_host_sync), and the image continues as an ordinary one.
  */
 #include "mjhost.h"
