@@ -236,3 +236,21 @@ def test_decode_and_encode_on_planes_that_stay_on_the_device():
     ctypes.CDLL(None).free(out)
     for d in dev:
         L.mjx_free(d)
+
+
+def test_optimised_tables_round_trip_through_the_python_mirror():
+    """entropy.encode_scan(optimize=True) builds tables for the image on the device pass + host table
+    generation; the decoder, given those tables, returns the planes; the stream is not longer than
+    the one coded with the Annex K tables"""
+    from libmodjpeg_amd import entropy as E
+    geom, mcus_x, mcus_y = [(2, 2), (1, 1), (1, 1)], 50, 30
+    rng = np.random.default_rng(21)
+    planes = random_planes(rng, geom, mcus_x, mcus_y, 0.12, 300)
+    true_dims = [(p.shape[1], p.shape[0]) for p in planes]
+    plain = E.encode_scan(planes, true_dims, geom, mcus_x, mcus_y)
+    data, dc_t, ac_t = E.encode_scan(planes, true_dims, geom, mcus_x, mcus_y, optimize=True)
+    assert len(data) <= len(plain) and len(dc_t) == 2 and len(ac_t) == 2
+    back = [np.full_like(p, 0x5555) for p in planes]
+    E.decode_scan(data + E.EOI, back, geom, mcus_x, mcus_y, dc_tables=dc_t, ac_tables=ac_t)
+    for c in range(3):
+        assert np.array_equal(back[c], planes[c]), c
