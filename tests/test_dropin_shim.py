@@ -370,3 +370,41 @@ def test_read_compose_write_identical_with_both_entropy_paths_on_the_gpu(shim):
     if os.path.exists(ref):
         r = json.loads(subprocess.check_output([exe, ref, *args], text=True, env=env))
         assert gpu["fnv1a"] == r["fnv1a"]
+
+
+@pytest.mark.gpu
+def test_files_from_another_encoder(shim, tmp_path):
+    """JPEGs written by PIL (libjpeg-turbo: its own marker layout, all Huffman tables in one DHT segment,
+    optimised tables, comments and application segments): the GPU decoder gives libjpeg's arrays, and
+    the drop-in's CLI writes what the reference's CLI writes"""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    y, x = np.mgrid[0:413, 0:655]
+    base = np.stack([(x * 255 // 655), (y * 255 // 413), ((x + y) // 8 * 8) % 256], -1).astype(np.int16)
+    img = PIL.fromarray((base + rng.integers(-20, 20, base.shape)).clip(0, 255).astype(np.uint8))
+    probe, cli = os.path.join(HOST, "mjhost_probe"), os.path.join(HOST, "modjpeg")
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "modjpeg_ref")
+    env = dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0")
+    k = 0
+    for quality in (20, 75, 96):
+        for subsampling in (0, 1, 2):
+            for optimize in (False, True):
+                k += 1
+                src = tmp_path / f"pil{k}.jpg"
+                img.save(src, quality=quality, subsampling=subsampling, optimize=optimize, comment=b"made by PIL " * 50, dpi=(300, 300))
+                res = subprocess.run([probe, "decodecmp", str(src)], capture_output=True, text=True, env=env)
+                assert res.stdout.strip() == "same gpu", (quality, subsampling, optimize, res.stdout, res.stderr[-300:])
+                if os.path.exists(ref_cli) and k % 3 == 0:
+                    a, b = tmp_path / "a.jpg", tmp_path / "b.jpg"
+                    argv = ["-i", str(src), "-p", "br", "-m", "-7,-5", "-d", os.path.join(IMAGES, "dropon.png"), "-y", "15"]
+                    subprocess.run([ref_cli] + argv + ["-o", str(a)], check=True, capture_output=True)
+                    subprocess.run([cli] + argv + ["-o", str(b)], check=True, capture_output=True, env=env)
+                    assert a.read_bytes() == b.read_bytes(), (quality, subsampling, optimize)
+    gray = tmp_path / "gray.jpg"
+    img.convert("L").save(gray, quality=88, optimize=True)
+    res = subprocess.run([probe, "decodecmp", str(gray)], capture_output=True, text=True, env=env)
+    assert res.stdout.strip() == "same gpu", res.stdout
+    prog = tmp_path / "prog.jpg"
+    img.save(prog, quality=80, progressive=True)
+    res = subprocess.run([probe, "decodecmp", str(prog)], capture_output=True, text=True, env=env)
+    assert res.stdout.strip() == "same fallback", res.stdout
