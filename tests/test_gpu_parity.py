@@ -213,6 +213,32 @@ def test_host_buffer_entry_point(mj):
     assert np.array_equal(got, want)
 
 
+def test_host_buffer_call_mixes_narrow_and_wide_rectangles(mj):
+    """mjx_compose_host with three rectangles in one call: a narrow one (travels alone through pinned
+    memory), a wide one and a full-width one (whole rows straight from the caller's buffer); blocks
+    outside the rectangles must come back untouched"""
+    from libmodjpeg_amd._lib import HostRect, check, lib
+    vp = ctypes.c_void_p
+    wib, hib = 40, 24
+    shapes = [(3, 2, 5, 9), (1, 10, 6, 25), (15, 0, 4, 40)]  # row0, col0, rows, cols: 9*3 <= 40 < 25*3
+    rects = (HostRect * 3)()
+    keep, planes, want = [], [], []
+    for c, (row0, col0, rows, cols) in enumerate(shapes):
+        q = O.quant_table(c > 0)
+        plane = O.synth_coef(7, c, 0, wib * hib, q)
+        tile, alpha = O.synth_tile(7, c, 0, rows * cols), O.synth_alpha(7, c, 0, rows * cols, 2 + (c & 1))
+        ref = plane.copy()
+        O.compose_rect(ref, wib, row0, col0, rows, cols, q, tile, alpha)
+        got = plane.copy()
+        rects[c] = HostRect(got.ctypes.data + row0 * wib * 128, tile.ctypes.data, alpha.ctypes.data, q.ctypes.data, wib, col0, rows, cols, 0, 0)
+        keep += [q, tile, alpha]
+        planes.append(got)
+        want.append(ref)
+    check(lib().mjx_compose_host(rects, 3), "mjx_compose_host")
+    for c in range(3):
+        assert np.array_equal(planes[c], want[c]), c
+
+
 @pytest.mark.parametrize("family", ["bitpattern", "denormal", "huge_q", "mixed_sparse"])
 def test_fuzz_blocks_vs_oracle(mj, family):
     """large randomised differential test on adversarial inputs: raw random float bit patterns
