@@ -211,7 +211,6 @@ static int run_batch(const char *list, const char *outdir, int jobs, const actio
         fprintf(stderr, "Can't read the batch list '%s'\n", list);
         return 1;
     }
-    if(getenv("MJ_DEVICE_RESIDENT") == NULL) mjh_set_device_resident(1); /* MJ_DEVICE_RESIDENT=0 keeps the host arrays authoritative */
     memset(&b, 0, sizeof(b));
     while(fgets(line, sizeof(line), f) != NULL) {
         size_t n = strlen(line);
@@ -258,6 +257,9 @@ int main(int argc, char **argv) {
     const char *batch_list = NULL, *outdir = ".";
     int         nscript = 0, jobs = 4, c, i, rc = 0;
 
+    /* this program only ever touches an image through the mj_* functions, so images may stay on the
+     * device between read and write (MJ_DEVICE_RESIDENT=0 keeps the host arrays authoritative) */
+    if(getenv("MJ_DEVICE_RESIDENT") == NULL) mjh_set_device_resident(1);
     opterr = 1;
     /* leading ':' => a missing argument is reported as ':' like the reference's option string */
     while((c = getopt_long(argc, argv, ":i:o:d:p:m:y:b:r:xgPOAh", long_options, NULL)) != -1) {
