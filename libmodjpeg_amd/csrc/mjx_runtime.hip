@@ -340,12 +340,12 @@ pthread_cond_t  g_pool_free = PTHREAD_COND_INITIALIZER;
 
 // borrow an arena that already lives on the calling thread's device if there is one, else an
 // unused slot; blocks while all slots are busy
-// arenas in use at most (MJX_ARENAS, default 16): each owns a stream, and more streams than
+// arenas in use at most (MJX_ARENAS, default 32; created on first use, so a program with few threads has few): each owns a stream, and more streams than
 // hardware queues buy no further overlap
 int arena_limit() {
         static const int n = [] {
             const char *e = getenv("MJX_ARENAS");
-            const int   v = e ? atoi(e) : 16;
+            const int   v = e ? atoi(e) : 32;
             return v < 1 ? 1 : (v > kMaxArenas ? kMaxArenas : v);
         }();
         return n;
