@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--spinup-ms", type=float, default=400.0,
                     help="untimed steps run for this long before the W warm-up steps: the MI355X clock governor needs "
                          "~25 ms of sustained load to leave its idle state (per-step time falls from 1.29 to 0.92 ms)")
-    ap.add_argument("--workload", default="compose_1080p_batch", choices=list(WORKLOADS) + ["effects_4k_batch"])
+    ap.add_argument("--workload", default="compose_1080p_batch", choices=list(WORKLOADS) + ["effects_4k_batch", "entropy_1080p_batch"])
+    ap.add_argument("--threads", type=int, default=16, help="entropy_1080p_batch: host threads calling the coders concurrently")
     ap.add_argument("--regime", default="A2", choices=list(REGIMES))
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="images in the CPU baseline / parity sample (0 = skip)")
@@ -190,6 +191,8 @@ def main():
 
     if args.workload == "effects_4k_batch":
         return bench_effects(args, rank, world)
+    if args.workload == "entropy_1080p_batch":
+        return bench_entropy(args, rank, world)
 
     from libmodjpeg_amd.batch import ComposeBatch
 
@@ -305,6 +308,75 @@ def bench_effects(args, rank, world):
                          "kernel": "mjx::effect_dc_kernel", "kernel_ms_mean": mean_ms,
                          "note": "algorithmic 4 B per DC; the stream is sector-bound (one 2-byte field per 128-byte block)"},
             "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_entropy(args, rank, world):
+    """Secondary workload: the baseline Huffman coders on composed 1080p images
+    whose planes stay on the device.  One step = every image of the batch encoded to scan data and
+    decoded back into scratch planes, by `--threads` host threads calling the C ABI concurrently (the
+    library combines concurrent callers into one launch set).  Parity: decoded planes == originals."""
+    import threading
+    import time
+    import torch
+    import torch.distributed as dist
+    from libmodjpeg_amd import entropy as E
+    from libmodjpeg_amd.batch import ComposeBatch
+
+    images = args.images or 256
+    b = ComposeBatch(images, 1920, 1080, 256, 256, 52, 26, REGIMES[args.regime], image0=shard_image0(rank, images))
+    b.fill_synthetic()
+    b.build_plan().run()
+    torch.cuda.synchronize()
+    g = b.geo
+    scratch = [[torch.empty_like(b.coef[c][0]) for c in range(3)] for _ in range(args.threads)]
+    nbytes = [0] * args.threads
+
+    def step():
+        def work(tid):
+            total = 0
+            for i in range(tid, images, args.threads):
+                planes = [b.coef[c][i] for c in range(3)]
+                data = E.encode_scan(planes, g.true_dims, g.samp, g.mcus_x, g.mcus_y)
+                E.decode_scan(data + E.EOI, scratch[tid], g.samp, g.mcus_x, g.mcus_y)
+                total += len(data)
+            nbytes[tid] = total
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(args.threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    step()  # warm-up: arenas, first launches
+    ok = True
+    for tid in range(min(args.threads, images)):  # what each thread decoded last
+        i = tid + ((images - 1 - tid) // args.threads) * args.threads
+        for c in range(3):
+            w, h = g.true_dims[c]
+            ok = ok and bool(torch.equal(scratch[tid][c][:h, :w], b.coef[c][i][:h, :w]))
+    steps = max(1, min(args.steps, 10))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tot = sum_over_ranks(images, world, "cuda")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/s baseline Huffman encode + decode, 1080p 4:2:0, planes resident on the device", "value": tot * steps / elapsed, "unit": "images/s",
+            "n_gpus": world, "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "s16 JCOEF <-> Huffman bitstream", "data": "synthetic",
+            "config": {"workload": "entropy_1080p_batch", "images_per_gpu": images, "threads": args.threads, "scan_bytes_per_image": sum(nbytes) // images},
+            "parity": "decoded == original" if ok else "MISMATCH",
+            "roofline": None, "note": "latency-bound chains of small kernels (DESIGN.md 7): no HBM or MFMA roofline applies", "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 
