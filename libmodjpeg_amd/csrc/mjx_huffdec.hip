@@ -18,7 +18,7 @@
 //                      difference it read)
 //   4. DC pass         per component, prefix sum of the differences inside every restart segment
 // The walk is a latency chain (window -> table -> shift), so it is kept to one LDS look-up and a
-// handful of ALU operations per symbol: a 64-bit bit window in registers, table entries that carry
+// handful of ALU operations per symbol: a two-word bit window in registers, table entries that carry
 // the code length, the total bits to skip and the zigzag advance, a second-level table for codes
 // longer than the first-level index, no data-dependent branch except the end of a block.
 // Anything that is not a clean baseline stream (bad code, run past the block, wrong block count)
