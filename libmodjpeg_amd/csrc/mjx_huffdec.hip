@@ -785,7 +785,9 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
         // costs a launch that returns at once, a missing one a second pass over everything.
         const double bits_per_block = (double)rawlen * 8.0 / (double)S.nslots;
         const double est = S.period >= 5 ? 11.0 + pow(bits_per_block / 58.0, 2.4) : (S.period >= 2 ? 8.0 + pow(bits_per_block / 55.0, 2.4) : 6.5 + bits_per_block / 20.0);
-        req.first_rounds = est > 72.0 ? 72 : (int)est;
+        double seg = est; // a restart segment starts in a known state and settles in about as many rounds as it has chunks
+        if(S.ri > 0) seg = bits_per_block * (double)S.bpm * (double)S.ri / (double)kChunkBits + 3.0;
+        req.first_rounds = (seg < est ? seg : est) > 72.0 ? 72 : (int)(seg < est ? seg : est);
     }
     req.o_batch = o_batch;
     req.pin_batch = pin_batch;

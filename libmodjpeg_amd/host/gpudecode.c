@@ -94,7 +94,11 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
         const double  nbytes = (double)d->src->bytes_in_buffer;
         const double  bits_per_block = nbytes * 8.0 / ((double)nmcu * blocks_in_mcu);
         const int     period_like = d->num_components == 1 ? 1 : blocks_in_mcu;
-        const double  rounds = period_like >= 5 ? 11.0 + pow(bits_per_block / 58.0, 2.4) : (period_like >= 2 ? 8.0 + pow(bits_per_block / 55.0, 2.4) : 6.5 + bits_per_block / 20.0);
+        double        rounds = period_like >= 5 ? 11.0 + pow(bits_per_block / 58.0, 2.4) : (period_like >= 2 ? 8.0 + pow(bits_per_block / 55.0, 2.4) : 6.5 + bits_per_block / 20.0);
+        if(d->restart_interval > 0) { /* every restart segment starts in a known state: a segment settles in about as many rounds as it has chunks */
+            const double seg_rounds = bits_per_block * blocks_in_mcu * (double)d->restart_interval / 1024.0 + 3.0;
+            if(seg_rounds < rounds) rounds = seg_rounds;
+        }
         const double  gpu_ms = 0.35 + 0.055 * rounds + nbytes * 0.6e-6, cpu_ms = nbytes * 1.0e-5;
         if(min_bytes == -2) min_bytes = getenv("MJ_GPU_DECODE_MIN_BYTES") != NULL ? atol(getenv("MJ_GPU_DECODE_MIN_BYTES")) : -1;
         if(min_bytes >= 0 ? nbytes < (double)min_bytes : gpu_ms >= cpu_ms) BAIL(MJH_DECODE_UNSUPPORTED, "libjpeg is faster for this one");

@@ -277,6 +277,10 @@ int mjh_pixels_to_jpeg(unsigned char **outbuf, size_t *outlen, unsigned char *pi
         enc.comp_info[c].v_samp_factor = s->samp_factor[c].v_samp_factor;
     }
     jpeg_set_quality(&enc, 100, TRUE); /* quant tables of all ones: coefficient == dequantised value */
+    /* this JPEG only exists to be read back as coefficients (dropon.c:376/:415 does the same): a
+     * restart marker after every MCU changes no coefficient and lets the GPU decoder start every MCU
+     * in a known state, so a quality-100 stream (54 synchronisation rounds otherwise) settles in three */
+    enc.restart_interval = 1;
 
     jpeg_start_compress(&enc, TRUE);
     {
