@@ -121,6 +121,22 @@ def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0, timing=True):
 
 # ---- the multi-rank protocol (backend-agnostic: RCCL on the GPU box, gloo in the CPU tests) ----
 
+def init_rccl(dist, torch, local_rank):
+    """init_process_group + a first barrier with file descriptor 1 pointed at stderr: RCCL prints a
+    version banner on stdout when the communicator is created, and stdout is for the ONE JSON line"""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+        torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def rank_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -187,7 +203,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        init_rccl(dist, torch, local_rank)
 
     if args.workload == "effects_4k_batch":
         return bench_effects(args, rank, world)
