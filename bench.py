@@ -5,17 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of mj_compose_with_mask (reference compose.c:237) over one device-resident
-batch of synthetic images: by default BASELINE.json configs[2], 4096 x 1920x1080 4:2:0 JPEGs, one
-256x256 masked dropon each (1536 blocks per image, per-image tiles), smooth alpha regime A2
+batch of synthetic images: by default BASELINE.json configs[2]/[3], 4096 x 1920x1080 4:2:0 JPEGs,
+one 256x256 masked dropon each (1536 blocks per image, per-image tiles), smooth alpha regime A2
 (10 non-zero alpha-DCT coefficients per block).  Inputs are in HBM before the timed region.
 
-Multi-GPU: images are independent, so rank r owns its own 4096 images (global indices
-r*4096 ...), no data-path collective -> "scaling": "weak".  torch.distributed is
-used only for the barrier and the MAX/SUM of the timing scalars.
+Multi-GPU (BASELINE configs[3]): the block loop has no cross-block state (reference
+compose.c:256-338), so the ONE batch is cut by image index: rank r of N owns the images
+shard_range(4096, r, N) (512 per GPU at N = 8) -> "scaling": "strong".  `--scaling weak` keeps the
+workload's image count PER rank instead.  There is no data-path collective and no RCCL: the ranks
+only meet at the two barriers of the timed region and to reduce a few scalars, over gloo (TCP on
+127.0.0.1).  Started without torchrun, `--gpus N` (N > 1) spawns the N ranks itself.
 
 Also printed on the same JSON line:
   roofline      algorithmic bytes (768 B per composed block) / mean kernel duration from HIP events
-                recorded on the launch stream inside the timed region, against the 8 TB/s HBM peak
+                recorded on the launch stream inside the timed region, against the 8 TB/s HBM peak;
+                `kernel_ms_pristine` = the same kernel on planes restored from a pristine copy
+                before every launch (untimed restore; compose is in place and not idempotent)
+  per_rank      kernel ms, blocks and the parity verdict of every rank
   cpu_baseline  the CPU oracle (oracle/mjx_oracle.c, the restatement proven bit-identical to the
                 compiled reference) on a bounded sample of the same workload on this box's cores;
                 rank 0, N == 1 only.  The same sample is used to bit-compare the GPU output.
@@ -23,6 +29,7 @@ Also printed on the same JSON line:
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,29 +41,143 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 BYTES_PER_BLOCK = 768  # 128 JCOEF read + 256 tile + 256 alpha + 128 JCOEF write
 
 WORKLOADS = {
-    # name: (width, height, dropon_w, dropon_h, mcu_x, mcu_y, default images per GPU)
+    # name: (width, height, dropon_w, dropon_h, mcu_x, mcu_y, images of the whole job)
     "compose_1080p_batch": (1920, 1080, 256, 256, 52, 26, 4096),  # BASELINE configs[2]/[3]
     "compose_4k_fullframe": (3840, 2160, 3840, 2160, 0, 0, 1),    # BASELINE configs[1]
 }
-REGIMES = {"A1": 1, "A2": 2, "A3": 3}
+REGIMES = {"A1": 1, "A2": 2, "A3": 3, "A4": 4}
+METRIC_1080P = "8×8 DCT blocks/s masked-compose, 1080p batch; achieved HBM GB/s vs roofline"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default): the workload's images are cut over the ranks (configs[3]: the same 4096 images, 512 per GPU "
+                         "at N = 8); weak: every rank gets the workload's image count")
     ap.add_argument("--spinup-ms", type=float, default=400.0,
                     help="untimed steps run for this long before the W warm-up steps: the MI355X clock governor needs "
                          "~25 ms of sustained load to leave its idle state (per-step time falls from 1.29 to 0.92 ms)")
     ap.add_argument("--workload", default="compose_1080p_batch", choices=list(WORKLOADS) + ["effects_4k_batch", "entropy_1080p_batch"])
     ap.add_argument("--threads", type=int, default=16, help="entropy_1080p_batch: host threads calling the coders concurrently")
     ap.add_argument("--regime", default="A2", choices=list(REGIMES))
-    ap.add_argument("--images", type=int, default=0, help="images per GPU (default: the workload's)")
+    ap.add_argument("--images", type=int, default=0, help="images of the whole job (strong) / per GPU (weak); default: the workload's")
     ap.add_argument("--cpu-sample", type=int, default=256, help="images in the CPU baseline / parity sample (0 = skip)")
+    ap.add_argument("--pristine-launches", type=int, default=10, help="extra launches from restored planes for roofline.kernel_ms_pristine (0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ---- ranks: process per GPU; gloo carries the barriers and the scalar reductions ---------------
+
+def rank_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_ranks(world):
+    """gloo process group over 127.0.0.1 (env:// rendezvous of torchrun or of spawn_ranks).  The
+    data path needs no communicator, so none is created on the GPUs."""
+    if world == 1:
+        return
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+
+
+def shard_of(total, rank, world, scaling):
+    """(first global image index, image count) of `rank`.  strong: image i -> rank floor(i*world/total)
+    (contiguous shards); weak: `total` images per rank."""
+    from libmodjpeg_amd.batch import shard_range
+    if scaling == "weak":
+        return rank * total, total
+    lo, hi = shard_range(total, rank, world)
+    return lo, hi - lo
+
+
+def shard_image0(rank, images_per_gpu):
+    """weak scaling: rank r owns the images [r*images_per_gpu, (r+1)*images_per_gpu)"""
+    return rank * images_per_gpu
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def reduce_scalar(value, world, op):
+    """MAX / SUM of one host scalar over the ranks (CPU tensor over gloo)"""
+    if world == 1:
+        return value
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def sum_over_ranks(value, world, device=None):
+    return int(round(reduce_scalar(value, world, "sum")))
+
+
+def gather_objects(obj, world):
+    if world == 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def timed_steps(step, sync, steps, world, device=None, make_event=None):
+    """Exactly `steps` calls of `step()` bracketed by barrier + sync on both sides.  The clock runs
+    from after the opening barrier + sync to after the closing sync; the closing barrier follows.
+    Returns (elapsed seconds = MAX over ranks, per-step event pairs or None)."""
+    ev = [(make_event(), make_event()) for _ in range(steps)] if make_event else None
+    barrier(world)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        if ev:
+            ev[k][0].record()  # on the current stream == the stream the kernels are launched on
+        step()
+        if ev:
+            ev[k][1].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    barrier(world)
+    return reduce_scalar(elapsed, world, "max"), ev
+
+
+def spin_up(step, sync, spinup_ms):
+    """untimed: keep the device busy until its clocks have ramped (DVFS), in bursts of 8 steps"""
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < spinup_ms:
+        for _ in range(8):
+            step()
+        sync()
+
+
+def spawn_ranks(args_list, world):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this
+    process has not touched the GPU) and return rank 0's exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args_list, env=env))
+    codes = [p.wait() for p in procs]
+    return next((c for c in codes if c != 0), 0)
+
+
+# ---- CPU oracle legs ----------------------------------------------------------------------------
 
 def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0, timing=True):
     """Oracle compose on `nsample` images of the workload (only the dropon rectangles are
@@ -119,213 +240,253 @@ def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0, timing=True):
     return info, expected
 
 
-# ---- the multi-rank protocol (backend-agnostic: RCCL on the GPU box, gloo in the CPU tests) ----
-
-def init_rccl(dist, torch, local_rank):
-    """init_process_group + a first barrier with file descriptor 1 pointed at stderr: RCCL prints a
-    version banner on stdout when the communicator is created, and stdout is for the ONE JSON line"""
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
+def traffic_from_profiles(path, key):
+    """HBM bytes per launch from the rocprofv3 --pmc passes committed under profiles/ (FETCH_SIZE
+    doubled + WRITE_SIZE, as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be
+    collected from inside the process being timed, so this is the figure of the profiled run of the
+    same command, labelled with its source; None when there is no such pass."""
     try:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()
-        torch.cuda.synchronize()
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved, 1)
-        os.close(saved)
+        tj = json.load(open(path))
+        if key in tj:
+            return tj[key]["hbm_bytes_per_launch"], tj[key].get("source", os.path.relpath(path, ROOT))
+    except Exception:
+        pass
+    return None, None
 
 
-def rank_env():
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
-
-
-def shard_image0(rank, images_per_gpu):
-    """weak scaling: rank r owns the images [r*images_per_gpu, (r+1)*images_per_gpu); nothing is
-    exchanged between ranks"""
-    return rank * images_per_gpu
-
-
-def timed_steps(step, sync, steps, world, device, make_event=None):
-    """Exactly `steps` calls of `step()` bracketed by barrier + sync on both sides.  Returns
-    (elapsed seconds = MAX over ranks, per-step event pairs or None)."""
-    import torch
-    import torch.distributed as dist
-    ev = [(make_event(), make_event()) for _ in range(steps)] if make_event else None
-    if world > 1:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        if ev:
-            ev[k][0].record()  # on the current stream == the stream the kernels are launched on
-        step()
-        if ev:
-            ev[k][1].record()
-    sync()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed, ev
-
-
-def spin_up(step, sync, spinup_ms):
-    """untimed: keep the device busy until its clocks have ramped (DVFS), in bursts of 8 steps"""
-    t0 = time.perf_counter()
-    while (time.perf_counter() - t0) * 1e3 < spinup_ms:
-        for _ in range(8):
-            step()
-        sync()
-
-
-def sum_over_ranks(value, world, device):
-    import torch
-    import torch.distributed as dist
-    if world == 1:
-        return value
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return int(t.item())
-
+# ---- masked compose -------------------------------------------------------------------------------
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
     rank, world, local_rank = rank_env()
+    if world == 1 and args.gpus > 1:
+        sys.exit(spawn_ranks(sys.argv[1:], args.gpus))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        init_rccl(dist, torch, local_rank)
 
-    if args.workload == "effects_4k_batch":
-        return bench_effects(args, rank, world)
-    if args.workload == "entropy_1080p_batch":
-        return bench_entropy(args, rank, world)
+    import torch
+    # MJX_BENCH_DEVICES="0,0": rehearsal of the N-rank protocol on a box with fewer GPUs than ranks
+    devmap = [int(d) for d in os.environ.get("MJX_BENCH_DEVICES", "").split(",") if d != ""]
+    torch.cuda.set_device(devmap[local_rank] if devmap else local_rank)
+    init_ranks(world)
+    try:
+        if args.workload == "effects_4k_batch":
+            bench_effects(args, rank, world)
+        elif args.workload == "entropy_1080p_batch":
+            bench_entropy(args, rank, world)
+        else:
+            bench_compose(args, rank, world)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
 
+
+def bench_compose(args, rank, world):
+    import numpy as np
+    import torch
     from libmodjpeg_amd.batch import ComposeBatch
 
     width, height, dw, dh, mcu_x, mcu_y, default_images = WORKLOADS[args.workload]
-    images = args.images or default_images
+    total_images = args.images or default_images
     regime = REGIMES[args.regime]
-    image0 = shard_image0(rank, images)
+    image0, images = shard_of(total_images, rank, world, args.scaling)
+    assert images > 0, f"rank {rank}: empty shard ({total_images} images over {world} ranks)"
     batch = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, regime, image0=image0)
     batch.fill_synthetic()
     batch.build_plan()
     blocks_per_step = batch.total_blocks()
+    sync = torch.cuda.synchronize
 
     # ---- parity (+ CPU baseline) on a bounded sample: first pass from pristine inputs ----
     # N == 1: rank 0 times the CPU baseline on `--cpu-sample` images and checks them; N > 1: every
-    # rank checks a few images of its own shard (no CPU timing), the verdict is reduced over ranks
-    cpu_info, parity = None, "skipped"
-    if world == 1:
-        nsample = min(args.cpu_sample, images)
-    else:
-        nsample = min(args.cpu_sample, images, 4)
+    # rank checks a few images of its own shard (no CPU timing); every rank's verdict is reported
+    cpu_info, parity, bad, nsample = None, "skipped", 0, 0
+    if args.cpu_sample > 0:
+        nsample = min(args.cpu_sample, images) if world == 1 else min(args.cpu_sample, images, 4)
+    pristine = batch.rect_clone() if args.pristine_launches > 0 else None
     expected = None
     if nsample > 0:
+        # the sample: the first images of this rank's shard
         info, expected = cpu_baseline_and_expected((width, height, dw, dh, mcu_x, mcu_y), regime, nsample, image0, timing=(world == 1))
         cpu_info = info if world == 1 else None
     batch.run()
-    torch.cuda.synchronize()
+    sync()
     if expected is not None:
-        import numpy as np
-        bad = 0
         for i in range(nsample):
             for c in range(3):
                 if not np.array_equal(batch.rect_numpy(i, c).reshape(-1), expected[3 * i + c]):
                     bad += 1
-        bad_all = sum_over_ranks(bad, world, "cuda")
-        checked = sum_over_ranks(3 * nsample, world, "cuda")
-        parity = "bit-exact" if bad_all == 0 else f"MISMATCH in {bad_all} of {checked} rectangles"
-        if bad_all:
-            print(f"bench.py: GPU output differs from the oracle: {parity}", file=sys.stderr)
-            sys.exit(1)
+        parity = "bit-exact" if bad == 0 else f"MISMATCH in {bad} of {3 * nsample} rectangles"
+    bad_all = sum_over_ranks(bad, world)
+    if bad_all:
+        print(f"bench.py: rank {rank}: GPU output differs from the oracle: {parity}", file=sys.stderr)
+        sys.exit(1)
 
     # ---- clock spin-up (untimed, see --spinup-ms), then the W warm-up steps ----
-    spin_up(batch.run, torch.cuda.synchronize, args.spinup_ms)
+    spin_up(batch.run, sync, args.spinup_ms)
     for _ in range(args.warmup):
         batch.run()
-    torch.cuda.synchronize()
+    sync()
 
     # ---- timed region: exactly K steps ----
-    elapsed, ev = timed_steps(batch.run, torch.cuda.synchronize, args.steps, world, "cuda", lambda: torch.cuda.Event(enable_timing=True))
+    elapsed, ev = timed_steps(batch.run, sync, args.steps, world, make_event=lambda: torch.cuda.Event(enable_timing=True))
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     mean_kern_ms = sum(kern_ms) / len(kern_ms)
-    tot_blocks = sum_over_ranks(blocks_per_step, world, "cuda")
+    tot_blocks = sum_over_ranks(blocks_per_step, world)
+
+    # ---- the same launch on planes restored from the pristine copy before every launch (outside
+    # the contract's timed region; the restore is not between the events) ----
+    pristine_ms = None
+    if pristine is not None:
+        ms = []
+        for _ in range(args.pristine_launches):
+            batch.rect_restore(pristine)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            batch.run()
+            b.record()
+            sync()
+            ms.append(a.elapsed_time(b))
+        pristine_ms = sum(ms) / len(ms)
+
+    mine = {"rank": rank, "image0": image0, "images": images, "blocks_per_step": blocks_per_step, "kernel_ms_mean": mean_kern_ms,
+            "kernel_ms_min": min(kern_ms), "kernel_ms_pristine": pristine_ms, "parity": parity, "parity_sample_images": nsample,
+            "device": torch.cuda.get_device_name()}
+    per_rank = gather_objects(mine, world)
 
     if rank == 0:
         achieved = blocks_per_step * BYTES_PER_BLOCK / (mean_kern_ms * 1e-3) / 1e9
-        traffic = None
-        try:
-            tj = json.load(open(args.traffic_json))
-            key = f"{args.workload}:{args.regime}:{images}"
-            if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
+        traffic, traffic_src = traffic_from_profiles(args.traffic_json, f"{args.workload}:{args.regime}:{images}")
+        verdicts = {r["parity"] for r in per_rank}
         out = {
             # BASELINE.json's metric string, verbatim, for the workload it is quoted on
-            "metric": "8\u00d78 DCT blocks/s masked-compose, 1080p batch; achieved HBM GB/s vs roofline" if args.workload == "compose_1080p_batch" else "8\u00d78 DCT blocks/s masked-compose",
+            "metric": METRIC_1080P if args.workload == "compose_1080p_batch" else "8×8 DCT blocks/s masked-compose",
             "value": tot_blocks * args.steps / elapsed, "unit": "blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "s16 JCOEF, f32/f64 blend (reference typing)", "data": "synthetic",
-            "config": {"workload": args.workload, "images_per_gpu": images, "image": f"{width}x{height} 4:2:0",
+            "config": {"workload": args.workload, "images_total": tot_blocks // batch.blocks_per_image, "images_per_gpu": images, "image": f"{width}x{height} 4:2:0",
                        "dropon": f"{dw}x{dh} alpha-masked, per-image tiles, MCU ({mcu_x},{mcu_y})",
-                       "alpha_regime": args.regime, "blocks_per_step_per_gpu": blocks_per_step, "spinup_ms": args.spinup_ms, "parallelism": f"images sharded x{world}, no collective"},
-            "parity": parity,
+                       "alpha_regime": args.regime, "blocks_per_step_total": tot_blocks, "blocks_per_step_per_gpu": blocks_per_step, "spinup_ms": args.spinup_ms,
+                       "parallelism": f"images sharded x{world} ({args.scaling}), no collective, no RCCL"},
+            "parity": verdicts.pop() if len(verdicts) == 1 else "mixed: see per_rank",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "mjx::compose_kernel", "kernel_ms_mean": mean_kern_ms, "kernel_ms_min": min(kern_ms),
-                         "algorithmic_bytes_per_launch": blocks_per_step * BYTES_PER_BLOCK},
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mjx::compose_kernel", "kernel_ms_mean": mean_kern_ms,
+                         "kernel_ms_min": min(kern_ms), "kernel_ms_pristine": pristine_ms,
+                         "algorithmic_bytes_per_launch": blocks_per_step * BYTES_PER_BLOCK, "rank": 0},
+            "per_rank": per_rank,
             "cpu_baseline": cpu_info,
         }
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+
+
+# ---- DC effects (BASELINE configs[4]) ---------------------------------------------------------
+
+def effects_cpu_baseline_and_expected(geo, quant, image0, nsample, lum, cb, cr, timing):
+    """oracle orc_effect_dc (reference effect.c:185-222, :116-183) on `nsample` whole 4K images of
+    the same synthetic batch.  Returns (info, expected DC planes per (image, component))."""
+    import numpy as np
+    from tests import oracle_lib as O
+    planes = []
+    for i in range(nsample):
+        for c in range(3):
+            bpr, prow = geo.array_dims[c]
+            planes.append(O.synth_coef(image0 + i, c, 0, bpr * prow, quant[c]))
+
+    def run():
+        k = 0
+        for i in range(nsample):
+            for c, value in enumerate((lum, cb, cr)):
+                bpr, _ = geo.array_dims[c]
+                tw, th = geo.true_dims[c]
+                if not (c > 0 and value == 0):  # effect.c:134/:158
+                    O.effect_dc(planes[k], bpr, th, tw, int(quant[c][0]), value)
+                k += 1
+
+    t0 = time.perf_counter()
+    run()
+    t_first = time.perf_counter() - t0
+    expected = [p.copy() for p in planes]
+    if not timing:
+        return None, expected
+    reps, t_rep = 1, t_first
+    while t_rep < 2.0 and reps < 50:  # again in place: the work is data-independent
+        t0 = time.perf_counter()
+        run()
+        t_rep += time.perf_counter() - t0
+        reps += 1
+    dcs = nsample * sum(w * h for w, h in geo.true_dims)
+    info = {"value": dcs * reps / t_rep, "unit": "blocks/s", "cores": 1, "kind": "port",
+            "sample": f"{nsample} images x {dcs // nsample} DC blocks (3840x2160 4:2:0), oracle/mjx_oracle.c orc_effect_dc, 1 thread "
+                      f"(the reference is single-threaded), {reps} repeats"}
+    return info, expected
 
 
 def bench_effects(args, rank, world):
-    """BASELINE configs[4]: mj_effect_luminance(+7) then mj_effect_tint(+5, -3) over 4K 4:2:0
-    images (two launches, as the reference makes two calls)."""
+    """BASELINE configs[4]: mj_effect_luminance(+7) then mj_effect_tint(+5, -3) over 4096 4K 4:2:0
+    images (two launches, as the reference makes two calls), 1 -> 8 GPUs by image index."""
+    import numpy as np
     import torch
-    import torch.distributed as dist
     from libmodjpeg_amd.batch import EffectBatch
 
-    images = args.images or 1024
-    eb = EffectBatch(images, 3840, 2160, image0=shard_image0(rank, images))
+    total_images = args.images or 4096
+    image0, images = shard_of(total_images, rank, world, args.scaling)
+    lum, cb, cr = 7, 5, -3
+    eb = EffectBatch(images, 3840, 2160, image0=image0)
     eb.fill_synthetic()
-    eb.build_plans(7, 5, -3, fused=False)
+    eb.build_plans(lum, cb, cr, fused=False)
     dcs = eb.dc_blocks_per_image() * images
-    spin_up(eb.run, torch.cuda.synchronize, args.spinup_ms)
+    sync = torch.cuda.synchronize
+
+    # parity (+ CPU baseline at N == 1) on sampled images, first pass from pristine inputs
+    nsample = 0 if args.cpu_sample <= 0 else min(images, 2)
+    cpu_info, parity, bad = None, "skipped", 0
+    expected = None
+    if nsample:
+        cpu_info, expected = effects_cpu_baseline_and_expected(eb.geo, eb.quant, image0, nsample, lum, cb, cr, timing=(world == 1))
+    eb.run()
+    sync()
+    if expected is not None:
+        for i in range(nsample):
+            for c in range(3):
+                if not np.array_equal(eb.coef[c][i].cpu().numpy().reshape(-1), expected[3 * i + c]):
+                    bad += 1
+        parity = "bit-exact" if bad == 0 else f"MISMATCH in {bad} of {3 * nsample} planes"
+    if sum_over_ranks(bad, world):
+        print(f"bench.py: rank {rank}: GPU effects differ from the oracle: {parity}", file=sys.stderr)
+        sys.exit(1)
+
+    spin_up(eb.run, sync, args.spinup_ms)
     for _ in range(max(args.warmup, 1)):
         eb.run()
-    torch.cuda.synchronize()
-    elapsed, ev = timed_steps(eb.run, torch.cuda.synchronize, args.steps, world, "cuda", lambda: torch.cuda.Event(enable_timing=True))
+    sync()
+    elapsed, ev = timed_steps(eb.run, sync, args.steps, world, make_event=lambda: torch.cuda.Event(enable_timing=True))
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     mean_ms = sum(kern_ms) / len(kern_ms)
-    tot = sum_over_ranks(dcs, world, "cuda")
+    tot = sum_over_ranks(dcs, world)
+    per_rank = gather_objects({"rank": rank, "image0": image0, "images": images, "dc_blocks_per_step": dcs, "kernel_ms_mean": mean_ms, "parity": parity}, world)
     if rank == 0:
-        achieved = dcs * 4 / (mean_ms * 1e-3) / 1e9
+        achieved = dcs * 4 / (mean_ms * 1e-3) / 1e9          # SURVEY 8d: 2 B read + 2 B written per DC
+        line_gbs = dcs * 256 / (mean_ms * 1e-3) / 1e9        # what the memory system moves: one 128-byte line in, one out
+        traffic, traffic_src = traffic_from_profiles(args.traffic_json, f"effects_4k_batch:{images}")
+        verdicts = {r["parity"] for r in per_rank}
         print(json.dumps({
             "metric": "DC blocks/s mj_effect_luminance+mj_effect_tint, 4K batch", "value": tot * args.steps / elapsed, "unit": "blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "s16", "data": "synthetic",
-            "config": {"workload": "effects_4k_batch", "images_per_gpu": images, "image": "3840x2160 4:2:0", "calls": "luminance(+7); tint(+5,-3)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "mjx::effect_dc_kernel", "kernel_ms_mean": mean_ms,
-                         "note": "algorithmic 4 B per DC; the stream is sector-bound (one 2-byte field per 128-byte block)"},
-            "cpu_baseline": None}))
-    if world > 1:
-        dist.destroy_process_group()
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "s16", "data": "synthetic",
+            "config": {"workload": "effects_4k_batch", "images_total": total_images if args.scaling == "strong" else total_images * world, "images_per_gpu": images,
+                       "image": "3840x2160 4:2:0", "calls": "luminance(+7); tint(+5,-3)", "parallelism": f"images sharded x{world} ({args.scaling}), no collective, no RCCL"},
+            "parity": verdicts.pop() if len(verdicts) == 1 else "mixed: see per_rank",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mjx::effect_dc_kernel (two launches per step)", "kernel_ms_mean": mean_ms,
+                         "algorithmic_bytes_per_launch": dcs * 4,
+                         "line_granular": {"achieved": line_gbs, "frac": line_gbs / HBM_PEAK_GBS, "bytes_per_dc": 256,
+                                           "note": "the 2-byte DC is the only field used of each 128-byte block: a line is read and written back per DC"}},
+            "per_rank": per_rank,
+            "cpu_baseline": cpu_info}))
+        sys.stdout.flush()
 
 
 def bench_entropy(args, rank, world):
@@ -334,9 +495,7 @@ def bench_entropy(args, rank, world):
     decoded back into scratch planes, by `--threads` host threads calling the C ABI concurrently (the
     library combines concurrent callers into one launch set).  Parity: decoded planes == originals."""
     import threading
-    import time
     import torch
-    import torch.distributed as dist
     from libmodjpeg_amd import entropy as E
     from libmodjpeg_amd.batch import ComposeBatch
 
@@ -372,19 +531,8 @@ def bench_entropy(args, rank, world):
             w, h = g.true_dims[c]
             ok = ok and bool(torch.equal(scratch[tid][c][:h, :w], b.coef[c][i][:h, :w]))
     steps = max(1, min(args.steps, 10))
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    tot = sum_over_ranks(images, world, "cuda")
+    elapsed, _ = timed_steps(step, torch.cuda.synchronize, steps, world)
+    tot = sum_over_ranks(images, world)
     if rank == 0:
         print(json.dumps({
             "metric": "images/s baseline Huffman encode + decode, 1080p 4:2:0, planes resident on the device", "value": tot * steps / elapsed, "unit": "images/s",
@@ -393,8 +541,6 @@ def bench_entropy(args, rank, world):
             "config": {"workload": "entropy_1080p_batch", "images_per_gpu": images, "threads": args.threads, "scan_bytes_per_image": sum(nbytes) // images},
             "parity": "decoded == original" if ok else "MISMATCH",
             "roofline": None, "note": "latency-bound chains of small kernels (DESIGN.md 7): no HBM or MFMA roofline applies", "cpu_baseline": None}))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

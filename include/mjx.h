@@ -261,7 +261,18 @@ typedef struct mjx_huff_dscan {
  * outside the tables.  The caller then uses its ordinary decoder, which owns those semantics. */
 int mjx_huff_decode_host(const mjx_huff_dscan_t *scan);
 
-/* ---- synthetic workload generators (bench / test support; definition: mjx_synth.h) ------ */
+/* ---- synthetic workload generators (bench / test support; definition: mjx_synth.h) ------
+ * The *_batch forms fill one array of a whole batch with ONE launch: image i of the batch (global
+ * index image0 + i) starts image_stride_blocks * 64 elements after image i-1.  regime: MJX_ALPHA_*
+ * of mjx_synth.h (1 uniform, 2 smooth, 3 dense, 4 mixed).  mjx_synth_coef* return after the
+ * generator has finished; the float generators are asynchronous on `stream`. */
+int mjx_synth_coef_batch(int16_t *dst /* DEVICE */, size_t image_stride_blocks, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first_block,
+                         size_t nblocks, const uint16_t *q /* HOST[64] */, mjx_stream_t stream);
+int mjx_synth_tile_batch(float *dst, size_t image_stride_blocks, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first_block, size_t nblocks,
+                         mjx_stream_t stream);
+int mjx_synth_alpha_batch(float *dst, size_t image_stride_blocks, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first_block, size_t nblocks,
+                          int regime, mjx_stream_t stream);
+/* one image */
 int mjx_synth_coef(int16_t *dst /* DEVICE */, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks,
                    const uint16_t *q /* HOST[64] */, mjx_stream_t stream);
 int mjx_synth_tile(float *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, mjx_stream_t stream);

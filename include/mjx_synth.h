@@ -23,6 +23,14 @@
  *                A1 uniform : only w[0][0], a00 = 2040 (opaque)               -> 1 nnz / block
  *                A2 smooth  : a(k,l) != 0 only for k+l <= 3 (headline)        -> 10 nnz / block
  *                A3 dense   : all 64 non-zero                                 -> 64 nnz / block
+ *                A4 mixed   : the pattern differs from block to block, as under a real mask (a
+ *                             hard-edged shape with a soft rim, SURVEY.md 6 probe table: 7.1 nnz
+ *                             bimodal / 12.4 soft radial).  A per-block hash picks the class:
+ *                             6/64 edge blocks (dense, 64 nnz), 10/64 rim blocks (smooth, 10 nnz),
+ *                             8/64 outside the shape (alpha 0 => DC -1024+1024 = 0: 0 nnz),
+ *                             40/64 inside it (opaque, 1 nnz)                    -> 8.2 nnz / block
+ *                             on average.  Consecutive blocks land in different classes, which
+ *                             is what defeats a per-wavefront "no block needs this term" skip.
  */
 #ifndef MJX_SYNTH_H_
 #define MJX_SYNTH_H_
@@ -42,6 +50,7 @@
 #define MJX_ALPHA_UNIFORM 1 /* A1 */
 #define MJX_ALPHA_SMOOTH  2 /* A2 */
 #define MJX_ALPHA_DENSE   3 /* A3 */
+#define MJX_ALPHA_MIXED   4 /* A4 */
 
 /* n-th output (n = idx) of the splitmix64 stream seeded with `seed`. */
 MJX_HD uint64_t mjx_hash64(uint64_t seed, uint64_t idx) {
@@ -117,10 +126,22 @@ MJX_HD float mjx_alpha_scale(int a, int j) {
     return (float)((double)(float)a * K);
 }
 
+/* A4: class of a block: 0 outside the shape, 1 inside (opaque), 2 soft rim, 3 hard edge */
+MJX_HD int mjx_alpha_mixed_class(uint64_t stream, uint64_t block) {
+    unsigned u = (unsigned)(mjx_hash64(stream ^ 0xA4A4A4A4A4A4A4A4ull, block) & 63u);
+    return (u < 6u) ? 3 : ((u < 16u) ? 2 : ((u < 24u) ? 0 : 1));
+}
+
 /* integer alpha-DCT coefficient (DC already +1024) for the given regime */
 MJX_HD int mjx_synth_alpha_int(uint64_t stream, uint64_t block, int j, int regime) {
     uint64_t r = mjx_hash64(stream, block * 64ull + (uint64_t)j);
     int v = j >> 3, u = j & 7;
+    if(regime == MJX_ALPHA_MIXED) {
+        int cls = mjx_alpha_mixed_class(stream, block);
+        if(cls == 0) return 0;
+        if(cls == 1) return (j == 0) ? 2040 : 0;
+        regime = (cls == 2) ? MJX_ALPHA_SMOOTH : MJX_ALPHA_DENSE;
+    }
     if(regime == MJX_ALPHA_UNIFORM) {
         return (j == 0) ? 2040 : 0;
     }

@@ -78,6 +78,9 @@ SYMBOLS = [
     ("mjx_huff_encode_host", _i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
     ("mjx_huff_decode_host", _i, [_vp]),
     ("mjx_huff_optimal_table", _i, [_vp, _vp]),
+    ("mjx_synth_coef_batch", _i, [_vp, _sz, _u64, _u32, _u32, _u64, _sz, _vp, _vp]),
+    ("mjx_synth_tile_batch", _i, [_vp, _sz, _u64, _u32, _u32, _u64, _sz, _vp]),
+    ("mjx_synth_alpha_batch", _i, [_vp, _sz, _u64, _u32, _u32, _u64, _sz, _i, _vp]),
     ("mjx_synth_coef", _i, [_vp, _u64, _u32, _u64, _sz, _vp, _vp]),
     ("mjx_synth_tile", _i, [_vp, _u64, _u32, _u64, _sz, _vp]),
     ("mjx_synth_alpha", _i, [_vp, _u64, _u32, _u64, _sz, _i, _vp]),

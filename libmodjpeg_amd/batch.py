@@ -79,6 +79,7 @@ class ComposeBatch:
 
     # ---- contents -------------------------------------------------------------------------
     def fill_synthetic(self):
+        """one generator launch per array (blockIdx.y = image): 9 launches for the whole batch"""
         L = lib()
         vp = ctypes.c_void_p
         s = vp(torch.cuda.current_stream().cuda_stream)
@@ -86,15 +87,10 @@ class ComposeBatch:
             bpr, prow = self.geo.array_dims[c]
             pblocks = bpr * prow
             tblocks = self.rect[c][2] * self.rect[c][3]
-            q = self.quant[c]
-            qp = q.ctypes.data_as(vp)
-            cbase, cstep = self.coef[c].data_ptr(), pblocks * 128
-            tbase, abase, tstep = self.tile[c].data_ptr(), self.alpha[c].data_ptr(), tblocks * 256
-            for i in range(self.n):
-                g = self.image0 + i
-                check(L.mjx_synth_coef(vp(cbase + i * cstep), g, c, 0, pblocks, qp, s), "mjx_synth_coef")
-                check(L.mjx_synth_tile(vp(tbase + i * tstep), g, c, 0, tblocks, s), "mjx_synth_tile")
-                check(L.mjx_synth_alpha(vp(abase + i * tstep), g, c, 0, tblocks, self.regime, s), "mjx_synth_alpha")
+            qp = self.quant[c].ctypes.data_as(vp)
+            check(L.mjx_synth_coef_batch(vp(self.coef[c].data_ptr()), pblocks, self.image0, self.n, c, 0, pblocks, qp, s), "mjx_synth_coef_batch")
+            check(L.mjx_synth_tile_batch(vp(self.tile[c].data_ptr()), tblocks, self.image0, self.n, c, 0, tblocks, s), "mjx_synth_tile_batch")
+            check(L.mjx_synth_alpha_batch(vp(self.alpha[c].data_ptr()), tblocks, self.image0, self.n, c, 0, tblocks, self.regime, s), "mjx_synth_alpha_batch")
         torch.cuda.current_stream().synchronize()
 
     # ---- launch plan ------------------------------------------------------------------------
@@ -137,6 +133,17 @@ class ComposeBatch:
     def total_blocks(self):
         return self.n * self.blocks_per_image
 
+    def rect_clone(self):
+        """device copy of every dropon rectangle (compose is in place: the pristine blocks)"""
+        out = []
+        for c, (row0, col0, rows, cols) in enumerate(self.rect):
+            out.append(self.coef[c][:, row0:row0 + rows, col0:col0 + cols].clone())
+        return out
+
+    def rect_restore(self, saved):
+        for c, (row0, col0, rows, cols) in enumerate(self.rect):
+            self.coef[c][:, row0:row0 + rows, col0:col0 + cols].copy_(saved[c])
+
 
 class EffectBatch:
     """`n` 4:2:0 images for the DC effects: mj_effect_luminance(value) followed by
@@ -160,9 +167,7 @@ class EffectBatch:
             bpr, prow = self.geo.array_dims[c]
             pblocks = bpr * prow
             qp = self.quant[c].ctypes.data_as(vp)
-            base, step = self.coef[c].data_ptr(), pblocks * 128
-            for i in range(self.n):
-                check(L.mjx_synth_coef(vp(base + i * step), self.image0 + i, c, 0, pblocks, qp, s), "mjx_synth_coef")
+            check(L.mjx_synth_coef_batch(vp(self.coef[c].data_ptr()), pblocks, self.image0, self.n, c, 0, pblocks, qp, s), "mjx_synth_coef_batch")
         torch.cuda.current_stream().synchronize()
 
     def dc_blocks_per_image(self):

@@ -1,16 +1,13 @@
-// mjx_effects.hip — per-block effect kernels and synthetic-workload generators for gfx950.
+// mjx_effects.hip — per-block effect kernels for gfx950.
 //
 //   effect_dc_kernel    mj_effect_luminance / mj_effect_tint   reference src/effect.c:116-222
 //   effect_zero_kernel  mj_effect_grayscale / mj_effect_pixelate reference src/effect.c:28-114
-//   synth_*_kernel      inputs of SURVEY.md §8(d), definition in include/mjx_synth.h
 //
 // The DC effects touch 2 bytes of every 128-byte block: a pure strided HBM stream, one lane per
 // block.  All jobs of a batch (Y, Cb, Cr of every image, luminance and tint fused) go into one
 // launch: blockIdx.y selects the job, blockIdx.x/threadIdx.x the block inside it.
 #include "mjx_block_math.hpp"
 #include "mjx_internal.hpp"
-
-#include "../../include/mjx_synth.h"
 
 namespace mjx {
 
@@ -118,54 +115,6 @@ int launch_effect_zero(int16_t *coef, int bpr, int rows, int cols, int keep_dc, 
     if(threads <= 0) return MJX_OK;
     hipLaunchKernelGGL(effect_zero_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, coef, bpr, rows, cols, keep_dc);
     return check_hip(hipGetLastError(), "effect_zero_kernel launch", MJX_ERR_LAUNCH);
-}
-
-// ---- synthetic inputs: one lane per block row (8 values) ---------------------------------
-
-__global__ __launch_bounds__(256) void synth_coef_kernel(int16_t *__restrict__ dst, uint64_t stream, uint64_t first, size_t nblocks, QTable q) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t blk = t >> 3;
-    const int    r = (int)(t & 7);
-    if(blk >= nblocks) return;
-    int o[8];
-#pragma unroll
-    for(int u = 0; u < 8; ++u) o[u] = mjx_synth_coef(stream, first + blk, r * 8 + u, q.q[r * 8 + u]);
-    *reinterpret_cast<uint4 *>(dst + blk * 64 + r * 8) = make_uint4(((unsigned)o[0] & 0xFFFFu) | ((unsigned)o[1] << 16), ((unsigned)o[2] & 0xFFFFu) | ((unsigned)o[3] << 16),
-                                                                    ((unsigned)o[4] & 0xFFFFu) | ((unsigned)o[5] << 16), ((unsigned)o[6] & 0xFFFFu) | ((unsigned)o[7] << 16));
-}
-
-template <int KIND> __global__ __launch_bounds__(256) void synth_f32_kernel(float *__restrict__ dst, uint64_t stream, uint64_t first, size_t nblocks, int regime) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t blk = t >> 3;
-    const int    r = (int)(t & 7);
-    if(blk >= nblocks) return;
-    float o[8];
-#pragma unroll
-    for(int u = 0; u < 8; ++u) {
-        if(KIND == 0) o[u] = mjx_synth_tile(stream, first + blk, r * 8 + u);
-        else o[u] = mjx_synth_alpha(stream, first + blk, r * 8 + u, regime);
-    }
-    float4 *p = reinterpret_cast<float4 *>(dst + blk * 64 + r * 8);
-    p[0] = make_float4(o[0], o[1], o[2], o[3]);
-    p[1] = make_float4(o[4], o[5], o[6], o[7]);
-}
-
-static unsigned synth_grid(size_t nblocks) { return (unsigned)((nblocks * 8 + 255) / 256); }
-
-int launch_synth_coef(int16_t *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, const QTable &q, hipStream_t s) {
-    if(n == 0) return MJX_OK;
-    hipLaunchKernelGGL(synth_coef_kernel, dim3(synth_grid(n)), dim3(256), 0, s, dst, mjx_stream(MJX_SEED_COEF, image, comp), first, n, q);
-    return check_hip(hipGetLastError(), "synth_coef_kernel launch", MJX_ERR_LAUNCH);
-}
-int launch_synth_tile(float *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, hipStream_t s) {
-    if(n == 0) return MJX_OK;
-    hipLaunchKernelGGL(synth_f32_kernel<0>, dim3(synth_grid(n)), dim3(256), 0, s, dst, mjx_stream(MJX_SEED_TILE, image, comp), first, n, 0);
-    return check_hip(hipGetLastError(), "synth_tile_kernel launch", MJX_ERR_LAUNCH);
-}
-int launch_synth_alpha(float *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, int regime, hipStream_t s) {
-    if(n == 0) return MJX_OK;
-    hipLaunchKernelGGL(synth_f32_kernel<1>, dim3(synth_grid(n)), dim3(256), 0, s, dst, mjx_stream(MJX_SEED_ALPHA, image, comp), first, n, regime);
-    return check_hip(hipGetLastError(), "synth_alpha_kernel launch", MJX_ERR_LAUNCH);
 }
 
 } // namespace mjx

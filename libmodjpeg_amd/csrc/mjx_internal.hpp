@@ -39,10 +39,6 @@ struct DevDcJob {
     float    rq0;
 };
 
-struct QTable {
-    uint16_t q[64];
-};
-
 // host helpers (mjx_runtime.hip)
 int   check_hip(hipError_t e, const char *what, int err_code);
 bool  ensure_device();
@@ -87,8 +83,9 @@ int launch_convolve(const float *x, float *y, float w, int k, int l, int nblocks
 int launch_effect_dc(const DevDcJob *jobs, int njobs, int64_t max_blocks_per_job, hipStream_t s);
 int launch_effect_dc_vector(int16_t *dc, size_t n, int q0, float rq0, int value, hipStream_t s);
 int launch_effect_zero(int16_t *coef, int bpr, int rows, int cols, int keep_dc, hipStream_t s);
-int launch_synth_coef(int16_t *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, const QTable &q, hipStream_t s);
-int launch_synth_tile(float *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, hipStream_t s);
-int launch_synth_alpha(float *dst, uint64_t image, uint32_t comp, uint64_t first, size_t n, int regime, hipStream_t s);
+// mjx_synth.hip: one launch per array of a batch (blockIdx.y = image); image_stride in blocks; d_q = DEVICE u16[64]
+int launch_synth_coef(int16_t *dst, size_t image_stride, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first, size_t n, const uint16_t *d_q,
+                      hipStream_t s);
+int launch_synth_f32(int kind, float *dst, size_t image_stride, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first, size_t n, int regime, hipStream_t s);
 
 } // namespace mjx

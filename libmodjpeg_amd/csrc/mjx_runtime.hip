@@ -791,32 +791,58 @@ int mjx_convolve_host(const float *x, float *y, float w, int k, int l, int nbloc
 }
 
 // ------------------------------------------------------------------------------------------
-// synthetic inputs
+// synthetic inputs: one launch per array of a batch.  The quant table goes to the device through
+// the leased arena (128 bytes); the call returns when the generator has finished, because the
+// arena goes back to the pool with the lease.
 // ------------------------------------------------------------------------------------------
-int mjx_synth_coef(int16_t *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, const uint16_t *q, mjx_stream_t stream) {
+int mjx_synth_coef_batch(int16_t *dst, size_t image_stride_blocks, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first_block, size_t nblocks,
+                         const uint16_t *q, mjx_stream_t stream) {
     if(dst == nullptr || q == nullptr) return MJX_ERR_NULL_DATA;
-    if(!aligned16(dst)) return MJX_ERR_BAD_ARG;
-    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
-    QTable t;
+    if(!aligned16(dst) || (nimages > 1 && image_stride_blocks < nblocks)) return MJX_ERR_BAD_ARG;
     for(int i = 0; i < 64; ++i) {
         if(q[i] == 0) return MJX_ERR_BAD_ARG;
-        t.q[i] = q[i];
     }
-    return launch_synth_coef(dst, image, comp, first_block, nblocks, t, (hipStream_t)stream);
+    if(nimages == 0 || nblocks == 0) return MJX_OK;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    ArenaLease arena;
+    int        err = arena->prepare(256, 256);
+    if(err != MJX_OK) return err;
+    hipStream_t s = (hipStream_t)stream;
+    memcpy(arena->pin, q, 128);
+    err = check_hip(hipMemcpyAsync(arena->dev, arena->pin, 128, hipMemcpyHostToDevice, s), "hipMemcpyAsync(q)", MJX_ERR_LAUNCH);
+    if(err == MJX_OK) err = launch_synth_coef(dst, image_stride_blocks, image0, nimages, comp, first_block, nblocks, reinterpret_cast<const uint16_t *>(arena->dev), s);
+    const int serr = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
+    return err != MJX_OK ? err : serr;
+}
+
+int mjx_synth_tile_batch(float *dst, size_t image_stride_blocks, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first_block, size_t nblocks,
+                         mjx_stream_t stream) {
+    if(dst == nullptr) return MJX_ERR_NULL_DATA;
+    if(!aligned16(dst) || (nimages > 1 && image_stride_blocks < nblocks)) return MJX_ERR_BAD_ARG;
+    if(nimages == 0 || nblocks == 0) return MJX_OK;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    return launch_synth_f32(0, dst, image_stride_blocks, image0, nimages, comp, first_block, nblocks, 0, (hipStream_t)stream);
+}
+
+int mjx_synth_alpha_batch(float *dst, size_t image_stride_blocks, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first_block, size_t nblocks,
+                          int regime, mjx_stream_t stream) {
+    if(dst == nullptr) return MJX_ERR_NULL_DATA;
+    if(!aligned16(dst) || regime < 1 || regime > 4 || (nimages > 1 && image_stride_blocks < nblocks)) return MJX_ERR_BAD_ARG;
+    if(nimages == 0 || nblocks == 0) return MJX_OK;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    return launch_synth_f32(1, dst, image_stride_blocks, image0, nimages, comp, first_block, nblocks, regime, (hipStream_t)stream);
+}
+
+int mjx_synth_coef(int16_t *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, const uint16_t *q, mjx_stream_t stream) {
+    return mjx_synth_coef_batch(dst, nblocks, image, 1, comp, first_block, nblocks, q, stream);
 }
 
 int mjx_synth_tile(float *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, mjx_stream_t stream) {
-    if(dst == nullptr) return MJX_ERR_NULL_DATA;
-    if(!aligned16(dst)) return MJX_ERR_BAD_ARG;
-    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
-    return launch_synth_tile(dst, image, comp, first_block, nblocks, (hipStream_t)stream);
+    return mjx_synth_tile_batch(dst, nblocks, image, 1, comp, first_block, nblocks, stream);
 }
 
 int mjx_synth_alpha(float *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, int regime, mjx_stream_t stream) {
-    if(dst == nullptr) return MJX_ERR_NULL_DATA;
-    if(!aligned16(dst) || regime < 1 || regime > 3) return MJX_ERR_BAD_ARG;
-    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
-    return launch_synth_alpha(dst, image, comp, first_block, nblocks, regime, (hipStream_t)stream);
+    return mjx_synth_alpha_batch(dst, nblocks, image, 1, comp, first_block, nblocks, regime, stream);
 }
 
 } // extern "C"

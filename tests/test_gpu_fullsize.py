@@ -77,8 +77,10 @@ def test_full_batch_zero_alpha_is_identity(torch_mod):
         assert torch.equal(b.coef[c], before[c]), c
 
 
-@pytest.mark.parametrize("regime", [2, 3])
+@pytest.mark.parametrize("regime", [2, 3, 4])
 def test_full_batch_schedule_independence_and_oracle_samples(torch_mod, regime):
+    """regime 4 (mixed): every block has its own non-zero pattern, so octets mix blocks that skip
+    almost every term with blocks that need all 64"""
     torch = torch_mod
     n = N_IMAGES if regime == 2 else 1024
     ref = None
@@ -132,20 +134,22 @@ def test_4k_fullframe_vs_oracle(torch_mod):
         assert np.array_equal(b.coef[c][0].cpu().numpy().reshape(-1), jobs[c][0]), c
 
 
+def _dc_expect(torch, dc, q0, value):
+    """reference effect.c:207-217 on a tensor of DCs: every step on a short"""
+    d = (dc.to(torch.int32) * q0).to(torch.int16).to(torch.int32)  # short *= q
+    d = (d + value).to(torch.int16).to(torch.int32)                # short += value
+    d = d.clamp(-2047, 2047)
+    return torch.div(d, q0, rounding_mode="trunc").to(torch.int16)
+
+
 def test_effects_4k_batch_closed_form(torch_mod):
-    """BASELINE configs[4] (reduced to 512 images = 12.7 GB): luminance(+7), tint(+5,-3), then values
-    that clamp; the DC arithmetic of reference effect.c:207-217 evaluated with torch int ops over
-    the whole batch, everything but the DCs untouched"""
+    """BASELINE configs[4] on 512 images (12.7 GB), compared element for element: luminance(+7),
+    tint(+5,-3), then values that clamp; the DC arithmetic of reference effect.c:207-217 evaluated
+    with torch int ops over the whole batch, everything but the DCs untouched"""
     torch = torch_mod
     from libmodjpeg_amd.batch import EffectBatch
     eb = EffectBatch(512, 3840, 2160)
     eb.fill_synthetic()
-
-    def expect(dc, q0, value):
-        d = (dc.to(torch.int32) * q0).to(torch.int16).to(torch.int32)  # short *= q
-        d = (d + value).to(torch.int16).to(torch.int32)                # short += value
-        d = d.clamp(-2047, 2047)
-        return torch.div(d, q0, rounding_mode="trunc").to(torch.int16)
 
     for lum, cb, cr, fused in ((7, 5, -3, False), (-1900, 300, 0, True)):
         before = [p.clone() for p in eb.coef]
@@ -155,7 +159,7 @@ def test_effects_4k_batch_closed_form(torch_mod):
             tw, th = eb.geo.true_dims[c]
             want = before[c].clone()
             if not (c > 0 and value == 0):
-                want[:, :th, :tw, 0] = expect(before[c][:, :th, :tw, 0], int(eb.quant[c][0]), value)
+                want[:, :th, :tw, 0] = _dc_expect(torch, before[c][:, :th, :tw, 0], int(eb.quant[c][0]), value)
             assert torch.equal(eb.coef[c], want), (lum, cb, cr, c)
     # the padded block row of the Y array (row 270.. none for 4K; for 1080p row 135) is never touched
     eb2 = EffectBatch(8, 1920, 1080)
@@ -164,6 +168,83 @@ def test_effects_4k_batch_closed_form(torch_mod):
     eb2.build_plans(100, 0, 0).run()
     torch.cuda.synchronize()
     assert torch.equal(eb2.coef[0][:, 135], pad)
+
+
+def test_effects_4k_batch_full_size(torch_mod):
+    """BASELINE configs[4] at its size: 4096 x 3840x2160 4:2:0 = 102 GB of JCOEF resident on one
+    device, mj_effect_luminance(+7) then mj_effect_tint(+5,-3) as two launches.  Every DC of the
+    batch is compared with the closed form of reference effect.c:207-217; the other 63 coefficients
+    of every block are covered by two checksums taken before and after (a copy of the batch would
+    not fit); sampled images are replayed through the oracle."""
+    torch = torch_mod
+    from libmodjpeg_amd.batch import EffectBatch
+    n = N_IMAGES
+    eb = EffectBatch(n, 3840, 2160)
+    assert sum(p.numel() * 2 for p in eb.coef) == n * 194400 * 128 == 101921587200
+    eb.fill_synthetic()
+    wts = torch.arange(1, 64, device="cuda", dtype=torch.int32) * 2654435 % 1009  # position weights of the AC checksum
+
+    def ac_sums(p):
+        s1 = s2 = 0
+        for lo in range(0, n, 128):  # chunks: the int32 temporaries stay small
+            ac = p[lo:lo + 128, :, :, 1:].to(torch.int32)
+            s1 += int(ac.sum(dtype=torch.int64))
+            s2 += int((ac * wts).sum(dtype=torch.int64))
+        return s1, s2
+
+    dc_before = [p[..., 0].clone() for p in eb.coef]
+    sums_before = [ac_sums(p) for p in eb.coef]
+    lum, cb, cr = 7, 5, -3
+    eb.build_plans(lum, cb, cr, fused=False).run()
+    torch.cuda.synchronize()
+    for c, value in enumerate((lum, cb, cr)):
+        tw, th = eb.geo.true_dims[c]
+        want = dc_before[c].clone()
+        want[:, :th, :tw] = _dc_expect(torch, dc_before[c][:, :th, :tw], int(eb.quant[c][0]), value)
+        assert torch.equal(eb.coef[c][..., 0], want), c
+        assert ac_sums(eb.coef[c]) == sums_before[c], c
+    for i in (0, n // 2 + 1, n - 1):
+        for c, value in enumerate((lum, cb, cr)):
+            bpr, prow = eb.geo.array_dims[c]
+            tw, th = eb.geo.true_dims[c]
+            want = O.synth_coef(i, c, 0, bpr * prow, eb.quant[c])
+            O.effect_dc(want, bpr, th, tw, int(eb.quant[c][0]), value)
+            assert np.array_equal(eb.coef[c][i].cpu().numpy().reshape(-1), want), (i, c)
+
+
+def test_compose_step_time_does_not_depend_on_the_plane_contents(torch_mod):
+    """bench.py composes the same planes in place step after step (compose.c:237 is in place and
+    not idempotent).  The kernel has one data-dependent path, (int)Y for Y >= 2^31
+    (mjx_compose.hip octet_step): with |tile|, |coef*q| <= 2^15 and sum |w| < 64 it cannot be
+    reached from this workload, before or after any number of compositions.  Timing the launch on
+    pristine planes and after 60 compositions in place must therefore agree."""
+    torch = torch_mod
+    b = _batch(2).build_plan()
+    pristine = b.rect_clone()
+
+    def timed(restore):
+        ms = []
+        for _ in range(12):
+            if restore:
+                b.rect_restore(pristine)
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            b.run()
+            e.record()
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_time(e))
+        return float(np.median(ms))
+
+    for _ in range(200):  # clocks up
+        b.run()
+    torch.cuda.synchronize()
+    t_inplace = timed(False)   # planes composed > 200 times
+    t_pristine = timed(True)
+    t_inplace2 = timed(False)
+    assert abs(t_pristine - t_inplace) <= 0.06 * t_inplace and abs(t_inplace2 - t_inplace) <= 0.06 * t_inplace, (t_pristine, t_inplace, t_inplace2)
+    # and the values stay inside the range the bound assumes
+    for c in range(3):
+        assert int(_rect_view(b, c).to(torch.int32).abs().max()) * int(b.quant[c].max()) < 2 ** 31
 
 
 def test_compose_inside_a_hip_graph(torch_mod):

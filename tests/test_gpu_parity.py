@@ -244,7 +244,9 @@ def test_fuzz_blocks_vs_oracle(mj, family):
     """large randomised differential test on adversarial inputs: raw random float bit patterns
     (NaN, Inf, denormals, huge magnitudes) for tiles and weights, full-range int16 coefficients,
     quantisers up to 65535, random sparsity patterns (each block its own) -- GPU == oracle"""
-    rng = np.random.default_rng(abs(hash(family)) % (2**32))
+    import zlib
+    seed = zlib.crc32(family.encode())  # stable across runs (str hashes change with PYTHONHASHSEED)
+    rng = np.random.default_rng(seed)
     rows, cols = 96, 100  # 9600 blocks per plane, cols not a multiple of 8
     n = rows * cols
     q = rng.integers(1, 256, 64).astype(np.uint16)
@@ -280,4 +282,4 @@ def test_fuzz_blocks_vs_oracle(mj, family):
         jobs.append((want[r0 * cols * 64:r1 * cols * 64], cols, 0, 0, r1 - r0, cols, q, tile[r0 * cols:r1 * cols].reshape(-1), alpha[r0 * cols:r1 * cols].reshape(-1)))
     O.compose_jobs(jobs, nthreads)
     got = m.planes_numpy()[0].reshape(-1)
-    assert np.array_equal(got, want), (family, int((got != want).sum()))
+    assert np.array_equal(got, want), (family, "seed", seed, "differing coefficients", int((got != want).sum()))

@@ -1,8 +1,10 @@
-"""N > 1 path on CPU: two gloo ranks run bench.py's multi-rank protocol (image sharding by rank,
-barrier + sync bracket, MAX-over-ranks of the elapsed time, SUM of the units, rank-0-only report)
-with the CPU oracle standing in for the device step.  The data path has no collective
-(SURVEY.md 8e); what is tested here is that the shards are disjoint and complete, that every rank
-composes exactly its own images, and that the reductions are what bench.py reports."""
+"""N > 1 path on CPU: two gloo ranks run bench.py's multi-rank protocol (the ONE batch cut by image
+index = strong scaling, barrier + sync bracket, MAX-over-ranks of the elapsed time, SUM of the
+units, per-rank reports gathered on rank 0) with the CPU oracle standing in for the device step.
+The data path has no collective; what is tested here is that the shards are disjoint
+and complete (also for rank counts that do not divide the batch), that every rank composes exactly
+its own images, and that the reductions are what bench.py reports.  bench.py itself uses this same
+gloo group on the GPU box: no RCCL communicator is involved in the measurement."""
 import json
 import os
 import subprocess
@@ -22,9 +24,9 @@ from tests import oracle_lib as O
 from libmodjpeg_amd.batch import quant_table, shard_range
 
 rank, world, _ = bench.rank_env()
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
-images = 3                                     # images per rank (weak scaling)
-image0 = bench.shard_image0(rank, images)
+bench.init_ranks(world)                        # gloo, env:// rendezvous on 127.0.0.1 (what bench.py does on the GPU box)
+TOTAL = 7                                      # images of the whole job: strong scaling, 4 + 3
+image0, images = bench.shard_of(TOTAL, rank, world, "strong")
 q = quant_table(False)
 rows, cols = 4, 5
 state = []
@@ -37,12 +39,12 @@ def step():
         O.compose_rect(plane, cols, 0, 0, rows, cols, q, tile, alpha)
     time.sleep(0.01 * (rank + 1))              # rank 1 is slower: MAX must pick it up
 
-elapsed, _ = bench.timed_steps(step, lambda: None, 4, world, "cpu")
-total = bench.sum_over_ranks(images * rows * cols, world, "cpu")
+elapsed, _ = bench.timed_steps(step, lambda: None, 4, world)
+total = bench.sum_over_ranks(images * rows * cols, world)
 digest = [int(np.bitwise_xor.reduce(p.view(np.uint16).astype(np.int64) * 31 + 7)) for p, _, _ in state]
-out = {"rank": rank, "image0": image0, "elapsed": elapsed, "total": total, "digest": digest, "strong": shard_range(10, rank, world)}
-gathered = [None] * world
-dist.all_gather_object(gathered, out)
+out = {"rank": rank, "image0": image0, "images": images, "elapsed": elapsed, "total": total, "digest": digest,
+       "weak": bench.shard_of(TOTAL, rank, world, "weak"), "backend": dist.get_backend()}
+gathered = bench.gather_objects(out, world)
 if rank == 0:
     print(json.dumps(gathered))
 dist.destroy_process_group()
@@ -63,19 +65,44 @@ def test_two_rank_protocol_on_gloo(tmp_path):
         return [ln for ln in text.splitlines() if ln.startswith("[{")]
     assert reports(outs[1][0]) == []  # only rank 0 reports
     res = json.loads(reports(outs[0][0])[-1])
-    assert [r["image0"] for r in res] == [0, 3]  # disjoint, contiguous shards
-    assert res[0]["total"] == res[1]["total"] == 2 * 3 * 20  # SUM over ranks
+    assert [(r["image0"], r["images"]) for r in res] == [(0, 4), (4, 3)]  # the one batch of 7, cut by image index
+    assert res[0]["total"] == res[1]["total"] == 7 * 20  # SUM over ranks = the whole job
     assert res[0]["elapsed"] == res[1]["elapsed"] >= 4 * 0.02  # MAX over ranks (rank 1 sleeps 20 ms per step)
-    assert res[0]["strong"] == [0, 5] and res[1]["strong"] == [5, 10]
-    # each rank composed its own images: the result equals a single-process run over all six
+    assert [tuple(r["weak"]) for r in res] == [(0, 7), (7, 7)]
+    assert {r["backend"] for r in res} == {"gloo"}  # no RCCL in the measurement protocol
+    # each rank composed its own images: the result equals a single-process run over all seven
     from tests import oracle_lib as O
     from libmodjpeg_amd.batch import quant_table
     q = quant_table(False)
     want = []
-    for g in range(6):
+    for g in range(7):
         plane = O.synth_coef(g, 0, 0, 20, q)
         tile, alpha = O.synth_tile(g, 0, 0, 20), O.synth_alpha(g, 0, 0, 20, 2)
         for _ in range(4):
             O.compose_rect(plane, 5, 0, 0, 4, 5, q, tile, alpha)
         want.append(int(np.bitwise_xor.reduce(plane.view(np.uint16).astype(np.int64) * 31 + 7)))
     assert res[0]["digest"] + res[1]["digest"] == want
+
+
+def test_strong_split_is_disjoint_and_complete():
+    """BASELINE configs[3]: the same 4096-image batch over N GPUs, image i -> rank floor(i*N/4096)
+    (SURVEY.md 8e); also rank counts that do not divide the batch"""
+    import bench
+    for total in (4096, 4095, 7, 1):
+        for world in (1, 2, 3, 4, 5, 6, 7, 8):
+            seen = []
+            for r in range(world):
+                lo, n = bench.shard_of(total, r, world, "strong")
+                assert n >= 0
+                seen.extend(range(lo, lo + n))
+            assert seen == list(range(total)), (total, world)
+            sizes = [bench.shard_of(total, r, world, "strong")[1] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    assert bench.shard_of(4096, 3, 8, "strong") == (1536, 512)
+    assert bench.shard_of(4096, 3, 8, "weak") == (3 * 4096, 4096)
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr

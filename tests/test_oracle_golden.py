@@ -144,3 +144,11 @@ def test_synth_is_deterministic_and_in_range():
         assert cnt.max() <= nnz and np.median(cnt) >= nnz - 1
     # A1: opaque, w00 == 0.25 exactly
     assert np.all(O.synth_alpha(0, 0, 0, 4, 1).reshape(-1, 64)[:, 0] == np.float32(0.25))
+    # A4 mixed: the non-zero pattern differs from block to block (0 / 1 / ~10 / ~64 per block), ~8 on average,
+    # and most octets of 8 consecutive blocks hold blocks of different classes
+    cnt = (O.synth_alpha(5, 1, 0, 4096, 4).reshape(-1, 64) != 0).sum(axis=1)
+    frac = [np.mean(cnt == 0), np.mean(cnt == 1), np.mean((cnt >= 8) & (cnt <= 10)), np.mean(cnt >= 60)]
+    assert abs(frac[0] - 8 / 64) < 0.03 and abs(frac[1] - 40 / 64) < 0.04 and abs(frac[2] - 10 / 64) < 0.03 and abs(frac[3] - 6 / 64) < 0.03, frac
+    assert 6.5 < cnt.mean() < 10
+    octets = cnt.reshape(-1, 8)
+    assert np.mean(octets.max(axis=1) >= 60) > 0.4 and np.mean((octets.max(axis=1) >= 60) & (octets.min(axis=1) <= 1)) > 0.4
