@@ -57,6 +57,7 @@ typedef void *mjx_stream_t; /* a hipStream_t, or NULL for the default stream */
 /* ---- device plumbing (so that C callers need no HIP headers) -------------------------- */
 int         mjx_device_count(void);                 /* number of HIP devices, 0 if none */
 int         mjx_set_device(int ordinal);            /* hipSetDevice for the calling thread */
+int         mjx_get_device(int *ordinal);           /* the calling thread's current device */
 const char *mjx_error_string(int err);
 int         mjx_malloc(void **dev, size_t bytes);   /* hipMalloc, 256-byte aligned */
 int         mjx_free(void *dev);

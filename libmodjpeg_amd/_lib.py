@@ -49,6 +49,7 @@ _vp, _i, _sz, _u64, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctype
 SYMBOLS = [
     ("mjx_device_count", _i, []),
     ("mjx_set_device", _i, [_i]),
+    ("mjx_get_device", _i, [ctypes.POINTER(_i)]),
     ("mjx_error_string", ctypes.c_char_p, [_i]),
     ("mjx_malloc", _i, [ctypes.POINTER(_vp), _sz]),
     ("mjx_free", _i, [_vp]),

@@ -6,11 +6,13 @@
  *
  * Batch extension: the same action script applied to many files,
  *
- *     modjpeg --batch list.txt --outdir out/ [--jobs N]  -p br -m -10,-10 -d logo.png -y 20 -O
+ *     modjpeg --batch list.txt --outdir out/ [--jobs N] [--devices G]  -p br -m -10,-10 -d logo.png -y 20 -O
  *
  * where list.txt names one input JPEG per line ("-" = stdin).  Every file is read, run through
  * the script (all options except -i/-o, in order) and written to <outdir>/<basename>.  N host
- * threads work on different files.  An image is decoded on the GPU and STAYS there (shadow.c):
+ * threads work on different files; on a host with several GPUs thread t works on device t mod G
+ * (G = --devices, default: every device present), each image from read to write on one device,
+ * nothing crossing between devices.  An image is decoded on the GPU and STAYS there (shadow.c):
  * compose and the effects run in place, the encoder reads the planes where they are, and only
  * compressed bytes cross PCIe in either direction; concurrent decodes are launched as one batch.
  * Files the GPU entropy coders decline (progressive, arithmetic, -P/-A output) go through libjpeg
@@ -25,7 +27,7 @@
 #include <string.h>
 #include <time.h>
 
-enum { OPT_BATCH = 1000, OPT_OUTDIR, OPT_JOBS };
+enum { OPT_BATCH = 1000, OPT_OUTDIR, OPT_JOBS, OPT_DEVICES };
 
 static const struct option long_options[] = {
     {"input", required_argument, NULL, 'i'},     {"output", required_argument, NULL, 'o'},   {"dropon", required_argument, NULL, 'd'},
@@ -33,7 +35,8 @@ static const struct option long_options[] = {
     {"tintblue", required_argument, NULL, 'b'},  {"tintred", required_argument, NULL, 'r'},  {"pixelate", no_argument, NULL, 'x'},
     {"grayscale", no_argument, NULL, 'g'},       {"progressive", no_argument, NULL, 'P'},    {"optimize", no_argument, NULL, 'O'},
     {"arithmetric", no_argument, NULL, 'A'},     {"help", no_argument, NULL, 'h'},           {"batch", required_argument, NULL, OPT_BATCH},
-    {"outdir", required_argument, NULL, OPT_OUTDIR}, {"jobs", required_argument, NULL, OPT_JOBS}, {NULL, 0, NULL, 0}};
+    {"outdir", required_argument, NULL, OPT_OUTDIR}, {"jobs", required_argument, NULL, OPT_JOBS}, {"devices", required_argument, NULL, OPT_DEVICES},
+    {NULL, 0, NULL, 0}};
 
 typedef struct {
     int   code;
@@ -70,7 +73,9 @@ static void usage(void) {
           "  -y, --luminance v   -b, --tintblue v   -r, --tintred v   -x, --pixelate   -g, --grayscale\n"
           "  -O, --optimize   -P, --progressive   -A, --arithmetric     options for later --output\n"
           "batch mode:\n"
-          "  --batch list.txt --outdir dir [--jobs N]   run the script (everything but -i/-o) on every listed file\n",
+          "  --batch list.txt --outdir dir [--jobs N] [--devices G]\n"
+          "                            run the script (everything but -i/-o) on every listed file with N threads\n"
+          "                            spread over G GPUs (default: all)\n",
           stderr);
 }
 
@@ -150,11 +155,27 @@ typedef struct {
     const action_t *script;
     int             nscript;
     const char     *outdir;
+    int             ndevices, started; /* worker t works on device t mod ndevices */
     pthread_mutex_t lock;
 } batch_t;
 
+/* drop-in internals (shadow.c) */
+int mjh_device_count(void);
+int mjh_use_device(int ordinal);
+
 static void *batch_worker(void *arg) {
     batch_t *b = (batch_t *)arg;
+    int      me;
+    pthread_mutex_lock(&b->lock);
+    me = b->started++;
+    pthread_mutex_unlock(&b->lock);
+    if(b->ndevices > 1 && mjh_use_device(me % b->ndevices) != MJ_OK) {
+        fprintf(stderr, "modjpeg: worker %d cannot use GPU %d\n", me, me % b->ndevices);
+        pthread_mutex_lock(&b->lock);
+        b->failed++;
+        pthread_mutex_unlock(&b->lock);
+        return NULL;
+    }
     for(;;) {
         state_t  s;
         action_t io;
@@ -199,7 +220,7 @@ static void *batch_worker(void *arg) {
  * because this program only ever touches an image through the mj_* functions. */
 void mjh_set_device_resident(int on);
 
-static int run_batch(const char *list, const char *outdir, int jobs, const action_t *script, int nscript) {
+static int run_batch(const char *list, const char *outdir, int jobs, int devices, const action_t *script, int nscript) {
     batch_t    b;
     FILE      *f = strcmp(list, "-") == 0 ? stdin : fopen(list, "r");
     char       line[4096];
@@ -229,6 +250,11 @@ static int run_batch(const char *list, const char *outdir, int jobs, const actio
     pthread_mutex_init(&b.lock, NULL);
     if(jobs < 1) jobs = 1;
     if(jobs > b.nfiles) jobs = b.nfiles > 0 ? b.nfiles : 1;
+    {
+        const int present = mjh_device_count();
+        b.ndevices = (devices > 0 && devices < present) ? devices : present;
+        if(b.ndevices > jobs) b.ndevices = jobs;
+    }
 
     clock_gettime(CLOCK_MONOTONIC, &t0);
     th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)jobs);
@@ -237,7 +263,8 @@ static int run_batch(const char *list, const char *outdir, int jobs, const actio
     clock_gettime(CLOCK_MONOTONIC, &t1);
     {
         const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-        fprintf(stderr, "modjpeg: %d files, %d failed, %d threads, %.3f s, %.1f images/s\n", b.nfiles, b.failed, jobs, sec, sec > 0 ? b.nfiles / sec : 0.0);
+        fprintf(stderr, "modjpeg: %d files, %d failed, %d threads on %d GPU%s, %.3f s, %.1f images/s\n", b.nfiles, b.failed, jobs, b.ndevices, b.ndevices == 1 ? "" : "s", sec,
+                sec > 0 ? b.nfiles / sec : 0.0);
         if(getenv("MJ_CLI_TIMING") != NULL && b.nfiles > 0) {
             extern int mjh_shadow_count, mjh_gpu_decode_count, mjh_gpu_encode_count;
             fprintf(stderr, "modjpeg: per file, in the worker that had it: read %.3f ms, script %.3f ms, write+free %.3f ms\n", b.t_read / b.nfiles, b.t_script / b.nfiles,
@@ -255,7 +282,7 @@ static int run_batch(const char *list, const char *outdir, int jobs, const actio
 int main(int argc, char **argv) {
     action_t   *script = (action_t *)calloc((size_t)argc + 1, sizeof(action_t));
     const char *batch_list = NULL, *outdir = ".";
-    int         nscript = 0, jobs = 4, c, i, rc = 0;
+    int         nscript = 0, jobs = 4, devices = 0, c, i, rc = 0;
 
     /* this program only ever touches an image through the mj_* functions, so images may stay on the
      * device between read and write (MJ_DEVICE_RESIDENT=0 keeps the host arrays authoritative) */
@@ -270,6 +297,7 @@ int main(int argc, char **argv) {
             case OPT_BATCH: batch_list = optarg; break;
             case OPT_OUTDIR: outdir = optarg; break;
             case OPT_JOBS: jobs = atoi(optarg); break;
+            case OPT_DEVICES: devices = atoi(optarg); break;
             default:
                 script[nscript].code = c;
                 script[nscript].arg = optarg;
@@ -279,7 +307,7 @@ int main(int argc, char **argv) {
     }
 
     if(batch_list != NULL) {
-        rc = run_batch(batch_list, outdir, jobs, script, nscript);
+        rc = run_batch(batch_list, outdir, jobs, devices, script, nscript);
     }
     else {
         state_t s;

@@ -28,6 +28,13 @@ int        mjh_shadow_count = 0; /* images that were kept on the device (tests) 
 
 void mjh_set_device_resident(int on) { g_resident = on ? 1 : 0; }
 
+/* multi-GPU hosts: a thread works on the device it selected last (hipSetDevice semantics); images,
+ * staging arenas, decode/encode batches and cached tiles all belong to the device of the thread that
+ * made them, so a program shards its threads over the devices and nothing crosses between GPUs
+ * (image i -> device, one host thread + stream per device, no peer access) */
+int mjh_device_count(void) { return mjx_device_count(); }
+int mjh_use_device(int ordinal) { return mjh_from_mjx(mjx_set_device(ordinal)); }
+
 int mjh_device_resident(void) {
     if(g_resident < 0) {
         const char *e = getenv("MJ_DEVICE_RESIDENT");

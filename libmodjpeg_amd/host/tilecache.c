@@ -8,10 +8,15 @@
  * the first MCU and the target's colour space and sampling, so the typical caller - one dropon
  * composed into many images of one geometry - gets the same tiles every time.
  *
- * This cache keys on a 128-bit hash of exactly those inputs and keeps the tiles RESIDENT ON THE
- * DEVICE: a hit costs one hash of the visible pixels and no PCIe traffic for tiles.  It is
- * transparent (same results as without it; MJ_TILE_CACHE=0 disables it), bounded (8 entries,
- * 1 GiB), process-wide and mutex-protected; entries in use are never evicted.
+ * This cache indexes on a 128-bit hash of exactly those inputs plus the HIP device the tiles live
+ * on, and keeps the tiles RESIDENT ON THAT DEVICE: a hit costs one hash and one comparison of the
+ * visible pixels and no PCIe traffic for tiles.  The hash only says where to look: an entry is used
+ * when its device, its parameters and its copy of the visible pixels equal the caller's byte for
+ * byte, so a hash collision can never hand out another overlay's tiles.  It is transparent (same
+ * results as without it; MJ_TILE_CACHE=0 disables it), bounded (8 entries, 1 GiB including the
+ * pixel copies), process-wide and mutex-protected; entries in use are never evicted, and the lock
+ * is held only for table look-ups and pointer moves: tile preparation, hipMalloc, the upload and
+ * every hipFree happen outside it.
  */
 #include "mjhost.h"
 
@@ -26,10 +31,15 @@ struct mjh_tiles {
     uint64_t key[2];
     int      valid, users;
     uint64_t stamp;
-    size_t   bytes;
+    size_t   bytes;    /* device bytes + the host copy of the window */
     int      ncomp;
     int      rows[4], cols[4];
     float   *dev_tile[4], *dev_alpha[4];
+    /* what the key stands for, compared on every hit: a hash decides where to look, never what is equal */
+    int            device;     /* HIP ordinal the tiles live on */
+    int            params[16]; /* colour spaces, in-MCU offset, crop size, sampling */
+    size_t         win_bytes;
+    unsigned char *window;     /* the visible overlay pixels, image rows then alpha rows */
 };
 
 static struct mjh_tiles g_slots[CACHE_SLOTS];
@@ -41,7 +51,8 @@ static int cache_enabled(void) {
     return !(e != NULL && e[0] == '0');
 }
 
-/* two independent multiply-xorshift lanes over 8-byte words */
+/* two independent multiply-xorshift lanes over 8-byte words: an index into the cache, not an
+ * identity (see matches()) */
 typedef struct {
     uint64_t a, b;
 } hash128_t;
@@ -69,15 +80,29 @@ static void hash_bytes(hash128_t *h, const void *data, size_t len) {
     h->b = b;
 }
 
-static void make_key(uint64_t key[2], const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_sampling_t *s, int bx, int by, int cx, int cy, int cw, int ch) {
-    hash128_t h = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
-    int       params[16] = {d->colorspace, (int)cs, bx, by, cw, ch, s->h_factor, s->v_factor, 0, 0, 0, 0, 0, 0, 0, 0};
-    int       c, y;
+/* everything the prepared tiles depend on besides the pixels (reference dropon.c:325-350) */
+static void make_params(int params[16], const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_sampling_t *s, int bx, int by, int cw, int ch) {
+    int c;
+    memset(params, 0, 16 * sizeof(int));
+    params[0] = d->colorspace;
+    params[1] = (int)cs;
+    params[2] = bx;
+    params[3] = by;
+    params[4] = cw;
+    params[5] = ch;
+    params[6] = s->h_factor;
+    params[7] = s->v_factor;
     for(c = 0; c < 4; c++) {
         params[8 + 2 * c] = s->samp_factor[c].h_samp_factor;
         params[9 + 2 * c] = s->samp_factor[c].v_samp_factor;
     }
-    hash_bytes(&h, params, sizeof(params));
+}
+
+static void make_key(uint64_t key[2], const int params[16], int device, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
+    hash128_t h = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
+    int       y;
+    hash_bytes(&h, params, 16 * sizeof(int));
+    hash_bytes(&h, &device, sizeof(device));
     for(y = 0; y < ch; y++) { /* only the visible window decides the tiles */
         const size_t off = ((size_t)(y + cy) * (size_t)d->width + (size_t)cx) * 3;
         hash_bytes(&h, d->image + off, (size_t)cw * 3);
@@ -87,18 +112,36 @@ static void make_key(uint64_t key[2], const mj_dropon_t *d, J_COLOR_SPACE cs, co
     key[1] = h.b;
 }
 
-static void slot_free(struct mjh_tiles *t) {
+/* a slot holds exactly these tiles: same device, same parameters, same visible pixels byte for byte */
+static int matches(const struct mjh_tiles *t, const uint64_t key[2], const int params[16], int device, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
+    const size_t row = (size_t)cw * 3;
+    int          y;
+    if(!t->valid || t->key[0] != key[0] || t->key[1] != key[1] || t->device != device) return 0;
+    if(memcmp(t->params, params, 16 * sizeof(int)) != 0 || t->win_bytes != 2 * row * (size_t)ch) return 0;
+    for(y = 0; y < ch; y++) {
+        const size_t off = ((size_t)(y + cy) * (size_t)d->width + (size_t)cx) * 3;
+        if(memcmp(t->window + (size_t)y * row, d->image + off, row) != 0) return 0;
+        if(memcmp(t->window + ((size_t)ch + (size_t)y) * row, d->alpha + off, row) != 0) return 0;
+    }
+    return 1;
+}
+
+/* device buffers and window copy of an entry that has left the table (called WITHOUT the lock) */
+static void contents_free(struct mjh_tiles *t) {
     int c;
     for(c = 0; c < 4; c++) {
         if(t->dev_tile[c]) (void)mjx_free(t->dev_tile[c]);
         if(t->dev_alpha[c]) (void)mjx_free(t->dev_alpha[c]);
     }
+    free(t->window);
     memset(t, 0, sizeof(*t));
 }
 
-/* upload freshly compiled tiles into `t` */
-static int slot_fill(struct mjh_tiles *t, const mj_compileddropon_t *cd) {
-    int c;
+/* upload freshly compiled tiles into `t` and keep a copy of the window (called WITHOUT the lock,
+ * on a private struct) */
+static int contents_fill(struct mjh_tiles *t, const mj_compileddropon_t *cd, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
+    const size_t row = (size_t)cw * 3;
+    int          c, y;
     t->ncomp = cd->image_ncomponents;
     t->bytes = 0;
     for(c = 0; c < t->ncomp; c++) {
@@ -113,23 +156,36 @@ static int slot_fill(struct mjh_tiles *t, const mj_compileddropon_t *cd) {
         if((e = mjx_memcpy_h2d(t->dev_alpha[c], cd->alpha[c].blocks[0], bytes, NULL)) != MJX_OK) return e;
         t->bytes += 2 * bytes;
     }
+    t->win_bytes = 2 * row * (size_t)ch;
+    t->window = (unsigned char *)malloc(t->win_bytes ? t->win_bytes : 1);
+    if(t->window == NULL) return MJX_ERR_MEMORY;
+    for(y = 0; y < ch; y++) {
+        const size_t off = ((size_t)(y + cy) * (size_t)d->width + (size_t)cx) * 3;
+        memcpy(t->window + (size_t)y * row, d->image + off, row);
+        memcpy(t->window + ((size_t)ch + (size_t)y) * row, d->alpha + off, row);
+    }
+    t->bytes += t->win_bytes;
     return MJX_OK;
 }
 
 int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, mj_sampling_t *s, int bx, int by, int cx, int cy, int cw, int ch) {
     uint64_t            key[2];
+    int                 params[16], device = 0;
     mj_compileddropon_t cd;
-    struct mjh_tiles   *t = NULL;
+    struct mjh_tiles   *t = NULL, *victim = NULL;
+    struct mjh_tiles    fresh, evicted[CACHE_SLOTS];
     size_t              total = 0;
-    int                 i, rv;
+    int                 i, rv, nevicted = 0;
 
     *out = NULL;
     if(!cache_enabled()) return MJ_OK; /* caller takes the uncached path */
-    make_key(key, d, cs, s, bx, by, cx, cy, cw, ch);
+    if(mjx_get_device(&device) != MJX_OK) return MJ_OK; /* no device: the compose call itself reports it */
+    make_params(params, d, cs, s, bx, by, cw, ch);
+    make_key(key, params, device, d, cx, cy, cw, ch);
 
     pthread_mutex_lock(&g_lock);
     for(i = 0; i < CACHE_SLOTS; i++) {
-        if(g_slots[i].valid && g_slots[i].key[0] == key[0] && g_slots[i].key[1] == key[1]) {
+        if(matches(&g_slots[i], key, params, device, d, cx, cy, cw, ch)) {
             g_slots[i].users++;
             g_slots[i].stamp = ++g_clock;
             *out = &g_slots[i];
@@ -139,17 +195,27 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
     }
     pthread_mutex_unlock(&g_lock);
 
-    /* miss: prepare outside the lock (libjpeg work), then publish */
+    /* miss: prepare (libjpeg work) and upload with no lock held, then publish */
     rv = mj_compile_dropon(&cd, d, cs, s, bx, by, cx, cy, cw, ch);
     if(rv != MJ_OK) return rv;
+    memset(&fresh, 0, sizeof(fresh));
+    rv = mjh_from_mjx(contents_fill(&fresh, &cd, d, cx, cy, cw, ch));
+    mj_free_compileddropon(&cd);
+    if(rv != MJ_OK) {
+        contents_free(&fresh);
+        return rv;
+    }
+    fresh.key[0] = key[0];
+    fresh.key[1] = key[1];
+    fresh.device = device;
+    memcpy(fresh.params, params, sizeof(params));
 
     pthread_mutex_lock(&g_lock);
-    /* somebody else may have published the same key meanwhile */
+    /* somebody else may have published the same tiles meanwhile */
     for(i = 0; i < CACHE_SLOTS; i++) {
-        if(g_slots[i].valid && g_slots[i].key[0] == key[0] && g_slots[i].key[1] == key[1]) t = &g_slots[i];
+        if(matches(&g_slots[i], key, params, device, d, cx, cy, cw, ch)) t = &g_slots[i];
     }
     if(t == NULL) {
-        struct mjh_tiles *victim = NULL;
         for(i = 0; i < CACHE_SLOTS; i++) total += g_slots[i].valid ? g_slots[i].bytes : 0;
         for(i = 0; i < CACHE_SLOTS; i++) { /* a free slot, else the least recently used idle one */
             if(!g_slots[i].valid) {
@@ -158,27 +224,24 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
             }
             if(g_slots[i].users == 0 && (victim == NULL || g_slots[i].stamp < victim->stamp)) victim = &g_slots[i];
         }
-        /* keep the footprint bounded: drop idle entries, oldest first, while over budget */
-        while(total > CACHE_BYTES) {
+        /* keep the footprint bounded: drop idle entries, oldest first, while over budget; what
+         * leaves the table is freed after the lock is released */
+        while(total + fresh.bytes > CACHE_BYTES) {
             struct mjh_tiles *old = NULL;
             for(i = 0; i < CACHE_SLOTS; i++)
                 if(g_slots[i].valid && g_slots[i].users == 0 && &g_slots[i] != victim && (old == NULL || g_slots[i].stamp < old->stamp)) old = &g_slots[i];
             if(old == NULL) break;
             total -= old->bytes;
-            slot_free(old);
+            evicted[nevicted++] = *old;
+            memset(old, 0, sizeof(*old));
         }
         if(victim != NULL) {
-            if(victim->valid) slot_free(victim);
-            rv = mjh_from_mjx(slot_fill(victim, &cd));
-            if(rv == MJ_OK) {
-                victim->key[0] = key[0];
-                victim->key[1] = key[1];
-                victim->valid = 1;
-                t = victim;
-            }
-            else {
-                slot_free(victim);
-            }
+            if(victim->valid) evicted[nevicted++] = *victim;
+            *victim = fresh;
+            victim->valid = 1;
+            victim->users = 0;
+            memset(&fresh, 0, sizeof(fresh)); /* ownership moved into the table */
+            t = victim;
         }
     }
     if(t != NULL) {
@@ -186,10 +249,10 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
         t->stamp = ++g_clock;
     }
     pthread_mutex_unlock(&g_lock);
-    mj_free_compileddropon(&cd);
-    if(t == NULL && rv == MJ_OK) return MJ_OK; /* every slot busy: uncached path */
-    *out = t;
-    return rv;
+    for(i = 0; i < nevicted; i++) contents_free(&evicted[i]);
+    contents_free(&fresh); /* lost the race, or every slot busy: nothing is kept */
+    *out = t;              /* NULL: the caller takes the uncached path */
+    return MJ_OK;
 }
 
 void mjh_tiles_release(struct mjh_tiles *t) {

@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "libmjx_oracle.so")
+ORACLE_SO = os.environ.get("MJX_ORACLE_SO") or os.path.join(ORACLE_DIR, "libmjx_oracle.so")  # override: sanitizer builds (scripts/asan_cpu.sh)
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libmodjpeg_ref.so")
 
 _f32p = ctypes.POINTER(ctypes.c_float)
