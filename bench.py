@@ -66,6 +66,7 @@ def parse(argv=None):
     ap.add_argument("--images", type=int, default=0, help="images of the whole job (strong) / per GPU (weak); default: the workload's")
     ap.add_argument("--cpu-sample", type=int, default=256, help="images in the CPU baseline / parity sample (0 = skip)")
     ap.add_argument("--pristine-launches", type=int, default=10, help="extra launches from restored planes for roofline.kernel_ms_pristine (0 = skip)")
+    ap.add_argument("--no-group", action="store_true", help="compose: keep every octet 8 consecutive blocks (no grouping of blocks by alpha density)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     return ap.parse_args(argv)
 
@@ -293,7 +294,7 @@ def bench_compose(args, rank, world):
     assert images > 0, f"rank {rank}: empty shard ({total_images} images over {world} ranks)"
     batch = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, regime, image0=image0)
     batch.fill_synthetic()
-    batch.build_plan()
+    batch.build_plan(group_by_density=not args.no_group)
     blocks_per_step = batch.total_blocks()
     sync = torch.cuda.synchronize
 
@@ -368,7 +369,8 @@ def bench_compose(args, rank, world):
             "dtype": "s16 JCOEF, f32/f64 blend (reference typing)", "data": "synthetic",
             "config": {"workload": args.workload, "images_total": tot_blocks // batch.blocks_per_image, "images_per_gpu": images, "image": f"{width}x{height} 4:2:0",
                        "dropon": f"{dw}x{dh} alpha-masked, per-image tiles, MCU ({mcu_x},{mcu_y})",
-                       "alpha_regime": args.regime, "blocks_per_step_total": tot_blocks, "blocks_per_step_per_gpu": blocks_per_step, "spinup_ms": args.spinup_ms,
+                       "alpha_regime": args.regime, "density_grouping": (not args.no_group), "gather_octets_per_gpu": int(batch.gather_octets),
+                       "blocks_per_step_total": tot_blocks, "blocks_per_step_per_gpu": blocks_per_step, "spinup_ms": args.spinup_ms,
                        "parallelism": f"images sharded x{world} ({args.scaling}), no collective, no RCCL"},
             "parity": verdicts.pop() if len(verdicts) == 1 else "mixed: see per_rank",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

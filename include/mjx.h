@@ -89,6 +89,17 @@ typedef struct mjx_compose_plan mjx_compose_plan_t;
  * Rectangles must not overlap each other inside one plan. */
 int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs,
                             const uint16_t *qtables, int nq);
+/* The same with options.  MJX_PLAN_GROUP_BY_DENSITY: the alpha tiles (which must hold their final
+ * contents) are scanned once on the device, and inside every rectangle whose blocks differ a lot in
+ * their number of non-zero weights (reference convolve.c:32 skips a term per block; a mask with a
+ * hard edge has mostly 1-weight blocks and a few 64-weight ones) the blocks that share a wavefront
+ * are chosen by density instead of by position, so that a dense block no longer makes seven sparse
+ * neighbours wait for its 64 terms.  Purely a schedule: the results are identical. */
+#define MJX_PLAN_GROUP_BY_DENSITY 1
+int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs,
+                               const uint16_t *qtables, int nq, int flags);
+/* octets (8 blocks) of the plan that were formed by density rather than by position */
+int64_t mjx_compose_plan_gather_octets(const mjx_compose_plan_t *plan);
 void mjx_compose_plan_destroy(mjx_compose_plan_t *plan);
 /* total 8x8 blocks the plan composes per run */
 int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan);

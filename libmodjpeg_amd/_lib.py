@@ -15,6 +15,7 @@ MJX_ERR_MEMORY = 2
 MJX_ERR_NULL_DATA = 3
 MJX_ERR_BAD_ARG = 4
 MJX_ERR_LAUNCH = 5
+MJX_PLAN_GROUP_BY_DENSITY = 1
 
 
 class MjxError(RuntimeError):
@@ -57,6 +58,8 @@ SYMBOLS = [
     ("mjx_memcpy_d2h", _i, [_vp, _vp, _sz, _vp]),
     ("mjx_stream_synchronize", _i, [_vp]),
     ("mjx_compose_plan_create", _i, [ctypes.POINTER(_vp), ctypes.POINTER(RectJob), _i, _vp, _i]),
+    ("mjx_compose_plan_create_ex", _i, [ctypes.POINTER(_vp), ctypes.POINTER(RectJob), _i, _vp, _i, _i]),
+    ("mjx_compose_plan_gather_octets", ctypes.c_int64, [_vp]),
     ("mjx_compose_plan_destroy", None, [_vp]),
     ("mjx_compose_plan_blocks", ctypes.c_int64, [_vp]),
     ("mjx_compose_run", _i, [_vp, _vp]),

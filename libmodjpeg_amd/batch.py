@@ -14,7 +14,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import DcJob, RectJob, check, lib
+from ._lib import MJX_PLAN_GROUP_BY_DENSITY, DcJob, RectJob, check, lib
 
 _BASE_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
                        14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
@@ -94,7 +94,9 @@ class ComposeBatch:
         torch.cuda.current_stream().synchronize()
 
     # ---- launch plan ------------------------------------------------------------------------
-    def build_plan(self):
+    def build_plan(self, group_by_density=True):
+        """group_by_density: octets are formed from blocks of similar alpha density where a rectangle
+        mixes sparse and dense blocks (mjx_compose_plan_create_ex); a schedule only, same results"""
         jobs = (RectJob * (3 * self.n))()
         j = 0
         for i in range(self.n):
@@ -106,8 +108,10 @@ class ComposeBatch:
                 j += 1
         qt = np.ascontiguousarray(np.stack(self.quant))
         self.destroy_plan()
-        check(lib().mjx_compose_plan_create(ctypes.byref(self.plan), jobs, 3 * self.n, qt.ctypes.data_as(ctypes.c_void_p), 3), "mjx_compose_plan_create")
+        check(lib().mjx_compose_plan_create_ex(ctypes.byref(self.plan), jobs, 3 * self.n, qt.ctypes.data_as(ctypes.c_void_p), 3,
+                                               MJX_PLAN_GROUP_BY_DENSITY if group_by_density else 0), "mjx_compose_plan_create_ex")
         assert lib().mjx_compose_plan_blocks(self.plan) == self.n * self.blocks_per_image
+        self.gather_octets = lib().mjx_compose_plan_gather_octets(self.plan)
         return self
 
     def run(self):

@@ -31,6 +31,10 @@
 #ifndef MJX_NT
 #define MJX_NT 1
 #endif
+// keep M_SQRT2 * (double)z_l[0] of all eight l in registers (16 VGPRs) instead of recomputing it per term
+#ifndef MJX_SZ0_CACHE
+#define MJX_SZ0_CACHE 1
+#endif
 
 namespace mjx {
 
@@ -55,27 +59,45 @@ MJX_DEV void lds_put_row(float *img, int b, int r, const float (&a)[8]) {
     p[0] = make_float4(a[0], a[1], a[2], a[3]);
     p[1] = make_float4(a[4], a[5], a[6], a[7]);
 }
-// LDS -> row layout
-MJX_DEV void lds_get_row(const float *img, int b, int r, float (&a)[8]) {
-    const float4 *p = reinterpret_cast<const float4 *>(img + b * kBlockStride + r * kRowStride);
-    float4        lo = p[0], hi = p[1];
-    a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w;
-    a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
-}
 // LDS -> column layout: lane (b,u) reads element u of every row
 MJX_DEV void lds_get_col(const float *img, int b, int r, float (&a)[8]) {
     const float *p = img + b * kBlockStride + r;
     static_for<8>([&](auto V) { a[V] = p[V * kRowStride]; });
 }
-// column layout -> LDS
-MJX_DEV void lds_put_col(float *img, int b, int r, const float (&a)[8]) {
-    float *p = img + b * kBlockStride + r;
-    static_for<8>([&](auto V) { p[V * kRowStride] = a[V]; });
+// Y goes back from column to row layout through an image of its own shape: rows of 8 dwords, block
+// stride 82.  The column writes (ds_write_b32, 32 lanes per cycle, bank = dword mod 32) then fall
+// on every bank at most twice (2-way is free for a 4-byte store), and the row comes back as four
+// ds_read_b64 (32 lanes per cycle over 64 banks, bank pair = (41 b + 4 r + j) mod 32: all different)
+// instead of two ds_read_b128 that conflicted 3-way on the 12/104 image (measured,
+// profiles/r02/lds_patterns_pmc.txt).  Inline asm keeps the four reads from being fused into
+// ds_read2_b64 / ds_read_b128, whose lane grouping differs; the values are needed at once, so the
+// wait is part of the statement.
+constexpr int kYRowStride = 8;
+constexpr int kYBlockStride = 82;
+static_assert(kWaveBlocks * kYBlockStride <= kImageDwords, "the Y image lives in the Z image's storage");
+MJX_DEV void lds_put_col_y(float *img, int b, int u, const float (&a)[8]) {
+    float *p = img + b * kYBlockStride + u;
+    static_for<8>([&](auto V) { p[V * kYRowStride] = a[V]; });
+}
+MJX_DEV void lds_get_row_y(const float *img, int b, int r, float (&a)[8]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const unsigned at = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)(img + b * kYBlockStride + r * kYRowStride);
+    f2             v0, v1, v2, v3;
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(at) : "memory");
+    a[0] = v0.x; a[1] = v0.y; a[2] = v1.x; a[3] = v1.y; a[4] = v2.x; a[5] = v2.y; a[6] = v3.x; a[7] = v3.y;
 }
 
 MJX_DEV unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
 
-constexpr unsigned long long kOnes = 0x0101010101010101ull; // bit 8b of every block b
+// The row-layout alpha registers of lane (b, r) hold the row stored at position r of block b's
+// LDS image = source row (r - 2b) & 7 (see the landing layout below), so in the ballots source row
+// K of block b sits at bit 8b + ((K + 2b) & 7)
+constexpr unsigned long long row_mask(int K) {
+    unsigned long long m = 0;
+    for(int b = 0; b < 8; ++b) m |= 1ull << (8 * b + ((K + 2 * b) & 7));
+    return m;
+}
 
 // ------------------------------------------------------------------------------------------
 // the whole per-octet computation, given the operands in row layout
@@ -84,25 +106,31 @@ constexpr unsigned long long kOnes = 0x0101010101010101ull; // bit 8b of every b
 // ------------------------------------------------------------------------------------------
 template <class WRow>
 MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow)[8], WRow &&weight_row, float *imgZ, int b, int r) {
-    // which terms does this octet need?  bit (8b + k) of m[l] <=> alpha_b[k][l] != 0
+    // which terms does this octet need?  bit (8b + rp) of m[l] <=> alpha_b[(rp - 2b) & 7][l] != 0
     unsigned long long m[8];
     static_for<8>([&](auto L) { m[L] = __ballot(al[L] != 0.0f); });
 
-    // H stage in row layout, z_l moved to column layout through LDS.  z_l is computed only for
-    // columns l that some block of the octet uses, but read back unconditionally (stale LDS for an
-    // unused l is never consumed: its terms all have w == 0): the loads are then straight-line
-    // code, z[l] needs no merge copies (22 VGPRs less) and the round trips overlap.
+    // H stage in row layout, z_l moved to column layout through LDS, only for the columns l that
+    // some block of the octet uses; z[l] of the others stays undefined and is never consumed (its
+    // terms all have w == 0).  The round trips of consecutive l overlap: DS operations of one wave
+    // execute in order, so the next put_row may be issued before this get_col has returned.
     float        z[8][8];
     const double sx0 = kSqrt2 * (double)x[0];
+#if MJX_SZ0_CACHE
+    double       sz0[8]; // M_SQRT2 * (double)z_l[0], used by the row v == k of every term (k >= 1, l)
+#endif
     static_for<8>([&](auto L) {
         if(m[L] != 0ull) {
             float zr[8];
             hstage<L>(x, sx0, zr);
             lds_put_row(imgZ, b, r, zr);
+            wave_sync();
+            lds_get_col(imgZ, b, r, z[L]);
+            wave_sync();
+#if MJX_SZ0_CACHE
+            sz0[L] = kSqrt2 * (double)z[L][0];
+#endif
         }
-        wave_sync();
-        lds_get_col(imgZ, b, r, z[L]);
-        wave_sync();
     });
 
     // V stage in column layout: k outer, l inner, as reference compose.c:303-312.  Rows of alpha
@@ -113,7 +141,8 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
     float y[8];
     static_for<8>([&](auto V) { y[V] = 0.0f; });
     static_for<8>([&](auto K) {
-        if((any & (kOnes << K)) != 0ull) {
+        constexpr unsigned long long kRowK = row_mask(K);
+        if((any & kRowK) != 0ull) {
             float wk[8];
             weight_row(K, wk); // alpha_b[K][0..7], broadcast inside the block
             static_for<8>([&](auto L) {
@@ -123,9 +152,12 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
                         vstage_first(y, z[L], w);
                     }
                     else {
-                        // M_SQRT2*(double)z_l[0] is recomputed per term (cvt + mul) rather than kept
-                        // for all eight l: 16 VGPRs would cost the third wave per SIMD
+#if MJX_SZ0_CACHE
+                        vstage<K>(y, z[L], K == 0 ? 0.0 : sz0[L], w);
+#else
+                        // M_SQRT2*(double)z_l[0] recomputed per term (cvt + mul)
                         vstage<K>(y, z[L], K == 0 ? 0.0 : kSqrt2 * (double)z[L][0], w);
+#endif
                     }
                 }
             });
@@ -133,51 +165,65 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
     });
 
     // back to row layout for the integer tail and the store
-    lds_put_col(imgZ, b, r, y);
+    lds_put_col_y(imgZ, b, r, y);
     wave_sync();
-    lds_get_row(imgZ, b, r, yrow);
+    lds_get_row_y(imgZ, b, r, yrow);
     wave_sync();
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
-// compose kernel: per-wave software pipeline with LDS-DMA prefetch.
+// compose kernel: per-wave software pipeline with LDS-DMA prefetch, MJX_DEPTH octets ahead.
 //
-// A wave owns a *run* of consecutive octets of one job.  While it computes octet i, the 5 KiB of
-// octet i+1 (1 KiB JCOEF, 2 KiB tile, 2 KiB alpha) are already in flight from HBM straight into
-// wave-private LDS buffers by `global_load_lds_dwordx4` (no VGPR destination, so the prefetch
-// costs no registers and occupancy stays at 3 waves per SIMD).
+// A wave owns a *run* of consecutive octets of one job and is a workgroup of its own (the kernel
+// has no workgroup barrier; one-wave workgroups let the CU hold as many waves as LDS and registers
+// allow instead of multiples of four).  While it blends octet i, the 5 KiB each of octets i+1 ..
+// i+MJX_DEPTH (1 KiB JCOEF, 2 KiB tile, 2 KiB alpha) are in flight from HBM straight into
+// wave-private LDS buffers by `global_load_lds_dwordx4` (no VGPR destination: the prefetch costs no
+// registers).  Measured on MI355X (profiles/r02/): with the blend compiled out the depth-1 pipeline
+// of round 1 streamed the headline batch at 68 % of the 8 TB/s peak, i.e. bytes in flight, not the
+// VALU, bounded regimes A1/A2; depth 2 on one-wave workgroups holds 10 waves x 10 KiB per CU.
 //
-// The kernel is VALU-issue bound for every mask that is not trivially sparse (rocprofv3:
-// ~80 % of the SIMD issue slots at 10 non-zero weights per block), and on gfx950 every VALU
-// instruction costs about the same issue time whatever its type (scripts/ubench/valu_rate.hip),
-// so the per-octet instruction count is what is optimised here:
-//   * JCOEF stays packed (2 x int16 per register): dequantisation is v_pk_mul_lo_u16, the
-//     `short += (int)Y` is v_pk_add_u16, only the float conversions touch single elements
-//   * per-lane addresses advance incrementally from octet to octet (tile column + plane block
-//     index); the float division only runs once per run and for a ragged last octet
-//   * `(int)Y` uses the saturating hardware conversion; its only difference to the reference's
-//     x86 conversion (Y >= 2^31) is detected per wave and sent down a slow path
+// Buffers per wave: JCOEF and tile are copied to registers at the top of a step, so their
+// MJX_DEPTH slots are refilled at once (slot of octet i = i mod DEPTH receives octet i+DEPTH);
+// alpha is read throughout the blend (broadcast weight rows), so it has DEPTH+1 slots.
 //
-// LDS-DMA writes LDS "wave-uniform base + 16*lane", the global SOURCE address is per lane:
+// LDS-DMA writes LDS "wave-uniform base + 16*lane", the global SOURCE address is per lane, so a
+// piece can land permuted at no cost as long as the wave instruction still covers one contiguous
+// KiB of memory (a permutation that breaks a piece into 16-byte fragments at 32-byte stride was
+// measured 5 % slower end to end: profiles/r02/ab_layout_getcol_noblend.txt):
 //   JCOEF piece  dest chunk = lane -> (block lane>>3, row lane&7): natural order, the per-block
 //                source address carries the rectangle -> plane mapping
-//   tile pieces  natural order (2 x 1 KiB; the second piece is the first + 1024 bytes on both
-//                sides, so it reuses the address registers with an immediate offset)
-//   alpha pieces natural order except that the 8 rows of block b are rotated by 2b rows, so the
-//                broadcast read of weight row k (8 lanes of a block read the same 32 bytes, 4
-//                blocks per ds_read_b128 lane group) falls on 4 different bank groups
+//   tile pieces  2 x 1 KiB (4 blocks each; the second piece is the first + 1024 bytes on both
+//                sides).  The two 16-byte halves of every row of blocks 2,3,6,7 land swapped:
+//                ds_read_b128 serves 16 lanes per cycle over 64 banks, and rows read at a 32-byte
+//                lane stride would use only half of the banks (2-way conflict, measured); with the
+//                swap, half of the lanes of every lane group read the other half and the access is
+//                conflict-free.  Each lane reads "its low half" at +16*ph, ph = (b>>1)&1.
+//   alpha pieces the same half swap, and the 8 rows of block b rotated by 2b rows, so that the
+//                broadcast read of weight row k (8 lanes of a block read the same 16 bytes, 4
+//                blocks per ds_read_b128 lane group) falls on 4 different bank groups.  The row
+//                layout read of alpha (only its zero pattern is used, for the skip ballots) takes
+//                the row at position r, i.e. source row (r - 2b) & 7: row_mask() below.
 // vmcnt bookkeeping (VMEM ops retire in issue order): per octet 5 DMA pieces are issued, later
-// one JCOEF store; at the top of iteration i >= 1 the youngest outstanding op is store(i-1), so
-// `s_waitcnt vmcnt(1)` is exactly "the pieces of octet i have landed".  To keep that count exact
-// the store is unconditional (lanes past the end of the job duplicate the job's last block: same
-// address, same bytes) and the kernel must not spill (a scratch access is a VMEM op): build()
-// checks ScratchSize == 0.
+// one JCOEF store.  At the top of step i the operations younger than the pieces of octet i are the
+// pieces of the octets i+1 .. i+DEPTH-1 already issued and the stores of the last min(i, DEPTH)
+// steps: wait_vmcnt_n(5 * pending + min(i, DEPTH)) is exactly "octet i has landed".  To keep that
+// count exact the store is unconditional (lanes past the end of the job duplicate the job's last
+// block: same address, same bytes) and the kernel must not spill (a scratch access is a VMEM op):
+// build() checks ScratchSize == 0.
 // ------------------------------------------------------------------------------------------
 #ifndef MJX_RUN_OCTETS
 #define MJX_RUN_OCTETS 16
 #endif
+#ifndef MJX_DEPTH
+#define MJX_DEPTH 1
+#endif
+#ifndef MJX_GROUP_WAVES
+#define MJX_GROUP_WAVES 4
+#endif
+static_assert(MJX_DEPTH >= 1 && MJX_DEPTH <= 3, "prefetch depth");
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void       lvoid_t;
@@ -199,7 +245,7 @@ MJX_DEV unsigned lds_addr(const float *p) {
 // as a pending LDS write and then puts `s_waitcnt vmcnt(0)` in front of every later ds_read it
 // cannot prove disjoint (all of the blend's transposes), which would serialise the prefetch with
 // the compute it hides behind.  The asm form is invisible to the compiler's counters; the kernel
-// counts the pieces itself (wait_vmcnt) and has no compiler-visible VMEM load while pieces are in
+// counts the pieces itself (wait_vmcnt_n) and has no compiler-visible VMEM load while pieces are in
 // flight.  M0 carries the LDS base; it is compiler-reserved, so it is saved/restored inside the
 // statement.
 //
@@ -236,13 +282,48 @@ MJX_DEV void tile_rc(const DevJob &job, int nc, int &trow, int &tcol) {
     if(tcol >= job.cols) { trow += 1; tcol -= job.cols; }
 }
 
-// per-lane addressing state of a run
+// per-lane addressing state of a run: describes the octet whose pieces were issued last
 struct OctetAddr {
     int      tcol;  // tile column of this lane's JCOEF block (lane>>3)
     unsigned pblk;  // its block index inside the plane
     unsigned toff;  // byte offset of this lane's tile chunk inside job.tile (alpha: aoff)
     unsigned aoff;
 };
+
+// tile / alpha pieces: piece j holds blocks 4j .. 4j+3, 16 chunks of 16 B per block.  Chunk (row
+// position rp, half position hp) of block b holds half hp ^ ph(b) of tile row rp, resp. of alpha
+// source row (rp - 2b) & 7 (rotation and half swap are the same for b and b+4).  Byte offset of
+// this lane's chunk inside its block:
+MJX_DEV void chunk_in_block(int lane, unsigned &t_in, unsigned &a_in) {
+    const int bq = lane >> 4, ch = lane & 15;
+    const int half = (ch & 1) ^ ((bq >> 1) & 1);
+    const int k_rot = ((ch >> 1) - 2 * bq) & 7;
+    t_in = (unsigned)((ch >> 1) * 32 + half * 16);
+    a_in = (unsigned)(k_rot * 32 + half * 16);
+}
+
+// one piece from scalar base + per-lane 32-bit offset
+MJX_DEV void dma16_so(const void *sbase, unsigned voff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MJX_NT_SFX "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
+
+// gather form (runs of a plan grouped by density, mjx_compose_plan_create_ex): the 8 blocks of the
+// octet are named by the run's gather table in LDS (tile block index, plane block index), so the
+// four tile / alpha pieces are 4 x 256-byte segments each instead of one contiguous KiB
+MJX_DEV int16_t *dma_octet_gather(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned a_in, unsigned dC, unsigned dT, unsigned dA) {
+    const int  bq = lane >> 4;
+    const int2 e = *reinterpret_cast<const int2 *>(G + (o * kWaveBlocks + (lane >> 3)) * 2);
+    const int  t_lo = G[(o * kWaveBlocks + bq) * 2], t_hi = G[(o * kWaveBlocks + 4 + bq) * 2];
+    int16_t   *cptr = job.coef + (size_t)(unsigned)e.y * 64 + (lane & 7) * 8;
+    dma16(cptr, dC);
+    dma16_so(job.tile, (unsigned)t_lo * 256u + t_in, dT);
+    dma16_so(job.tile, (unsigned)t_hi * 256u + t_in, dT + 1024);
+    dma16_so(job.alpha, (unsigned)t_lo * 256u + a_in, dA);
+    dma16_so(job.alpha, (unsigned)t_hi * 256u + a_in, dA + 1024);
+    return cptr;
+}
 
 // generic (slow) form: any octet, lanes past the end of the job clamp to its last block.
 // Issues the 5 pieces and leaves `a` describing this octet.
@@ -256,12 +337,11 @@ MJX_DEV int16_t *dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
     a.pblk = __umul24((unsigned)(job.row0 + trow), (unsigned)job.bpr) + (unsigned)(job.col0 + a.tcol);
     int16_t *cptr = job.coef + (size_t)a.pblk * 64 + (lane & 7) * 8;
     dma16(cptr, dC);
-    // tile / alpha: piece j holds blocks 4j .. 4j+3, 16 chunks of 16 B per block; alpha row
-    // position rp of block b holds source row (rp - 2b) & 7 (the same for b and b+4)
-    const int bq = lane >> 4, ch = lane & 15;
-    const int k_rot = ((ch >> 1) - 2 * bq) & 7;
-    a.toff = (unsigned)(n0 + bq) * 256u + (unsigned)ch * 16u;
-    a.aoff = (unsigned)(n0 + bq) * 256u + (unsigned)(k_rot * 32 + (ch & 1) * 16);
+    const int bq = lane >> 4;
+    unsigned  t_in, a_in;
+    chunk_in_block(lane, t_in, a_in);
+    a.toff = (unsigned)(n0 + bq) * 256u + t_in;
+    a.aoff = (unsigned)(n0 + bq) * 256u + a_in;
     if(n0 + 7 <= last) {
         dma16x2(job.tile, a.toff, dT);
         dma16x2(job.alpha, a.aoff, dA);
@@ -270,7 +350,6 @@ MJX_DEV int16_t *dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
         int n_lo = n0 + bq, n_hi = n0 + 4 + bq;
         n_lo = n_lo < last ? n_lo : last;
         n_hi = n_hi < last ? n_hi : last;
-        const unsigned t_in = (unsigned)ch * 16u, a_in = (unsigned)(k_rot * 32 + (ch & 1) * 16);
         dma16(reinterpret_cast<const char *>(job.tile) + (size_t)n_lo * 256 + t_in, dT);
         dma16(reinterpret_cast<const char *>(job.tile) + (size_t)n_hi * 256 + t_in, dT + 1024);
         dma16(reinterpret_cast<const char *>(job.alpha) + (size_t)n_lo * 256 + a_in, dA);
@@ -297,9 +376,38 @@ MJX_DEV int16_t *dma_octet_next(const DevJob &job, int lane, OctetAddr &a, unsig
     return cptr;
 }
 
-template <int N> MJX_DEV void wait_vmcnt() {
-    if constexpr(N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+// issue the pieces of octet o of the run.  Consecutive run: the octet starts at tile block
+// first + 8 o (the one after `a` unless it is the first of the run or ragged); gather run: see above.
+struct RunCtx {
+    int        first;   // consecutive: first tile block of the run
+    bool       gather;  // wave-uniform
+    const int *G;       // gather: the run's table in LDS
+    unsigned   t_in, a_in;
+};
+MJX_DEV int16_t *dma_octet(const DevJob &job, const RunCtx &rc, int o, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
+    if(rc.gather) return dma_octet_gather(job, o, lane, rc.G, rc.t_in, rc.a_in, dC, dT, dA);
+    const int n = rc.first + o * kWaveBlocks;
+    if(o != 0 && n + kWaveBlocks <= job.nblocks) return dma_octet_next(job, lane, a, dC, dT, dA);
+    return dma_octet_generic(job, n, lane, a, dC, dT, dA);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
+MJX_DEV void wait_vmcnt_n(int n) {
+    switch(n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break; // never more than needed
+    }
 }
 
 MJX_DEV float s16_lo_to_f32(unsigned p) { return (float)(int)(short)(p & 0xFFFFu); }
@@ -319,29 +427,20 @@ MJX_DEV int cvt_i32_sat(float f) {
     return r;
 }
 
-// one octet: operands are in LDS (pC, pT, pA); prefetch of the next octet goes to (pC, pT, pAn)
-// NEXT: 0 = no next octet, 1 = next octet is full (fast addressing), 2 = runtime choice
-template <bool FIRST>
-MJX_DEV int16_t *octet_step(const DevJob &job, int n_next, bool has_next, int16_t *cptr, OctetAddr &addr, int lane, int b, int r, const float *qrow,
-                            float *pC, float *pT, float *pA, float *pAn, float *imgZ) {
-    wait_vmcnt<FIRST ? 0 : 1>();
+// wave-private LDS
+struct WaveLds {
+    float C[MJX_DEPTH][256];     // JCOEF of octet i in slot i mod DEPTH
+    float T[MJX_DEPTH][512];     // tile
+    float A[MJX_DEPTH + 1][512]; // alpha of octet i in slot i mod (DEPTH+1): live during the blend
+    float Z[kImageDwords];       // transposition image
+    float Q[8 * 12];             // quant row r: 8 x u16 then 8 reciprocals
+    int   G[MJX_RUN_OCTETS * kWaveBlocks * 2]; // gather runs: (tile block, plane block) of every block of the run
+};
 
-    const uint4  c4 = *reinterpret_cast<const uint4 *>(pC + lane * 4);
-    const float4 t_lo = *reinterpret_cast<const float4 *>(pT + lane * 8);
-    const float4 t_hi = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4);
-    const float *arow = pA + b * 64 + ((r + 2 * b) & 7) * 8;
-    const float4 a_lo = *reinterpret_cast<const float4 *>(arow);
-    const float4 a_hi = *reinterpret_cast<const float4 *>(arow + 4);
-    const uint4  q4 = *reinterpret_cast<const uint4 *>(qrow); // this lane's quant row, 8 x u16
-    // the JCOEF and tile buffers are about to be overwritten by the next octet's DMA
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-    int16_t *cnext = cptr;
-    if(has_next) {
-        if(n_next + kWaveBlocks <= job.nblocks) cnext = dma_octet_next(job, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(pAn));
-        else cnext = dma_octet_generic(job, n_next, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(pAn));
-    }
-
+// one octet whose operands have landed in (pC, pT, pA): registers, blend, store to cptr
+MJX_DEV void octet_compute(int16_t *cptr, int lane, int b, int r, const float *qrow, const uint4 c4, const float4 t_lo, const float4 t_hi, const float4 a_lo,
+                           const float4 a_hi, const float *pA, float *imgZ) {
+    const uint4 q4 = *reinterpret_cast<const uint4 *>(qrow); // this lane's quant row, 8 x u16
     // D: (short)(coef * q), two coefficients per register (compose.c:277-286)
     const unsigned cd[4] = {pk_mul_lo_u16(c4.x, q4.x), pk_mul_lo_u16(c4.y, q4.y), pk_mul_lo_u16(c4.z, q4.z), pk_mul_lo_u16(c4.w, q4.w)};
     const float    t[8] = {t_lo.x, t_lo.y, t_lo.z, t_lo.w, t_hi.x, t_hi.y, t_hi.z, t_hi.w};
@@ -352,13 +451,20 @@ MJX_DEV int16_t *octet_step(const DevJob &job, int n_next, bool has_next, int16_
         x[2 * P + 1] = t[2 * P + 1] - s16_hi_to_f32(cd[P]);
     });
 
+    const int ph = (b >> 1) & 1; // this block's rows land with their halves swapped (see above)
+#if MJX_EXP_NOBLEND
+    // experiment only (wrong results): the streaming ceiling of the pipeline without the blend
+    (void)ph; (void)pA; (void)imgZ;
+    static_for<8>([&](auto U) { y[U] = x[U] * al[U]; });
+#else
     octet_blend(x, al, y,
                 [&](int K, float (&wk)[8]) {
                     const float *wrow = pA + b * 64 + ((K + 2 * b) & 7) * 8;
-                    const float4 lo = *reinterpret_cast<const float4 *>(wrow), hi = *reinterpret_cast<const float4 *>(wrow + 4);
+                    const float4 lo = *reinterpret_cast<const float4 *>(wrow + 4 * ph), hi = *reinterpret_cast<const float4 *>(wrow + 4 - 4 * ph);
                     wk[0] = lo.x; wk[1] = lo.y; wk[2] = lo.z; wk[3] = lo.w; wk[4] = hi.x; wk[5] = hi.y; wk[6] = hi.z; wk[7] = hi.w;
                 },
                 imgZ, b, r); // compose.c:300-312
+#endif
 
     // A: coef = (short)(coef + (int)Y) (compose.c:315-324).  v_cvt_i32_f32 differs from the x86
     // conversion of the reference only for Y >= 2^31 (0x7fffffff instead of 0x80000000; NaN and
@@ -382,25 +488,20 @@ MJX_DEV int16_t *octet_step(const DevJob &job, int n_next, bool has_next, int16_
         o[P] = pack16(q_lo, q_hi);
     });
     global_store16(cptr, make_uint4(o[0], o[1], o[2], o[3]));
-    return cnext;
 }
 
 #ifndef MJX_COMPOSE_MIN_WAVES
 #define MJX_COMPOSE_MIN_WAVES 3
 #endif
-__global__ __launch_bounds__(256, MJX_COMPOSE_MIN_WAVES) void compose_kernel(const DevJob *__restrict__ jobs, const Run *__restrict__ runs, int nruns,
-                                                                          const uint16_t *__restrict__ qtab, const float *__restrict__ rqtab) {
-    __shared__ __attribute__((aligned(16))) float sC[kWavesPerGroup][256];
-    __shared__ __attribute__((aligned(16))) float sT[kWavesPerGroup][512];
-    __shared__ __attribute__((aligned(16))) float sA0[kWavesPerGroup][512];
-    __shared__ __attribute__((aligned(16))) float sA1[kWavesPerGroup][512];
-    __shared__ __attribute__((aligned(16))) float sZ[kWavesPerGroup][kImageDwords];
-    __shared__ __attribute__((aligned(16))) float sQ[kWavesPerGroup][8 * 12];
+__global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void compose_kernel(const DevJob *__restrict__ jobs, const Run *__restrict__ runs, int nruns,
+                                                                                            const uint16_t *__restrict__ qtab, const float *__restrict__ rqtab,
+                                                                                            const GatherEntry *__restrict__ gather) {
+    __shared__ __attribute__((aligned(16))) WaveLds lds[MJX_GROUP_WAVES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = lane >> 3, r = lane & 7;
-    const int ridx = blockIdx.x * kWavesPerGroup + wave;
+    const int ridx = blockIdx.x * MJX_GROUP_WAVES + wave;
     if(ridx >= nruns) return; // wave-uniform; the kernel uses no workgroup barrier
 
     const Run    run = runs[ridx];
@@ -408,11 +509,23 @@ __global__ __launch_bounds__(256, MJX_COMPOSE_MIN_WAVES) void compose_kernel(con
     const int    first = __builtin_amdgcn_readfirstlane(run.first);
     const int    noct = __builtin_amdgcn_readfirstlane(run.noctets);
     const DevJob job = jobs[jidx];
+    WaveLds     &L = lds[wave];
+
+    RunCtx rc;
+    rc.first = first;
+    rc.gather = __builtin_amdgcn_readfirstlane(run.gather) != 0;
+    rc.G = L.G;
+    chunk_in_block(lane, rc.t_in, rc.a_in);
+    if(rc.gather) { // the run's gather table (noct x 64 bytes <= 1 KiB) into LDS: one piece, 16 bytes per lane
+        const int chunk = lane < noct * 4 ? lane : noct * 4 - 1;
+        dma16(reinterpret_cast<const char *>(gather + (size_t)first * kWaveBlocks) + chunk * 16, lds_addr(reinterpret_cast<const float *>(L.G)));
+    }
 
     // Row r of the job's quant table (8 x u16) and of its reciprocals (8 x f32), staged in LDS as
     // 12 dwords per row.  These are the only compiler-visible VMEM loads of the kernel; writing
-    // them to LDS makes the compiler retire them here, before the first DMA piece is issued.
-    float *qrow = sQ[wave] + r * 12;
+    // them to LDS makes the compiler retire them here, before the first octet's pieces are issued
+    // (the same wait covers the gather table).
+    float *qrow = L.Q + r * 12;
     {
         const uint4  q4 = *reinterpret_cast<const uint4 *>(qtab + job.qidx * 64 + r * 8);
         const float4 rq_lo = *reinterpret_cast<const float4 *>(rqtab + job.qidx * 64 + r * 8);
@@ -425,28 +538,80 @@ __global__ __launch_bounds__(256, MJX_COMPOSE_MIN_WAVES) void compose_kernel(con
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
 
-    float *pC = sC[wave], *pT = sT[wave], *pA0 = sA0[wave], *pA1 = sA1[wave], *imgZ = sZ[wave];
-
+    // prologue: the first DEPTH octets of the run
     OctetAddr addr;
-    int16_t  *cptr = dma_octet_generic(job, first, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(pA0));
-    cptr = octet_step<true>(job, first + kWaveBlocks, noct > 1, cptr, addr, lane, b, r, qrow, pC, pT, pA0, pA1, imgZ);
-    // steady state, unrolled by two so that the alpha double buffer is addressed statically
-    int i = 1;
+    int16_t  *cp[MJX_DEPTH + 1]; // cp[d] = store address of octet i + d
+    static_for<MJX_DEPTH>([&](auto D) {
+        cp[D] = nullptr;
+        if(D < noct) cp[D] = dma_octet(job, rc, D, lane, addr, lds_addr(L.C[D]), lds_addr(L.T[D]), lds_addr(L.A[D]));
+    });
+
+    const int ph = (b >> 1) & 1;
+    int       sc = 0, sa = 0; // LDS slots of octet i: i mod DEPTH, i mod (DEPTH + 1)
 #pragma unroll 1
-    for(; i + 1 < noct; i += 2) {
-        cptr = octet_step<false>(job, first + (i + 1) * kWaveBlocks, true, cptr, addr, lane, b, r, qrow, pC, pT, pA1, pA0, imgZ);
-        cptr = octet_step<false>(job, first + (i + 2) * kWaveBlocks, i + 2 < noct, cptr, addr, lane, b, r, qrow, pC, pT, pA0, pA1, imgZ);
-    }
-    if(i < noct) {
-        (void)octet_step<false>(job, 0, false, cptr, addr, lane, b, r, qrow, pC, pT, pA1, pA0, imgZ);
+    for(int i = 0; i < noct; ++i) {
+        const int ahead = noct - 1 - i < MJX_DEPTH - 1 ? noct - 1 - i : MJX_DEPTH - 1; // octets i+1.. already in flight
+        wait_vmcnt_n(5 * ahead + (i < MJX_DEPTH ? i : MJX_DEPTH));
+
+        float       *pC = L.C[sc], *pT = L.T[sc];
+        const float *pA = L.A[sa];
+        const uint4  c4 = *reinterpret_cast<const uint4 *>(pC + lane * 4);
+        const float4 t_lo = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4 * ph);
+        const float4 t_hi = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4 - 4 * ph);
+        // the alpha row stored at row position r of this block = source row (r - 2b) & 7: only the
+        // skip ballots of octet_blend look at it (row_mask)
+        const float4 a_lo = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 * ph);
+        const float4 a_hi = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 - 4 * ph);
+        // the JCOEF and tile slots are about to be overwritten by the DMA of octet i + DEPTH
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        int sn = sa + MJX_DEPTH; // alpha slot of octet i + DEPTH
+        sn = sn > MJX_DEPTH ? sn - (MJX_DEPTH + 1) : sn;
+        cp[MJX_DEPTH] = cp[0];
+        if(i + MJX_DEPTH < noct) cp[MJX_DEPTH] = dma_octet(job, rc, i + MJX_DEPTH, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(L.A[sn]));
+
+        octet_compute(cp[0], lane, b, r, qrow, c4, t_lo, t_hi, a_lo, a_hi, pA, L.Z);
+
+        static_for<MJX_DEPTH>([&](auto D) { cp[D] = cp[D + 1]; });
+        sc = sc + 1 == MJX_DEPTH ? 0 : sc + 1;
+        sa = sa == MJX_DEPTH ? 0 : sa + 1;
     }
 }
 
-int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, hipStream_t s) {
+int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, const GatherEntry *gather, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
-    const int groups = (nruns + kWavesPerGroup - 1) / kWavesPerGroup;
-    hipLaunchKernelGGL(compose_kernel, dim3((unsigned)groups), dim3(256), 0, s, jobs, runs, nruns, qtab, rqtab);
+    const int groups = (nruns + MJX_GROUP_WAVES - 1) / MJX_GROUP_WAVES;
+    hipLaunchKernelGGL(compose_kernel, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, jobs, runs, nruns, qtab, rqtab, gather);
     return check_hip(hipGetLastError(), "compose_kernel launch", MJX_ERR_LAUNCH);
+}
+
+// ------------------------------------------------------------------------------------------
+// density of the alpha tiles: non-zero weights per block (0..64), for plans that group blocks of
+// similar density into octets.  Walks the consecutive runs of a plan: lane (b, r) counts row r of
+// its block, the 8 lanes of a block add up, lane r == 0 writes the byte.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void alpha_nnz_kernel(const DevJob *__restrict__ jobs, const Run *__restrict__ runs, int nruns, uint8_t *__restrict__ nnz) {
+    const int lane = threadIdx.x & 63, b = lane >> 3, r = lane & 7;
+    const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if(ridx >= nruns) return;
+    const Run    run = runs[ridx];
+    const DevJob job = jobs[run.job];
+    for(int o = 0; o < run.noctets; ++o) {
+        const int    n = run.first + o * kWaveBlocks + b;
+        const int    nc = n < job.nblocks ? n : job.nblocks - 1;
+        const float4 lo = *reinterpret_cast<const float4 *>(job.alpha + (size_t)nc * 64 + r * 8), hi = *reinterpret_cast<const float4 *>(job.alpha + (size_t)nc * 64 + r * 8 + 4);
+        int          c = (lo.x != 0.0f) + (lo.y != 0.0f) + (lo.z != 0.0f) + (lo.w != 0.0f) + (hi.x != 0.0f) + (hi.y != 0.0f) + (hi.z != 0.0f) + (hi.w != 0.0f);
+        c += __shfl_xor(c, 1);
+        c += __shfl_xor(c, 2);
+        c += __shfl_xor(c, 4);
+        if(r == 0 && n < job.nblocks) nnz[(size_t)(unsigned)job.nnz_off + n] = (uint8_t)c;
+    }
+}
+
+int launch_alpha_nnz(const DevJob *jobs, const Run *runs, int nruns, uint8_t *nnz, hipStream_t s) {
+    if(nruns <= 0) return MJX_OK;
+    hipLaunchKernelGGL(alpha_nnz_kernel, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, jobs, runs, nruns, nnz);
+    return check_hip(hipGetLastError(), "alpha_nnz_kernel launch", MJX_ERR_LAUNCH);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -467,9 +632,9 @@ template <int K, int L> MJX_DEV void convolve_term(const float (&x)[8], float (&
     wave_sync();
     const double sz0 = kSqrt2 * (double)z[0];
     vstage<K>(y, z, sz0, w);
-    lds_put_col(img, b, r, y);
+    lds_put_col_y(img, b, r, y);
     wave_sync();
-    lds_get_row(img, b, r, yrow);
+    lds_get_row_y(img, b, r, yrow);
     wave_sync();
 }
 

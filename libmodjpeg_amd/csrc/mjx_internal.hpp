@@ -17,16 +17,22 @@ struct DevJob {
     int32_t      nblocks; // rows*cols
     int32_t      qidx;
     float        inv_cols; // 1.0f/cols, for the row/column split of the linear tile index
-    int32_t      pad;
+    int32_t      nnz_off;  // first block of this job in the plan's per-block density array
 };
 static_assert(sizeof(DevJob) == 56, "DevJob layout");
 
-// one wave's share of a launch: up to MJX_RUN_OCTETS consecutive octets (8 blocks each) of one job
+// one wave's share of a launch: up to MJX_RUN_OCTETS octets (8 blocks each) of one job
 struct Run {
     int32_t job;
-    int32_t first;   // first tile block
+    int32_t first;   // consecutive run: first tile block; gather run: its first octet in the plan's gather table
     int32_t noctets; // >= 1
-    int32_t pad;
+    int32_t gather;  // 0 = the octets are consecutive tile blocks, 1 = they are listed in the gather table
+};
+
+// one block of a gather octet
+struct GatherEntry {
+    int32_t  tile; // block index inside the job's tile / alpha arrays
+    uint32_t pblk; // block index inside the component plane
 };
 
 constexpr int kWaveBlocks = 8;     // one wavefront = 8 blocks x 8 lanes
@@ -77,7 +83,8 @@ struct ArenaLease {
 };
 
 // launchers implemented in the kernel translation units
-int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, hipStream_t s);
+int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, const GatherEntry *gather, hipStream_t s);
+int launch_alpha_nnz(const DevJob *jobs, const Run *runs, int nruns, uint8_t *nnz, hipStream_t s);
 int run_octets();
 int launch_convolve(const float *x, float *y, float w, int k, int l, int nblocks, hipStream_t s);
 int launch_effect_dc(const DevDcJob *jobs, int njobs, int64_t max_blocks_per_job, hipStream_t s);

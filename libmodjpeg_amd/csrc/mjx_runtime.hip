@@ -59,13 +59,15 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 using namespace mjx;
 
 struct mjx_compose_plan {
-    DevJob   *d_jobs = nullptr;
-    Run      *d_runs = nullptr;
-    int       nruns = 0;
-    uint16_t *d_q = nullptr;
-    float    *d_rq = nullptr;
-    int       njobs = 0;
-    int64_t   blocks = 0;
+    DevJob      *d_jobs = nullptr;
+    Run         *d_runs = nullptr;
+    int          nruns = 0;
+    uint16_t    *d_q = nullptr;
+    float       *d_rq = nullptr;
+    GatherEntry *d_gather = nullptr; // plans grouped by density: the blocks of every gather octet
+    int          njobs = 0;
+    int64_t      blocks = 0;
+    int64_t      gather_octets = 0;
 };
 
 struct mjx_dc_plan {
@@ -151,17 +153,82 @@ void mjx_compose_plan_destroy(mjx_compose_plan_t *p) {
     if(p->d_runs) (void)hipFree(p->d_runs);
     if(p->d_q) (void)hipFree(p->d_q);
     if(p->d_rq) (void)hipFree(p->d_rq);
+    if(p->d_gather) (void)hipFree(p->d_gather);
     delete p;
 }
 
 // host-side launch tables of a set of rectangles (shared by plans and the host-buffer path)
 namespace {
 struct Tables {
-    std::vector<DevJob> jobs;
-    std::vector<Run>    runs;
-    std::vector<float>  rq;
-    int64_t             blocks = 0;
+    std::vector<DevJob>      jobs;
+    std::vector<Run>         runs;
+    std::vector<GatherEntry> gather; // 8 entries per gather octet
+    std::vector<float>       rq;
+    std::vector<int8_t>      run_class; // density class of each run's first octet (parallel to runs)
+    int64_t                  blocks = 0;
+    int                      run_len = 0;
 };
+
+// density classes of a block by its number of non-zero weights.  Measured on MI355X:
+// up to ~16 terms per block the octet is bounded by the HBM stream, beyond that by the VALU, in
+// proportion to the terms the octet's densest block needs; so an octet should not mix classes.
+int density_class(unsigned nnz) { return nnz <= 16 ? 0 : (nnz <= 36 ? 1 : 2); }
+
+// the runs of the jobs in t.jobs.  nnz == nullptr: every job as consecutive octets.  Else nnz[] is
+// the per-block density (DevJob::nnz_off): a job whose blocks fall into more than one class is cut
+// into octets class by class, densest first (the long-running waves start first), through the
+// gather table; a job of one class keeps its consecutive octets.
+void build_runs(Tables &t, const uint8_t *nnz) {
+    const int run_blocks = t.run_len * kWaveBlocks;
+    t.runs.clear();
+    t.gather.clear();
+    t.run_class.clear();
+    std::vector<int> order;
+    for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
+        const DevJob &d = t.jobs[(size_t)jid];
+        bool          mixed = false;
+        if(nnz != nullptr) {
+            const uint8_t *z = nnz + (size_t)(unsigned)d.nnz_off;
+            const int      c0 = density_class(z[0]);
+            for(int n = 1; n < d.nblocks && !mixed; ++n) mixed = density_class(z[n]) != c0;
+        }
+        if(!mixed) {
+            for(int f = 0; f < d.nblocks; f += run_blocks) {
+                const int left = d.nblocks - f;
+                const int nb = left < run_blocks ? left : run_blocks;
+                t.runs.push_back(Run{jid, f, (nb + kWaveBlocks - 1) / kWaveBlocks, 0});
+                t.run_class.push_back(nnz != nullptr ? (int8_t)density_class(nnz[(size_t)(unsigned)d.nnz_off]) : (int8_t)0);
+            }
+            continue;
+        }
+        const uint8_t *z = nnz + (size_t)(unsigned)d.nnz_off;
+        order.clear();
+        for(int c = 2; c >= 0; --c)
+            for(int n = 0; n < d.nblocks; ++n)
+                if(density_class(z[n]) == c) order.push_back(n);
+        while(order.size() % kWaveBlocks != 0) order.push_back(order.back()); // a ragged last octet repeats its last block
+        const int noct = (int)(order.size() / kWaveBlocks);
+        const int g_run = t.run_len < run_octets() ? t.run_len : run_octets(); // a run's table is one LDS-DMA piece
+        for(int o = 0; o < noct; o += g_run) {
+            const int no = noct - o < g_run ? noct - o : g_run;
+            t.runs.push_back(Run{jid, (int)(t.gather.size() / kWaveBlocks), no, 1});
+            t.run_class.push_back((int8_t)density_class(z[order[(size_t)(o * kWaveBlocks)]]));
+            for(int k = 0; k < no * kWaveBlocks; ++k) {
+                const int n = order[(size_t)(o * kWaveBlocks + k)];
+                const int trow = n / d.cols, tcol = n - trow * d.cols;
+                t.gather.push_back(GatherEntry{n, (uint32_t)(d.row0 + trow) * (uint32_t)d.bpr + (uint32_t)(d.col0 + tcol)});
+            }
+        }
+    }
+    if(nnz != nullptr) { // the dense runs take several times as long: dispatch them first, the tail of the launch is sparse runs
+        std::vector<Run> sorted;
+        sorted.reserve(t.runs.size());
+        for(int c = 2; c >= 0; --c)
+            for(size_t i = 0; i < t.runs.size(); ++i)
+                if(t.run_class[i] == c) sorted.push_back(t.runs[i]);
+        t.runs.swap(sorted);
+    }
+}
 
 int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, Tables &t) {
     // the reference divides by quantval (compose.c:327-336): q == 0 is a caller bug there (SIGFPE)
@@ -183,7 +250,7 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
         const int v = atoi(e);
         if(v >= 1 && v <= 1024) run_len = v;
     }
-    const int run_blocks = run_len * kWaveBlocks;
+    t.run_len = run_len;
     // rectangles of >= 2^24 blocks are split by rows so that the kernel's float row/column split
     // of the linear tile index stays exact
     const int64_t kMaxJobBlocks = (1ll << 24) - 1;
@@ -202,6 +269,7 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
         const int max_rows = (int)(kMaxJobBlocks / j.cols);
         for(int r0 = 0; r0 < j.rows; r0 += max_rows) {
             const int rows = (j.rows - r0 < max_rows) ? (j.rows - r0) : max_rows;
+            if(t.blocks + (int64_t)rows * j.cols > 0x7FFFFFFFll) return MJX_ERR_BAD_ARG; // one plan: < 2^31 blocks
             DevJob    d;
             d.coef = j.coef;
             d.tile = j.tile + (size_t)r0 * (size_t)j.cols * 64;
@@ -213,24 +281,19 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
             d.nblocks = rows * j.cols;
             d.qidx = j.qtable;
             d.inv_cols = 1.0f / (float)j.cols;
-            d.pad = 0;
-            const int jid = (int)t.jobs.size();
+            d.nnz_off = (int32_t)t.blocks;
             t.jobs.push_back(d);
-            for(int f = 0; f < d.nblocks; f += run_blocks) {
-                const int left = d.nblocks - f;
-                const int nb = left < run_blocks ? left : run_blocks;
-                t.runs.push_back(Run{jid, f, (nb + kWaveBlocks - 1) / kWaveBlocks, 0});
-            }
             t.blocks += d.nblocks;
         }
     }
+    build_runs(t, nullptr);
     t.rq.resize((size_t)nq * 64);
     for(int i = 0; i < nq * 64; ++i) t.rq[(size_t)i] = rq_of(qtables[i]);
     return MJX_OK;
 }
 } // namespace
 
-int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq) {
+int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, int flags) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
     *plan = nullptr;
     if(njobs < 0 || nq < 0) return MJX_ERR_BAD_ARG;
@@ -244,19 +307,42 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
     mjx_compose_plan *p = new(std::nothrow) mjx_compose_plan;
     if(p == nullptr) return MJX_ERR_MEMORY;
     p->njobs = (int)t.jobs.size();
-    p->nruns = (int)t.runs.size();
     p->blocks = t.blocks;
 
     do {
         if(p->njobs == 0) break;
         if((err = check_hip(hipMalloc((void **)&p->d_jobs, t.jobs.size() * sizeof(DevJob)), "hipMalloc(jobs)", MJX_ERR_MEMORY))) break;
-        if((err = check_hip(hipMalloc((void **)&p->d_runs, t.runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMalloc((void **)&p->d_q, (size_t)nq * 64 * sizeof(uint16_t)), "hipMalloc(q)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMalloc((void **)&p->d_rq, (size_t)nq * 64 * sizeof(float)), "hipMalloc(rq)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMemcpy(p->d_jobs, t.jobs.data(), t.jobs.size() * sizeof(DevJob), hipMemcpyHostToDevice), "hipMemcpy(jobs)", MJX_ERR_LAUNCH))) break;
-        if((err = check_hip(hipMemcpy(p->d_runs, t.runs.data(), t.runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
         if((err = check_hip(hipMemcpy(p->d_q, qtables, (size_t)nq * 64 * sizeof(uint16_t), hipMemcpyHostToDevice), "hipMemcpy(q)", MJX_ERR_LAUNCH))) break;
         if((err = check_hip(hipMemcpy(p->d_rq, t.rq.data(), (size_t)nq * 64 * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(rq)", MJX_ERR_LAUNCH))) break;
+
+        if(flags & MJX_PLAN_GROUP_BY_DENSITY) {
+            // one pass over the alpha tiles as they are now: non-zero weights per block, then the
+            // octets are formed class by class.  The grouping only decides which blocks share a
+            // wavefront: results do not depend on it, nor on alpha changing afterwards.
+            Run     *d_tmp = nullptr;
+            uint8_t *d_nnz = nullptr;
+            std::vector<uint8_t> nnz((size_t)t.blocks);
+            err = check_hip(hipMalloc((void **)&d_tmp, t.runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY);
+            if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_nnz, (size_t)t.blocks), "hipMalloc(nnz)", MJX_ERR_MEMORY);
+            if(err == MJX_OK) err = check_hip(hipMemcpy(d_tmp, t.runs.data(), t.runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH);
+            if(err == MJX_OK) err = launch_alpha_nnz(p->d_jobs, d_tmp, (int)t.runs.size(), d_nnz, nullptr);
+            if(err == MJX_OK) err = check_hip(hipMemcpy(nnz.data(), d_nnz, (size_t)t.blocks, hipMemcpyDeviceToHost), "hipMemcpy(nnz)", MJX_ERR_LAUNCH);
+            if(d_tmp) (void)hipFree(d_tmp);
+            if(d_nnz) (void)hipFree(d_nnz);
+            if(err != MJX_OK) break;
+            build_runs(t, nnz.data());
+        }
+        p->nruns = (int)t.runs.size();
+        p->gather_octets = (int64_t)(t.gather.size() / kWaveBlocks);
+        if((err = check_hip(hipMalloc((void **)&p->d_runs, t.runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
+        if((err = check_hip(hipMemcpy(p->d_runs, t.runs.data(), t.runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
+        if(!t.gather.empty()) {
+            if((err = check_hip(hipMalloc((void **)&p->d_gather, t.gather.size() * sizeof(GatherEntry)), "hipMalloc(gather)", MJX_ERR_MEMORY))) break;
+            if((err = check_hip(hipMemcpy(p->d_gather, t.gather.data(), t.gather.size() * sizeof(GatherEntry), hipMemcpyHostToDevice), "hipMemcpy(gather)", MJX_ERR_LAUNCH))) break;
+        }
     } while(0);
     if(err != MJX_OK) {
         mjx_compose_plan_destroy(p);
@@ -266,12 +352,18 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
     return MJX_OK;
 }
 
+int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq) {
+    return mjx_compose_plan_create_ex(plan, jobs, njobs, qtables, nq, 0);
+}
+
+int64_t mjx_compose_plan_gather_octets(const mjx_compose_plan_t *plan) { return plan ? plan->gather_octets : 0; }
+
 int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan) { return plan ? plan->blocks : 0; }
 
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
     if(plan->nruns == 0) return MJX_OK;
-    return launch_compose(plan->d_jobs, plan->d_runs, plan->nruns, plan->d_q, plan->d_rq, (hipStream_t)stream);
+    return launch_compose(plan->d_jobs, plan->d_runs, plan->nruns, plan->d_q, plan->d_rq, plan->d_gather, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -554,7 +646,7 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     MJX_HIP(hipMemcpyAsync(base, arena->pin, packet, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
 
     err = launch_compose(reinterpret_cast<const DevJob *>(base + o_jobs), reinterpret_cast<const Run *>(base + o_runs), (int)t.runs.size(),
-                         reinterpret_cast<const uint16_t *>(base + o_q), reinterpret_cast<const float *>(base + o_rq), s);
+                         reinterpret_cast<const uint16_t *>(base + o_q), reinterpret_cast<const float *>(base + o_rq), nullptr, s);
     if(err == MJX_OK) {
         k = 0;
         for(int i = 0; i < n && err == MJX_OK; ++i) {

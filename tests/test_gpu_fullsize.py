@@ -112,6 +112,48 @@ def test_full_batch_schedule_independence_and_oracle_samples(torch_mod, regime):
         del b
 
 
+@pytest.mark.parametrize("dims", [(256, 256, 512), (48, 80, 64), (16, 16, 32)])
+def test_density_grouping_is_only_a_schedule(torch_mod, dims):
+    """mjx_compose_plan_create_ex(MJX_PLAN_GROUP_BY_DENSITY): with the mixed regime A4 (every block its
+    own pattern) most octets are formed by density, through the gather table; with the uniform regimes
+    none is.  Either way the result equals the plan of consecutive octets and the oracle.  The small
+    rectangles are ragged (60 and 15 blocks; 4 and 1)."""
+    torch = torch_mod
+    from libmodjpeg_amd.batch import ComposeBatch
+    dw, dh, n = dims
+    for regime in (4, 2):
+        out = []
+        for group in (True, False):
+            b = ComposeBatch(n, 1920, 1080, dw, dh, 52, 26, regime)
+            b.fill_synthetic()
+            b.build_plan(group_by_density=group)
+            if not group or regime != 4:
+                assert b.gather_octets == 0
+            elif dw * dh >= 48 * 80:
+                assert b.gather_octets > 0.5 * b.total_blocks() / 8
+            b.run()
+            torch.cuda.synchronize()
+            out.append([_rect_view(b, c).clone() for c in range(3)])
+            outside = [b.coef[c][:, 0:4].clone() for c in range(3)]
+            fresh = ComposeBatch(n, 1920, 1080, dw, dh, 52, 26, regime)
+            fresh.fill_synthetic()
+            for c in range(3):
+                assert torch.equal(outside[c], fresh.coef[c][:, 0:4])  # nothing outside the rectangle moved
+            del fresh
+        for c in range(3):
+            assert torch.equal(out[0][c], out[1][c]), (regime, c)
+        for i in (0, n - 1):
+            for c in range(3):
+                bpr, _ = b.geo.array_dims[c]
+                row0, col0, rows, cols = b.rect[c]
+                want = np.empty((rows, cols * 64), np.int16)
+                for l in range(rows):
+                    want[l] = O.synth_coef(i, c, (row0 + l) * bpr + col0, cols, b.quant[c])
+                want = want.reshape(-1)
+                O.compose_rect(want, cols, 0, 0, rows, cols, b.quant[c], O.synth_tile(i, c, 0, rows * cols), O.synth_alpha(i, c, 0, rows * cols, regime))
+                assert np.array_equal(out[0][c][i].cpu().numpy().reshape(-1), want), (regime, i, c)
+
+
 def test_4k_fullframe_vs_oracle(torch_mod):
     """BASELINE configs[1]: one 3840x2160 4:2:0 image, full-frame alpha-masked dropon (194 400 blocks)"""
     torch = torch_mod
