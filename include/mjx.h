@@ -142,6 +142,34 @@ int mjx_free_host(void *host);
 int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, int row0, int col0, int rows, int cols,
                           const uint16_t *q, const float *tile, const float *alpha);
 
+/* ---- tile preparation on the device -----------------------------------
+ * What mj_compile_dropon does through libjpeg (reference dropon.c:325-576, image.c:257-347): the
+ * crop window of an overlay (3 bytes per pixel image, 3 bytes per pixel replicated alpha), placed at
+ * (off_x, off_y) inside a canvas of whole MCUs, becomes one contiguous array of prepared float
+ * tiles per component for image and alpha, identical to the ones the linked libjpeg (IJG 9d) would
+ * have produced.  Supported: 3 components; target YCbCr from an RGB or YCbCr overlay, target RGB
+ * from an RGB overlay; every component at full resolution or subsampled 2x2.  Anything else returns
+ * MJX_ERR_BAD_ARG before touching the device, and the caller prepares the tiles with libjpeg.
+ * Block counts: canvas = crop + offset rounded up to whole MCUs; component c has
+ * canvas_w / (8 * hmax / h_samp[c]) columns and canvas_h / (8 * vmax / v_samp[c]) rows. */
+#define MJX_PREP_SOURCE_RGB 1
+#define MJX_PREP_SOURCE_YCC 5 /* = MJ_COLORSPACE_RGB / MJ_COLORSPACE_YCC of libmodjpeg.h */
+#define MJX_PREP_TARGET_RGB 2
+#define MJX_PREP_TARGET_YCC 3 /* = JCS_RGB / JCS_YCbCr of jpeglib.h */
+typedef struct mjx_tileprep {
+    const unsigned char *image;      /* HOST: width x height pixels, 3 bytes each */
+    const unsigned char *alpha;      /* HOST: the same geometry, alpha replicated into 3 bytes */
+    int32_t              width, height;
+    int32_t              crop_x, crop_y, crop_w, crop_h; /* visible window of the overlay */
+    int32_t              off_x, off_y;                   /* its offset inside the first MCU */
+    int32_t              source, target;                 /* MJX_PREP_SOURCE_*, MJX_PREP_TARGET_* */
+    int32_t              ncomp;                          /* 3 */
+    int32_t              h_samp[4], v_samp[4];           /* the target image's sampling factors */
+    float               *tile[4];                        /* DEVICE out, rows*cols*64 floats each */
+    float               *alpha_tile[4];
+} mjx_tileprep_t;
+int mjx_tiles_prepare(const mjx_tileprep_t *p);
+
 /* ---- one (k,l) term: mj_convolve (reference convolve.c:29), test seam ------------------- */
 /* y[b][64] += V_k(H_l(x[b][64])) * w for b < nblocks; x, y DEVICE float arrays. */
 int mjx_convolve(const float *x, float *y, float w, int k, int l, int nblocks, mjx_stream_t stream);

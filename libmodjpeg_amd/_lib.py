@@ -70,6 +70,7 @@ SYMBOLS = [
     ("mjx_compose_rect_host", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("mjx_effect_dc_host", _i, [_vp, _i, _i, _i, ctypes.c_uint16, _i]),
     ("mjx_effect_zero_host", _i, [_vp, _i, _i, _i, _i]),
+    ("mjx_tiles_prepare", _i, [_vp]),
     ("mjx_convolve_host", _i, [_vp, _vp, ctypes.c_float, _i, _i, _i]),
     ("mjx_convolve", _i, [_vp, _vp, ctypes.c_float, _i, _i, _i, _vp]),
     ("mjx_effect_dc", _i, [ctypes.POINTER(DcJob), _i, _vp]),

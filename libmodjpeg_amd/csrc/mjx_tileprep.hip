@@ -1,0 +1,193 @@
+// mjx_tileprep.hip — overlay pixels -> prepared DCT-domain tiles on the device (SURVEY.md §8 row f-1,
+// second half).
+//
+// Replaces, for the cases listed below, what the reference does on every mj_compose call through
+// libjpeg (reference src/dropon.c:325-576 and src/image.c:257-347): pad the cropped overlay to whole
+// MCUs, compress image and alpha at quality 100 in the target's colour space and sampling, read the
+// coefficients back, convert to float tiles (alpha: DC + 1024, scaling c(i)c(j)/1020).  At quality
+// 100 every quantiser is 1, so a prepared coefficient is
+//          round_half_away( FDCT(samples) / 8 )
+// with FDCT the integer "islow" transform of the linked libjpeg (IJG 9d): jpeg_fdct_islow on 8x8
+// samples for a component at full resolution, jpeg_fdct_16x16 on 16x16 samples for a component
+// subsampled 2x2 (IJG >= 7 folds the downsampling into the transform).  Both are reproduced here as
+// the exact integer linear forms of mjx_fdct_tables.h, measured on the library and verified bit
+// for bit (tests/golden/make_fdct_tables.py, tests/test_fdct_tables.py); the RGB -> YCbCr
+// conversion is libjpeg's 16-bit fixed-point table arithmetic (jccolor.c: FIX(x) = x * 65536 + 0.5,
+// ONE_HALF rounding for Y, CBCR_OFFSET + ONE_HALF - 1 for the chroma).  The Huffman round trip
+// the reference makes is lossless and is simply not made.  Parity: the tiles equal the ones the
+// reference's mj_compile_dropon prepared (tests/test_dropin_shim.py, golden compose_kat.npz) and
+// the host path's on random overlays, as float bit patterns.
+//
+// Supported: three components, target YCbCr (overlay RGB: converted; overlay YCbCr: as is) or RGB
+// (overlay RGB), every component either at full resolution or subsampled 2x2.  Everything else
+// returns MJX_ERR_BAD_ARG and the caller prepares the tiles with libjpeg as before.
+//
+// One wavefront per output block: the N x N samples go to LDS (colour conversion on the way),
+// pass 1 along the rows (N x 8 outputs), pass 2 down the columns (8 x 8), quantisation, float.
+#include "mjx_internal.hpp"
+
+#include "mjx_fdct_tables.h"
+
+#include <string.h>
+
+namespace mjx {
+
+struct PrepComp {
+    float  *tile, *alpha;   // DEVICE out: rows * cols blocks of 64 floats
+    int32_t rows, cols;     // blocks
+    int32_t n;              // samples per block edge: 8 or 16
+    int32_t first;          // index of this component's first block in the launch
+};
+
+struct PrepJob {
+    const unsigned char *image, *alpha; // DEVICE: the crop window, 3 bytes per pixel, crop_w per row
+    int32_t  crop_w, crop_h, off_x, off_y;
+    int32_t  convert;                   // 1: RGB -> YCbCr
+    int32_t  nblocks;                   // all components
+    PrepComp comp[3];
+};
+
+// libjpeg jccolor.c rgb_ycc_convert, SCALEBITS 16
+__device__ __forceinline__ int ycc_of_rgb(int c, int r, int g, int b) {
+    constexpr int kHalf = 1 << 15, kOffset = 128 << 16;
+    if(c == 0) return (19595 * r + 38470 * g + 7471 * b + kHalf) >> 16;
+    if(c == 1) return (-11059 * r - 21709 * g + 32768 * b + kOffset + kHalf - 1) >> 16;
+    return (32768 * r - 27439 * g - 5329 * b + kOffset + kHalf - 1) >> 16;
+}
+
+// alpha tile scaling, the reference's own double expressions (dropon.c:548-566)
+__device__ __forceinline__ double alpha_scale(int k, int l) {
+    const double c0 = 0.3535534, c1 = 0.5;
+    return (k == 0 ? c0 : c1) * (l == 0 ? c0 : c1) / 1020.0;
+}
+
+template <int N> __device__ __forceinline__ void prep_block(const PrepJob &job, int c, int kind, int brow, int bcol, float *out, int lane, int (*s)[16], int (*d1)[8]) {
+    const int *M1 = N == 8 ? &kFdct8M1[0][0] : &kFdct16M1[0][0], *M2 = N == 8 ? &kFdct8M2[0][0] : &kFdct16M2[0][0];
+    const int *B1 = N == 8 ? kFdct8B1 : kFdct16B1, *S1 = N == 8 ? kFdct8S1 : kFdct16S1;
+    const int *B2 = N == 8 ? kFdct8B2 : kFdct16B2, *S2 = N == 8 ? kFdct8S2 : kFdct16S2;
+    const unsigned char *pix = kind == 0 ? job.image : job.alpha;
+    // samples: canvas pixel (x, y) is overlay window pixel (x - off_x, y - off_y), zero outside it
+    for(int i = lane; i < N * N; i += 64) {
+        const int sy = i / N, sx = i - sy * N;
+        const int wx = bcol * N + sx - job.off_x, wy = brow * N + sy - job.off_y;
+        int r = 0, g = 0, b = 0;
+        if(wx >= 0 && wx < job.crop_w && wy >= 0 && wy < job.crop_h) {
+            const unsigned char *p = pix + ((size_t)wy * job.crop_w + wx) * 3;
+            r = p[0]; g = p[1]; b = p[2];
+        }
+        // the alpha canvas is never converted (reference dropon.c:389-402 hands it over in the target's own space)
+        s[sy][sx] = (kind == 0 && job.convert) ? ycc_of_rgb(c, r, g, b) : (c == 0 ? r : (c == 1 ? g : b));
+    }
+    __syncthreads();
+    for(int i = lane; i < N * 8; i += 64) { // pass 1: row r, output l
+        const int r = i >> 3, l = i & 7;
+        int       acc = B1[l];
+#pragma unroll
+        for(int u = 0; u < N; ++u) acc += M1[l * N + u] * s[r][u];
+        d1[r][l] = acc >> S1[l];
+    }
+    __syncthreads();
+    {
+        const int k = lane >> 3, l = lane & 7; // pass 2: output (k, l)
+        int       acc = B2[k];
+#pragma unroll
+        for(int r = 0; r < N; ++r) acc += M2[k * N + r] * d1[r][l];
+        acc >>= S2[k];
+        // quantiser 1, divisor 8 (jcdctmgr.c forward_DCT): round half away from zero
+        int q = acc < 0 ? -((-acc + 4) >> 3) : ((acc + 4) >> 3);
+        float v;
+        if(kind == 0) {
+            v = (float)(int)(short)q; // dropon.c:476-485
+        }
+        else {
+            if((k | l) == 0) q = (int)(short)(unsigned short)((unsigned)q + 1024u); // dropon.c:542 on a JCOEF
+            v = (float)((double)(float)(int)(short)q * alpha_scale(k, l));             // dropon.c:548-566
+        }
+        out[k * 8 + l] = v;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void tileprep_kernel(PrepJob job) {
+    __shared__ int s[16][16];
+    __shared__ int d1[16][8];
+    const int lane = threadIdx.x;
+    int       id = blockIdx.x;
+    const int kind = id >= job.nblocks ? 1 : 0; // 0 image, 1 alpha
+    id -= kind * job.nblocks;
+    int c = 0;
+    if(id >= job.comp[1].first) c = 1;
+    if(id >= job.comp[2].first) c = 2;
+    const PrepComp pc = job.comp[c];
+    const int      blk = id - pc.first, brow = blk / pc.cols, bcol = blk - brow * pc.cols;
+    float         *out = (kind == 0 ? pc.tile : pc.alpha) + (size_t)blk * 64;
+    if(pc.n == 8) prep_block<8>(job, c, kind, brow, bcol, out, lane, s, d1);
+    else prep_block<16>(job, c, kind, brow, bcol, out, lane, s, d1);
+}
+
+} // namespace mjx
+
+using namespace mjx;
+
+extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
+    if(p == nullptr) return MJX_ERR_NULL_DATA;
+    if(p->image == nullptr || p->alpha == nullptr) return MJX_ERR_NULL_DATA;
+    if(p->ncomp != 3 || p->crop_w <= 0 || p->crop_h <= 0 || p->off_x < 0 || p->off_y < 0 || p->crop_x < 0 || p->crop_y < 0) return MJX_ERR_BAD_ARG;
+    if(p->crop_x + (int64_t)p->crop_w > p->width || p->crop_y + (int64_t)p->crop_h > p->height) return MJX_ERR_BAD_ARG;
+    int convert;
+    if(p->target == MJX_PREP_TARGET_YCC && p->source == MJX_PREP_SOURCE_RGB) convert = 1;
+    else if((p->target == MJX_PREP_TARGET_YCC && p->source == MJX_PREP_SOURCE_YCC) || (p->target == MJX_PREP_TARGET_RGB && p->source == MJX_PREP_SOURCE_RGB)) convert = 0;
+    else return MJX_ERR_BAD_ARG;
+    int hmax = 1, vmax = 1;
+    for(int c = 0; c < 3; ++c) {
+        if(p->h_samp[c] < 1 || p->v_samp[c] < 1) return MJX_ERR_BAD_ARG;
+        hmax = p->h_samp[c] > hmax ? p->h_samp[c] : hmax;
+        vmax = p->v_samp[c] > vmax ? p->v_samp[c] : vmax;
+    }
+    // whole MCUs, including the offset of the overlay inside its first MCU (dropon.c:340-350)
+    const int64_t mcu_w = 8 * hmax, mcu_h = 8 * vmax;
+    const int64_t W = (p->crop_w + (int64_t)p->off_x + mcu_w - 1) / mcu_w * mcu_w, H = (p->crop_h + (int64_t)p->off_y + mcu_h - 1) / mcu_h * mcu_h;
+    PrepJob job;
+    memset(&job, 0, sizeof(job));
+    int64_t total = 0;
+    for(int c = 0; c < 3; ++c) {
+        if(hmax % p->h_samp[c] != 0 || vmax % p->v_samp[c] != 0) return MJX_ERR_BAD_ARG;
+        const int fx = hmax / p->h_samp[c], fy = vmax / p->v_samp[c];
+        if(fx != fy || (fx != 1 && fx != 2)) return MJX_ERR_BAD_ARG; // 8x8 or 16x16 transforms only
+        if(p->tile[c] == nullptr || p->alpha_tile[c] == nullptr) return MJX_ERR_NULL_DATA;
+        job.comp[c].tile = p->tile[c];
+        job.comp[c].alpha = p->alpha_tile[c];
+        job.comp[c].n = 8 * fx;
+        job.comp[c].cols = (int32_t)(W / (8 * fx));
+        job.comp[c].rows = (int32_t)(H / (8 * fy));
+        job.comp[c].first = (int32_t)total;
+        total += (int64_t)job.comp[c].rows * job.comp[c].cols;
+    }
+    if(total * 2 > 0x7FFFFFFFll) return MJX_ERR_BAD_ARG;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+
+    // the crop window of image and alpha, packed, through the leased arena
+    const size_t row = (size_t)p->crop_w * 3, win = row * (size_t)p->crop_h, win_al = (win + 255) & ~(size_t)255;
+    ArenaLease   arena;
+    int          err = arena->prepare(2 * win_al, 2 * win_al);
+    if(err != MJX_OK) return err;
+    for(int y = 0; y < p->crop_h; ++y) {
+        const size_t src = ((size_t)(y + p->crop_y) * (size_t)p->width + (size_t)p->crop_x) * 3;
+        memcpy(arena->pin + (size_t)y * row, p->image + src, row);
+        memcpy(arena->pin + win_al + (size_t)y * row, p->alpha + src, row);
+    }
+    hipStream_t s = arena->stream;
+    MJX_HIP(hipMemcpyAsync(arena->dev, arena->pin, win_al + win, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    job.image = reinterpret_cast<const unsigned char *>(arena->dev);
+    job.alpha = reinterpret_cast<const unsigned char *>(arena->dev) + win_al;
+    job.crop_w = p->crop_w;
+    job.crop_h = p->crop_h;
+    job.off_x = p->off_x;
+    job.off_y = p->off_y;
+    job.convert = convert;
+    job.nblocks = (int32_t)total;
+    hipLaunchKernelGGL(tileprep_kernel, dim3((unsigned)(2 * total)), dim3(64), 0, s, job);
+    err = check_hip(hipGetLastError(), "tileprep_kernel launch", MJX_ERR_LAUNCH);
+    const int serr = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
+    return err != MJX_OK ? err : serr;
+}

@@ -82,6 +82,7 @@ typedef struct mjh_shadow {
 void          mjh_set_device_resident(int on);
 int           mjh_device_count(void);
 int           mjh_use_device(int ordinal); /* the calling thread's GPU from now on; MJ_OK or MJ_ERR_MEMORY */
+int           mjh_download(void *host, const void *dev, size_t bytes);
 int           mjh_device_resident(void);
 mjh_shadow_t *mjh_shadow_of(const mj_jpeg_t *m); /* NULL: an ordinary host image */
 mjh_shadow_t *mjh_shadow_create(mj_jpeg_t *m);

@@ -6,6 +6,9 @@
  *        reads the image (for its colour space / sampling), builds a dropon from raw pixels and
  *        writes the tiles mj_compile_dropon() prepares: per component int32 {wib, hib} then
  *        image tiles, then alpha tiles (float32).
+ *   mjhost_probe tilesgpu <same arguments as tiles>
+ *        the same tiles as they come out of the device-resident tile cache on a miss, i.e. prepared
+ *        on the GPU when the combination is one it reproduces (prints "gpu" or "host"), downloaded.
  *   mjhost_probe roundtrip <image.jpg> <out.bin>
  *        read -> write (optimised, progressive) -> read again; writes both coefficient sets.
  *   mjhost_probe stress <image.jpg> <dropon.png> <threads> <iterations>
@@ -350,6 +353,55 @@ int main(int argc, char **argv) {
         }
         fclose(f);
         mj_free_compileddropon(&cd);
+        mj_free_dropon(&d);
+        mj_free_jpeg(&m);
+        free(raw);
+        return 0;
+    }
+    if(argc >= 2 && strcmp(argv[1], "tilesgpu") == 0 && argc == 15) {
+        /* drop-in internals (tilecache.c, libmjx) */
+        struct mjh_tiles;
+        extern int  mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, mj_sampling_t *s, int bx, int by, int cx, int cy, int cw, int ch);
+        extern void mjh_tiles_release(struct mjh_tiles *t);
+        extern int  mjh_tiles_ncomp(const struct mjh_tiles *t);
+        extern void mjh_tiles_component(const struct mjh_tiles *t, int c, int *rows, int *cols, const float **dev_tile, const float **dev_alpha);
+        extern int  mjh_download(void *host, const void *dev, size_t bytes);
+        extern int  mjh_tiles_gpu_prepared;
+        mj_jpeg_t         m;
+        mj_dropon_t       d;
+        struct mjh_tiles *t = NULL;
+        int               w = atoi(argv[4]), h = atoi(argv[5]), c, rv;
+        size_t            bpp = (atoi(argv[6]) == MJ_COLORSPACE_RGBA || atoi(argv[6]) == MJ_COLORSPACE_YCCA) ? 4 : 3;
+        unsigned char    *raw = malloc((size_t)w * h * bpp);
+        FILE             *f = fopen(argv[3], "rb");
+        if(f == NULL || fread(raw, 1, (size_t)w * h * bpp, f) != (size_t)w * h * bpp) return 3;
+        fclose(f);
+        mj_init_jpeg(&m);
+        mj_init_dropon(&d);
+        if((rv = mj_read_jpeg_from_file(&m, argv[2], 0)) != MJ_OK) return 10 + rv;
+        if((rv = mj_read_dropon_from_raw(&d, raw, (unsigned)atoi(argv[6]), w, h, (short)atoi(argv[7]))) != MJ_OK) return 20 + rv;
+        rv = mjh_tiles_acquire(&t, &d, m.cinfo.jpeg_color_space, &m.sampling, atoi(argv[8]), atoi(argv[9]), atoi(argv[10]), atoi(argv[11]), atoi(argv[12]), atoi(argv[13]));
+        if(rv != MJ_OK) return 30 + rv;
+        if(t == NULL) return 40;
+        f = fopen(argv[14], "wb");
+        for(c = 0; c < mjh_tiles_ncomp(t); c++) {
+            int          dims[2], rows, cols;
+            const float *dt, *da;
+            float       *buf;
+            mjh_tiles_component(t, c, &rows, &cols, &dt, &da);
+            dims[0] = cols;
+            dims[1] = rows;
+            buf = malloc((size_t)rows * cols * 256 + 16);
+            fwrite(dims, sizeof(int), 2, f);
+            if(mjh_download(buf, dt, (size_t)rows * cols * 256) != 0) return 41;
+            fwrite(buf, 256, (size_t)rows * cols, f);
+            if(mjh_download(buf, da, (size_t)rows * cols * 256) != 0) return 42;
+            fwrite(buf, 256, (size_t)rows * cols, f);
+            free(buf);
+        }
+        fclose(f);
+        printf("%s\n", mjh_tiles_gpu_prepared > 0 ? "gpu" : "host");
+        mjh_tiles_release(t);
         mj_free_dropon(&d);
         mj_free_jpeg(&m);
         free(raw);

@@ -34,6 +34,8 @@ void mjh_set_device_resident(int on) { g_resident = on ? 1 : 0; }
  * (image i -> device, one host thread + stream per device, no peer access) */
 int mjh_device_count(void) { return mjx_device_count(); }
 int mjh_use_device(int ordinal) { return mjh_from_mjx(mjx_set_device(ordinal)); }
+/* test support (mjhost_probe): device -> host copy without linking the caller against libmjx_hip */
+int mjh_download(void *host, const void *dev, size_t bytes) { return mjh_from_mjx(mjx_memcpy_d2h(host, dev, bytes, NULL)); }
 
 int mjh_device_resident(void) {
     if(g_resident < 0) {

@@ -168,6 +168,69 @@ static int contents_fill(struct mjh_tiles *t, const mj_compileddropon_t *cd, con
     return MJX_OK;
 }
 
+/* MJ_GPU_TILEPREP=0: always prepare tiles with libjpeg on the host */
+static int device_prep_enabled(void) {
+    const char *e = getenv("MJ_GPU_TILEPREP");
+    return !(e != NULL && e[0] == '0');
+}
+
+/* the tiles of a miss prepared on the device (mjx_tiles_prepare: forward DCT, colour conversion and
+ * DCT-scaled chroma of the linked libjpeg as exact integer forms), nothing but the overlay's visible
+ * pixels crossing PCIe.  MJX_ERR_BAD_ARG: this overlay / target combination is libjpeg's (gray,
+ * CMYK, 4:2:2 ...), the caller takes the host path. */
+static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_sampling_t *s, int bx, int by, int cx, int cy, int cw,
+                                int ch) {
+    const size_t   row = (size_t)cw * 3;
+    mjx_tileprep_t p;
+    int            c, y, e, w, h;
+    if(cs != JCS_YCbCr && cs != JCS_RGB) return MJX_ERR_BAD_ARG;
+    if(d->colorspace != MJ_COLORSPACE_RGB && d->colorspace != MJ_COLORSPACE_YCC) return MJX_ERR_BAD_ARG;
+    if(s->h_factor <= 0 || s->v_factor <= 0) return MJX_ERR_BAD_ARG;
+    memset(&p, 0, sizeof(p));
+    p.image = d->image;
+    p.alpha = d->alpha;
+    p.width = d->width;
+    p.height = d->height;
+    p.crop_x = cx; p.crop_y = cy; p.crop_w = cw; p.crop_h = ch;
+    p.off_x = bx; p.off_y = by;
+    p.source = d->colorspace == MJ_COLORSPACE_RGB ? MJX_PREP_SOURCE_RGB : MJX_PREP_SOURCE_YCC;
+    p.target = cs == JCS_RGB ? MJX_PREP_TARGET_RGB : MJX_PREP_TARGET_YCC;
+    p.ncomp = 3;
+    w = (cw + bx + s->h_factor - 1) / s->h_factor * s->h_factor; /* whole MCUs (dropon.c:340-350) */
+    h = (ch + by + s->v_factor - 1) / s->v_factor * s->v_factor;
+    t->ncomp = 3;
+    t->bytes = 0;
+    for(c = 0; c < 3; c++) {
+        const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
+        size_t    bytes;
+        if(hs < 1 || vs < 1 || s->max_h_samp_factor % hs != 0 || s->max_v_samp_factor % vs != 0) return MJX_ERR_BAD_ARG;
+        if(s->max_h_samp_factor / hs != s->max_v_samp_factor / vs || s->max_h_samp_factor / hs > 2) return MJX_ERR_BAD_ARG;
+        p.h_samp[c] = hs;
+        p.v_samp[c] = vs;
+        t->cols[c] = w / (8 * (s->max_h_samp_factor / hs));
+        t->rows[c] = h / (8 * (s->max_v_samp_factor / vs));
+        bytes = (size_t)t->rows[c] * (size_t)t->cols[c] * 64 * sizeof(float);
+        if((e = mjx_malloc((void **)&t->dev_tile[c], bytes)) != MJX_OK) return e;
+        if((e = mjx_malloc((void **)&t->dev_alpha[c], bytes)) != MJX_OK) return e;
+        p.tile[c] = t->dev_tile[c];
+        p.alpha_tile[c] = t->dev_alpha[c];
+        t->bytes += 2 * bytes;
+    }
+    if((e = mjx_tiles_prepare(&p)) != MJX_OK) return e;
+    t->win_bytes = 2 * row * (size_t)ch;
+    t->window = (unsigned char *)malloc(t->win_bytes ? t->win_bytes : 1);
+    if(t->window == NULL) return MJX_ERR_MEMORY;
+    for(y = 0; y < ch; y++) {
+        const size_t off = ((size_t)(y + cy) * (size_t)d->width + (size_t)cx) * 3;
+        memcpy(t->window + (size_t)y * row, d->image + off, row);
+        memcpy(t->window + ((size_t)ch + (size_t)y) * row, d->alpha + off, row);
+    }
+    t->bytes += t->win_bytes;
+    return MJX_OK;
+}
+
+int mjh_tiles_gpu_prepared; /* statistics: misses whose tiles were prepared on the device */
+
 int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, mj_sampling_t *s, int bx, int by, int cx, int cy, int cw, int ch) {
     uint64_t            key[2];
     int                 params[16], device = 0;
@@ -195,15 +258,26 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
     }
     pthread_mutex_unlock(&g_lock);
 
-    /* miss: prepare (libjpeg work) and upload with no lock held, then publish */
-    rv = mj_compile_dropon(&cd, d, cs, s, bx, by, cx, cy, cw, ch);
-    if(rv != MJ_OK) return rv;
+    /* miss: prepare with no lock held, then publish.  On the device when the combination is one it
+     * reproduces (the usual colour cases); else by libjpeg on the host, uploaded afterwards */
     memset(&fresh, 0, sizeof(fresh));
-    rv = mjh_from_mjx(contents_fill(&fresh, &cd, d, cx, cy, cw, ch));
-    mj_free_compileddropon(&cd);
-    if(rv != MJ_OK) {
+    rv = device_prep_enabled() ? contents_fill_device(&fresh, d, cs, s, bx, by, cx, cy, cw, ch) : MJX_ERR_BAD_ARG;
+    if(rv == MJX_OK) {
+        __sync_fetch_and_add(&mjh_tiles_gpu_prepared, 1);
+        rv = MJ_OK;
+    }
+    else {
+        const int declined = rv == MJX_ERR_BAD_ARG;
         contents_free(&fresh);
-        return rv;
+        if(!declined) return mjh_from_mjx(rv);
+        rv = mj_compile_dropon(&cd, d, cs, s, bx, by, cx, cy, cw, ch);
+        if(rv != MJ_OK) return rv;
+        rv = mjh_from_mjx(contents_fill(&fresh, &cd, d, cx, cy, cw, ch));
+        mj_free_compileddropon(&cd);
+        if(rv != MJ_OK) {
+            contents_free(&fresh);
+            return rv;
+        }
     }
     fresh.key[0] = key[0];
     fresh.key[1] = key[1];

@@ -122,6 +122,90 @@ def test_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case):
     assert off == len(buf)
 
 
+def _read_tiles(path):
+    buf = open(path, "rb").read()
+    off, out = 0, []
+    while off < len(buf):
+        wib, hib = np.frombuffer(buf, np.int32, 2, off)
+        off += 8
+        n = int(wib) * int(hib) * 64
+        tile = np.frombuffer(buf, np.float32, n, off)
+        off += n * 4
+        alpha = np.frombuffer(buf, np.float32, n, off)
+        off += n * 4
+        out.append((int(hib), int(wib), tile, alpha))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["tl", "br", "crop"])
+def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case):
+    """tiles prepared ON THE DEVICE on a tile-cache miss (mjx_tiles_prepare: libjpeg 9d's forward DCTs
+    as exact integer forms, its colour conversion, DCT-scaled chroma) == the tiles the reference's
+    mj_compile_dropon prepared through libjpeg, as float bit patterns: image tiles, alpha DC offset
+    and scaling, padding, in-MCU offsets"""
+    g = np.load(os.path.join(golden_dir, "compose_kat.npz"))
+    w, h, cs, blend = [int(v) for v in g[f"{case}_dropon_meta"]]
+    img = g[f"{case}_dropon_image"].reshape(h, w, 3)
+    alp = g[f"{case}_dropon_alpha"].reshape(h, w, 3)
+    rgba = np.concatenate([img, alp[:, :, :1]], axis=2).astype(np.uint8)
+    raw = tmp_path / "raw.bin"
+    rgba.tofile(raw)
+    bx, by, cx, cy, cw, ch = _placement(g, case)
+    out = tmp_path / "tiles.bin"
+    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "tilesgpu", os.path.join(IMAGES, "image.jpg"), str(raw), str(w), str(h), "2", "255",
+                          str(bx), str(by), str(cx), str(cy), str(cw), str(ch), str(out)], capture_output=True, text=True)
+    assert res.returncode == 0 and res.stdout.strip() == "gpu", (res.returncode, res.stdout, res.stderr[-300:])
+    for c, (hib, wib, tile, alpha) in enumerate(_read_tiles(out)):
+        rows, cols = int(g[f"{case}_rect_c{c}"][2]), int(g[f"{case}_rect_c{c}"][3])
+        assert (hib, wib) == (rows, cols)
+        assert np.array_equal(tile.view(np.uint32), g[f"{case}_tile_c{c}"].reshape(-1).view(np.uint32)), (case, c)
+        assert np.array_equal(alpha.view(np.uint32), g[f"{case}_alpha_c{c}"].reshape(-1).view(np.uint32)), (case, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampling,expect", [("420", "gpu"), ("444", "gpu"), ("422", "host"), ("440", "host")])
+def test_gpu_tile_preparation_equals_libjpeg_on_random_overlays(shim, tmp_path, sampling, expect):
+    """device-prepared tiles == libjpeg-prepared tiles (the drop-in's host path, itself pinned to the
+    reference) on random overlays: RGB / RGBA / YCC / YCCA pixels, odd sizes, every kind of in-MCU
+    offset and crop, noise / smooth / saturated contents, translucent blends; 4:2:0 and 4:4:4 targets
+    are prepared on the device, 4:2:2 and 4:4:0 (libjpeg's 16x8 / 8x16 transforms) are declined and
+    come from the host path"""
+    rng = np.random.default_rng(int(sampling))
+    target = str(tmp_path / "target.jpg")
+    _make_input(target, ("200", "120"), sampling)
+    probe = os.path.join(HOST, "mjhost_probe")
+    for trial in range(14):
+        w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        cs = [1, 2, 5, 6][trial % 4]
+        bpp = 4 if cs in (2, 6) else 3
+        kind = trial % 3
+        if kind == 0:
+            pix = rng.integers(0, 256, (h, w, bpp), dtype=np.uint8)
+        elif kind == 1:
+            ramp = np.add.outer(np.arange(h) * int(rng.integers(0, 5)), np.arange(w) * int(rng.integers(0, 5)))[:, :, None] + rng.integers(0, 40, (1, 1, bpp))
+            pix = np.clip(ramp, 0, 255).astype(np.uint8)
+        else:
+            pix = rng.choice(np.array([0, 255], np.uint8), (h, w, bpp))
+        raw = tmp_path / f"raw{trial}.bin"
+        pix.tofile(raw)
+        cx, cy = int(rng.integers(0, w)), int(rng.integers(0, h))
+        cw, ch = int(rng.integers(1, w - cx + 1)), int(rng.integers(1, h - cy + 1))
+        bx, by = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+        blend = [255, 128, 1][trial % 3]
+        args = [target, str(raw), str(w), str(h), str(cs), str(blend), str(bx), str(by), str(cx), str(cy), str(cw), str(ch)]
+        a, b = tmp_path / f"host{trial}.bin", tmp_path / f"gpu{trial}.bin"
+        subprocess.check_call([probe, "tiles", *args, str(a)])
+        res = subprocess.run([probe, "tilesgpu", *args, str(b)], capture_output=True, text=True)
+        assert res.returncode == 0 and res.stdout.strip() == expect, (trial, res.returncode, res.stdout, res.stderr[-300:])
+        ta, tb = _read_tiles(a), _read_tiles(b)
+        assert len(ta) == len(tb) == 3
+        for c in range(3):
+            assert ta[c][:2] == tb[c][:2], (trial, c)
+            assert np.array_equal(ta[c][2].view(np.uint32), tb[c][2].view(np.uint32)), (trial, c, "image", args)
+            assert np.array_equal(ta[c][3].view(np.uint32), tb[c][3].view(np.uint32)), (trial, c, "alpha", args)
+
+
 def test_block_loops_fail_loudly_without_device(shim):
     import torch
     if torch.cuda.is_available():
