@@ -16,7 +16,30 @@
 
 namespace mjx {
 
+// MJX_INJECT_FAILURE="<substring>[:N]" (tests only): the N-th (default first) successful HIP call whose
+// description contains the substring is reported as failed, once.  This is how the early-return
+// paths of the host-buffer entry points are exercised (work queued on the arena's stream, arena
+// handed back): tests/test_gpu_parity.py::test_host_buffer_call_survives_an_injected_failure.
+static bool injected_failure(const char *what) {
+    static const char *pattern = getenv("MJX_INJECT_FAILURE");
+    static std::atomic<int> countdown{[] {
+        const char *p = getenv("MJX_INJECT_FAILURE");
+        const char *c = p ? strrchr(p, ':') : nullptr;
+        return c ? atoi(c + 1) : 1;
+    }()};
+    if(pattern == nullptr) return false;
+    static const size_t len = strrchr(pattern, ':') ? (size_t)(strrchr(pattern, ':') - pattern) : strlen(pattern);
+    if(len == 0 || strlen(what) < len) return false;
+    bool match = false;
+    for(const char *w = what; *w && !match; ++w) match = strncmp(w, pattern, len) == 0;
+    return match && countdown.fetch_sub(1) == 1;
+}
+
 int check_hip(hipError_t e, const char *what, int err_code) {
+    if(e == hipSuccess && injected_failure(what)) {
+        fprintf(stderr, "libmjx_hip: %s: failure injected (MJX_INJECT_FAILURE)\n", what);
+        return err_code;
+    }
     if(e == hipSuccess) return MJX_OK;
     fprintf(stderr, "libmjx_hip: %s failed: %s\n", what, hipGetErrorString(e));
     return err_code;

@@ -8,8 +8,9 @@
 // 100 every quantiser is 1, so a prepared coefficient is
 //          round_half_away( FDCT(samples) / 8 )
 // with FDCT the integer "islow" transform of the linked libjpeg (IJG 9d): jpeg_fdct_islow on 8x8
-// samples for a component at full resolution, jpeg_fdct_16x16 on 16x16 samples for a component
-// subsampled 2x2 (IJG >= 7 folds the downsampling into the transform).  Both are reproduced here as
+// samples for a component at full resolution, jpeg_fdct_16x16 / _16x8 / _8x16 on 16x16 / 16x8 /
+// 8x16 samples for a component subsampled 2:1 in both / the horizontal / the vertical direction
+// (IJG >= 7 folds the downsampling into the transform).  They are reproduced here as
 // the exact integer linear forms of mjx_fdct_tables.h, measured on the library and verified bit
 // for bit (tests/golden/make_fdct_tables.py, tests/test_fdct_tables.py); the RGB -> YCbCr
 // conversion is libjpeg's 16-bit fixed-point table arithmetic (jccolor.c: FIX(x) = x * 65536 + 0.5,
@@ -19,11 +20,12 @@
 // the host path's on random overlays, as float bit patterns.
 //
 // Supported: three components, target YCbCr (overlay RGB: converted; overlay YCbCr: as is) or RGB
-// (overlay RGB), every component either at full resolution or subsampled 2x2.  Everything else
-// returns MJX_ERR_BAD_ARG and the caller prepares the tiles with libjpeg as before.
+// (overlay RGB), every component at full resolution or subsampled 2:1 in either direction (4:4:4,
+// 4:2:2, 4:4:0, 4:2:0).  Everything else returns MJX_ERR_BAD_ARG and the caller prepares the tiles
+// with libjpeg as before.
 //
-// One wavefront per output block: the N x N samples go to LDS (colour conversion on the way),
-// pass 1 along the rows (N x 8 outputs), pass 2 down the columns (8 x 8), quantisation, float.
+// One wavefront per output block: the C x R samples go to LDS (colour conversion on the way),
+// pass 1 along the rows (R x 8 outputs), pass 2 down the columns (8 x 8), quantisation, float.
 #include "mjx_internal.hpp"
 
 #include "mjx_fdct_tables.h"
@@ -35,7 +37,7 @@ namespace mjx {
 struct PrepComp {
     float  *tile, *alpha;   // DEVICE out: rows * cols blocks of 64 floats
     int32_t rows, cols;     // blocks
-    int32_t n;              // samples per block edge: 8 or 16
+    int32_t nx, ny;         // samples per block: 8 or 16 in each direction
     int32_t first;          // index of this component's first block in the launch
 };
 
@@ -61,15 +63,30 @@ __device__ __forceinline__ double alpha_scale(int k, int l) {
     return (k == 0 ? c0 : c1) * (l == 0 ? c0 : c1) / 1020.0;
 }
 
-template <int N> __device__ __forceinline__ void prep_block(const PrepJob &job, int c, int kind, int brow, int bcol, float *out, int lane, int (*s)[16], int (*d1)[8]) {
-    const int *M1 = N == 8 ? &kFdct8M1[0][0] : &kFdct16M1[0][0], *M2 = N == 8 ? &kFdct8M2[0][0] : &kFdct16M2[0][0];
-    const int *B1 = N == 8 ? kFdct8B1 : kFdct16B1, *S1 = N == 8 ? kFdct8S1 : kFdct16S1;
-    const int *B2 = N == 8 ? kFdct8B2 : kFdct16B2, *S2 = N == 8 ? kFdct8S2 : kFdct16S2;
+// the tables of the C x R transform
+template <int C, int R> struct Fdct;
+#define MJX_FDCT(C, R)                                                                             \
+    template <> struct Fdct<C, R> {                                                                \
+        static __device__ __forceinline__ const int *M1() { return &kFdct##C##x##R##M1[0][0]; }    \
+        static __device__ __forceinline__ const int *M2() { return &kFdct##C##x##R##M2[0][0]; }    \
+        static __device__ __forceinline__ const int *B1() { return kFdct##C##x##R##B1; }           \
+        static __device__ __forceinline__ const int *S1() { return kFdct##C##x##R##S1; }           \
+        static __device__ __forceinline__ const int *B2() { return kFdct##C##x##R##B2; }           \
+        static __device__ __forceinline__ const int *S2() { return kFdct##C##x##R##S2; }           \
+    }
+MJX_FDCT(8, 8);
+MJX_FDCT(16, 16);
+MJX_FDCT(16, 8);
+MJX_FDCT(8, 16);
+
+template <int C, int R> __device__ __forceinline__ void prep_block(const PrepJob &job, int c, int kind, int brow, int bcol, float *out, int lane, int (*s)[16], int (*d1)[8]) {
+    using T = Fdct<C, R>;
+    const int *M1 = T::M1(), *M2 = T::M2(), *B1 = T::B1(), *S1 = T::S1(), *B2 = T::B2(), *S2 = T::S2();
     const unsigned char *pix = kind == 0 ? job.image : job.alpha;
     // samples: canvas pixel (x, y) is overlay window pixel (x - off_x, y - off_y), zero outside it
-    for(int i = lane; i < N * N; i += 64) {
-        const int sy = i / N, sx = i - sy * N;
-        const int wx = bcol * N + sx - job.off_x, wy = brow * N + sy - job.off_y;
+    for(int i = lane; i < C * R; i += 64) {
+        const int sy = i / C, sx = i - sy * C;
+        const int wx = bcol * C + sx - job.off_x, wy = brow * R + sy - job.off_y;
         int r = 0, g = 0, b = 0;
         if(wx >= 0 && wx < job.crop_w && wy >= 0 && wy < job.crop_h) {
             const unsigned char *p = pix + ((size_t)wy * job.crop_w + wx) * 3;
@@ -79,11 +96,11 @@ template <int N> __device__ __forceinline__ void prep_block(const PrepJob &job, 
         s[sy][sx] = (kind == 0 && job.convert) ? ycc_of_rgb(c, r, g, b) : (c == 0 ? r : (c == 1 ? g : b));
     }
     __syncthreads();
-    for(int i = lane; i < N * 8; i += 64) { // pass 1: row r, output l
+    for(int i = lane; i < R * 8; i += 64) { // pass 1: row r, output l
         const int r = i >> 3, l = i & 7;
         int       acc = B1[l];
 #pragma unroll
-        for(int u = 0; u < N; ++u) acc += M1[l * N + u] * s[r][u];
+        for(int u = 0; u < C; ++u) acc += M1[l * C + u] * s[r][u];
         d1[r][l] = acc >> S1[l];
     }
     __syncthreads();
@@ -91,7 +108,7 @@ template <int N> __device__ __forceinline__ void prep_block(const PrepJob &job, 
         const int k = lane >> 3, l = lane & 7; // pass 2: output (k, l)
         int       acc = B2[k];
 #pragma unroll
-        for(int r = 0; r < N; ++r) acc += M2[k * N + r] * d1[r][l];
+        for(int r = 0; r < R; ++r) acc += M2[k * R + r] * d1[r][l];
         acc >>= S2[k];
         // quantiser 1, divisor 8 (jcdctmgr.c forward_DCT): round half away from zero
         int q = acc < 0 ? -((-acc + 4) >> 3) : ((acc + 4) >> 3);
@@ -121,8 +138,10 @@ __global__ __launch_bounds__(64) void tileprep_kernel(PrepJob job) {
     const PrepComp pc = job.comp[c];
     const int      blk = id - pc.first, brow = blk / pc.cols, bcol = blk - brow * pc.cols;
     float         *out = (kind == 0 ? pc.tile : pc.alpha) + (size_t)blk * 64;
-    if(pc.n == 8) prep_block<8>(job, c, kind, brow, bcol, out, lane, s, d1);
-    else prep_block<16>(job, c, kind, brow, bcol, out, lane, s, d1);
+    if(pc.nx == 8 && pc.ny == 8) prep_block<8, 8>(job, c, kind, brow, bcol, out, lane, s, d1);
+    else if(pc.nx == 16 && pc.ny == 16) prep_block<16, 16>(job, c, kind, brow, bcol, out, lane, s, d1);
+    else if(pc.nx == 16) prep_block<16, 8>(job, c, kind, brow, bcol, out, lane, s, d1);
+    else prep_block<8, 16>(job, c, kind, brow, bcol, out, lane, s, d1);
 }
 
 } // namespace mjx
@@ -153,11 +172,12 @@ extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
     for(int c = 0; c < 3; ++c) {
         if(hmax % p->h_samp[c] != 0 || vmax % p->v_samp[c] != 0) return MJX_ERR_BAD_ARG;
         const int fx = hmax / p->h_samp[c], fy = vmax / p->v_samp[c];
-        if(fx != fy || (fx != 1 && fx != 2)) return MJX_ERR_BAD_ARG; // 8x8 or 16x16 transforms only
+        if((fx != 1 && fx != 2) || (fy != 1 && fy != 2)) return MJX_ERR_BAD_ARG; // 8x8, 16x16, 16x8, 8x16 transforms only
         if(p->tile[c] == nullptr || p->alpha_tile[c] == nullptr) return MJX_ERR_NULL_DATA;
         job.comp[c].tile = p->tile[c];
         job.comp[c].alpha = p->alpha_tile[c];
-        job.comp[c].n = 8 * fx;
+        job.comp[c].nx = 8 * fx;
+        job.comp[c].ny = 8 * fy;
         job.comp[c].cols = (int32_t)(W / (8 * fx));
         job.comp[c].rows = (int32_t)(H / (8 * fy));
         job.comp[c].first = (int32_t)total;

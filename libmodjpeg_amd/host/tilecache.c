@@ -177,7 +177,7 @@ static int device_prep_enabled(void) {
 /* the tiles of a miss prepared on the device (mjx_tiles_prepare: forward DCT, colour conversion and
  * DCT-scaled chroma of the linked libjpeg as exact integer forms), nothing but the overlay's visible
  * pixels crossing PCIe.  MJX_ERR_BAD_ARG: this overlay / target combination is libjpeg's (gray,
- * CMYK, 4:2:2 ...), the caller takes the host path. */
+ * CMYK, 4:1:1 ...), the caller takes the host path. */
 static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_sampling_t *s, int bx, int by, int cx, int cy, int cw,
                                 int ch) {
     const size_t   row = (size_t)cw * 3;
@@ -204,7 +204,7 @@ static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COL
         const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
         size_t    bytes;
         if(hs < 1 || vs < 1 || s->max_h_samp_factor % hs != 0 || s->max_v_samp_factor % vs != 0) return MJX_ERR_BAD_ARG;
-        if(s->max_h_samp_factor / hs != s->max_v_samp_factor / vs || s->max_h_samp_factor / hs > 2) return MJX_ERR_BAD_ARG;
+        if(s->max_h_samp_factor / hs > 2 || s->max_v_samp_factor / vs > 2) return MJX_ERR_BAD_ARG;
         p.h_samp[c] = hs;
         p.v_samp[c] = vs;
         t->cols[c] = w / (8 * (s->max_h_samp_factor / hs));

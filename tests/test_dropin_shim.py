@@ -164,7 +164,7 @@ def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sampling,expect", [("420", "gpu"), ("444", "gpu"), ("422", "host"), ("440", "host")])
+@pytest.mark.parametrize("sampling,expect", [("420", "gpu"), ("444", "gpu"), ("422", "gpu"), ("440", "gpu")])
 def test_gpu_tile_preparation_equals_libjpeg_on_random_overlays(shim, tmp_path, sampling, expect):
     """device-prepared tiles == libjpeg-prepared tiles (the drop-in's host path, itself pinned to the
     reference) on random overlays: RGB / RGBA / YCC / YCCA pixels, odd sizes, every kind of in-MCU

@@ -283,3 +283,44 @@ def test_fuzz_blocks_vs_oracle(mj, family):
     O.compose_jobs(jobs, nthreads)
     got = m.planes_numpy()[0].reshape(-1)
     assert np.array_equal(got, want), (family, "seed", seed, "differing coefficients", int((got != want).sum()))
+
+
+@pytest.mark.parametrize("where", ["hipMemcpyAsync(D2H)", "HostToDevice, s):2", "compose_kernel launch"])
+def test_host_buffer_call_survives_an_injected_failure(where, tmp_path):
+    """mjx_compose_host bails out early when a HIP call fails (MJX_INJECT_FAILURE reports one
+    successful call as failed): it must return the error with nothing of its own still queued on
+    the staging arena it hands back - the very next call reuses that arena and must be bit-exact -
+    and it must not have corrupted the caller's planes beyond the rectangle."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["MJX_ROOT"])
+from libmodjpeg_amd._lib import lib, MJX_OK, MJX_ERR_LAUNCH
+from tests import oracle_lib as O
+L = lib()
+rows, cols, bpr, prow = 24, 40, 120, 68
+q = O.quant_table(False)
+def run(seed):
+    plane = O.synth_coef(seed, 0, 0, bpr * prow, q)
+    tile, alpha = O.synth_tile(seed, 0, 0, rows * cols), O.synth_alpha(seed, 0, 0, rows * cols, 2)
+    want = plane.copy()
+    O.compose_rect(want, bpr, 5, 7, rows, cols, q, tile, alpha)
+    before = plane.copy()
+    rc = L.mjx_compose_rect_host(plane.ctypes.data, bpr, prow, 5, 7, rows, cols, q.ctypes.data, tile.ctypes.data, alpha.ctypes.data)
+    return rc, plane, want, before
+rc, plane, want, before = run(1)
+assert rc == MJX_ERR_LAUNCH, rc
+view = lambda p: p.reshape(prow, bpr, 64)
+mask = np.ones((prow, bpr), bool); mask[5:5 + rows, 7:7 + cols] = False
+assert np.array_equal(view(plane)[mask], view(before)[mask])      # nothing outside the rectangle was touched
+for seed in (2, 3, 4):                                            # the arena is reused at once
+    rc, plane, want, _ = run(seed)
+    assert rc == MJX_OK and np.array_equal(plane, want), (seed, rc)
+print("ok")
+"""
+    env = dict(os.environ, MJX_INJECT_FAILURE=where, MJX_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MJX_ARENAS="1")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert res.returncode == 0 and res.stdout.strip().endswith("ok"), (res.stdout[-300:], res.stderr[-800:])
+    assert "failure injected" in res.stderr
