@@ -168,9 +168,8 @@ def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case
 def test_gpu_tile_preparation_equals_libjpeg_on_random_overlays(shim, tmp_path, sampling, expect):
     """device-prepared tiles == libjpeg-prepared tiles (the drop-in's host path, itself pinned to the
     reference) on random overlays: RGB / RGBA / YCC / YCCA pixels, odd sizes, every kind of in-MCU
-    offset and crop, noise / smooth / saturated contents, translucent blends; 4:2:0 and 4:4:4 targets
-    are prepared on the device, 4:2:2 and 4:4:0 (libjpeg's 16x8 / 8x16 transforms) are declined and
-    come from the host path"""
+    offset and crop, noise / smooth / saturated contents, translucent blends; 4:2:0, 4:4:4, 4:2:2 and
+    4:4:0 targets (libjpeg's 8x8, 16x16, 16x8 and 8x16 transforms) are all prepared on the device"""
     rng = np.random.default_rng(int(sampling))
     target = str(tmp_path / "target.jpg")
     _make_input(target, ("200", "120"), sampling)
