@@ -45,6 +45,16 @@ class DcJob(ctypes.Structure):
                 ("value", ctypes.c_int32), ("q0", ctypes.c_uint16), ("reserved", ctypes.c_uint16)]
 
 
+class TilePrep(ctypes.Structure):
+    """struct mjx_tileprep (include/mjx.h)"""
+    _fields_ = [("image", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("crop_x", ctypes.c_int32), ("crop_y", ctypes.c_int32), ("crop_w", ctypes.c_int32), ("crop_h", ctypes.c_int32),
+                ("off_x", ctypes.c_int32), ("off_y", ctypes.c_int32), ("source", ctypes.c_int32), ("target", ctypes.c_int32), ("ncomp", ctypes.c_int32),
+                ("h_samp", ctypes.c_int32 * 4), ("v_samp", ctypes.c_int32 * 4), ("tile", ctypes.c_void_p * 4), ("alpha_tile", ctypes.c_void_p * 4)]
+
+
+MJX_PREP_SOURCE_RGB, MJX_PREP_SOURCE_YCC, MJX_PREP_TARGET_RGB, MJX_PREP_TARGET_YCC = 1, 5, 2, 3
+
 # every symbol include/mjx.h declares: (name, restype, argtypes)
 _vp, _i, _sz, _u64, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint32
 SYMBOLS = [
@@ -70,7 +80,7 @@ SYMBOLS = [
     ("mjx_compose_rect_host", _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     ("mjx_effect_dc_host", _i, [_vp, _i, _i, _i, ctypes.c_uint16, _i]),
     ("mjx_effect_zero_host", _i, [_vp, _i, _i, _i, _i]),
-    ("mjx_tiles_prepare", _i, [_vp]),
+    ("mjx_tiles_prepare", _i, [ctypes.POINTER(TilePrep)]),
     ("mjx_convolve_host", _i, [_vp, _vp, ctypes.c_float, _i, _i, _i]),
     ("mjx_convolve", _i, [_vp, _vp, ctypes.c_float, _i, _i, _i, _vp]),
     ("mjx_effect_dc", _i, [ctypes.POINTER(DcJob), _i, _vp]),

@@ -324,3 +324,47 @@ print("ok")
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert res.returncode == 0 and res.stdout.strip().endswith("ok"), (res.stdout[-300:], res.stderr[-800:])
     assert "failure injected" in res.stderr
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
+    """mjx_compose_plan_create_ex(MJX_PLAN_GROUP_BY_DENSITY) on rectangles whose blocks have every
+    density from 0 to 64 non-zero weights (signed zeros, denormals and NaN weights included), ragged
+    sizes, several jobs per plan sharing quant tables: grouped plan == plain plan == oracle"""
+    import torch
+    from libmodjpeg_amd._lib import MJX_PLAN_GROUP_BY_DENSITY, RectJob, check, lib
+    rng = np.random.default_rng(seed)
+    shapes = [(40, 50, 3, 5, 13, 21), (20, 25, 0, 0, 20, 25), (9, 33, 2, 30, 7, 3), (64, 16, 10, 4, 37, 9), (8, 8, 1, 1, 1, 1)]  # prow, bpr, row0, col0, rows, cols
+    quants = np.stack([rng.integers(1, 256, 64), rng.integers(1, 65536, 64)]).astype(np.uint16)
+    host, dev, jobs = [], [], (RectJob * len(shapes))()
+    for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
+        n = rows * cols
+        coef = rng.integers(-1024, 1024, (prow, bpr, 64)).astype(np.int16)
+        tile = np.round(rng.standard_normal((n, 64)) * 200).astype(np.float32)
+        alpha = (rng.standard_normal((n, 64)) * 0.05).astype(np.float32)
+        dens = rng.choice([0.0, 0.02, 0.1, 0.3, 0.6, 1.0], n)[:, None]
+        alpha = np.where(rng.random((n, 64)) < dens, alpha, np.float32(0))
+        alpha[rng.random((n, 64)) < 0.02] = np.float32(-0.0)
+        alpha[rng.random((n, 64)) < 0.002] = np.float32(1e-41)
+        if seed == 12:
+            alpha[rng.random((n, 64)) < 0.001] = np.float32("nan")
+        alpha = np.ascontiguousarray(alpha, np.float32)
+        host.append((coef, tile, alpha))
+    results = []
+    for flags in (MJX_PLAN_GROUP_BY_DENSITY, 0):
+        dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
+        for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
+            jobs[j] = RectJob(dev[j][0].data_ptr(), dev[j][1].data_ptr(), dev[j][2].data_ptr(), bpr, prow, row0, col0, rows, cols, j % 2)
+        plan = ctypes.c_void_p()
+        check(lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 2, flags), "plan")
+        if flags:
+            assert lib().mjx_compose_plan_gather_octets(plan) > 0
+        check(lib().mjx_compose_run(plan, None), "run")
+        torch.cuda.synchronize()
+        lib().mjx_compose_plan_destroy(plan)
+        results.append([d[0].cpu().numpy() for d in dev])
+    for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
+        want = host[j][0].reshape(-1).copy()
+        O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 2]), host[j][1].reshape(-1), host[j][2].reshape(-1))
+        assert np.array_equal(results[1][j].reshape(-1), want), ("plain plan", j)
+        assert np.array_equal(results[0][j].reshape(-1), want), ("grouped plan", j)
