@@ -45,7 +45,7 @@ WORKLOADS = {
     "compose_1080p_batch": (1920, 1080, 256, 256, 52, 26, 4096),  # BASELINE configs[2]/[3]
     "compose_4k_fullframe": (3840, 2160, 3840, 2160, 0, 0, 1),    # BASELINE configs[1]
 }
-REGIMES = {"A1": 1, "A2": 2, "A3": 3, "A4": 4}
+REGIMES = {"A1": 1, "A2": 2, "A3": 3, "A4": 4, "A5": 5}  # A5: tiles of a real overlay (hard-edged disc), prepared on the device
 METRIC_1080P = "8×8 DCT blocks/s masked-compose, 1080p batch; achieved HBM GB/s vs roofline"
 
 
@@ -180,9 +180,10 @@ def spawn_ranks(args_list, world):
 
 # ---- CPU oracle legs ----------------------------------------------------------------------------
 
-def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0, timing=True):
+def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0, timing=True, tiles=None):
     """Oracle compose on `nsample` images of the workload (only the dropon rectangles are
-    generated: nothing else is read by the path).  Returns (info dict, expected rect arrays)."""
+    generated: nothing else is read by the path).  `tiles`: per component (tile, alpha) arrays used
+    for every image instead of the synthetic ones (regime A5).  Returns (info dict, expected rect arrays)."""
     import numpy as np
     from libmodjpeg_amd.batch import Geometry420, quant_table
     from tests import oracle_lib as O
@@ -202,8 +203,11 @@ def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0, timing=True):
                 for l in range(rows):  # the rectangle's blocks keep their plane block index
                     rect[l] = O.synth_coef(image0 + i, c, (row0 + l) * bpr + col0, cols, quant[c])
                 rect = rect.reshape(-1)
-                tile = O.synth_tile(image0 + i, c, 0, rows * cols)
-                alpha = O.synth_alpha(image0 + i, c, 0, rows * cols, regime)
+                if tiles is not None:
+                    tile, alpha = tiles[c]
+                else:
+                    tile = O.synth_tile(image0 + i, c, 0, rows * cols)
+                    alpha = O.synth_alpha(image0 + i, c, 0, rows * cols, regime)
                 jobs.append((rect, cols, 0, 0, rows, cols, quant[c], tile, alpha))
                 keep.append(rect)
         return jobs, keep
@@ -308,7 +312,10 @@ def bench_compose(args, rank, world):
     expected = None
     if nsample > 0:
         # the sample: the first images of this rank's shard
-        info, expected = cpu_baseline_and_expected((width, height, dw, dh, mcu_x, mcu_y), regime, nsample, image0, timing=(world == 1))
+        tiles = None
+        if regime == 5:  # the oracle gets the device-prepared tiles as its input (their own parity: tests/test_dropin_shim.py)
+            tiles = [(np.ascontiguousarray(batch.tile[c][0].cpu().numpy().reshape(-1)), np.ascontiguousarray(batch.alpha[c][0].cpu().numpy().reshape(-1))) for c in range(3)]
+        info, expected = cpu_baseline_and_expected((width, height, dw, dh, mcu_x, mcu_y), regime, nsample, image0, timing=(world == 1), tiles=tiles)
         cpu_info = info if world == 1 else None
     batch.run()
     sync()

@@ -14,7 +14,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import MJX_PLAN_GROUP_BY_DENSITY, DcJob, RectJob, check, lib
+from ._lib import (MJX_PLAN_GROUP_BY_DENSITY, MJX_PREP_SOURCE_RGB, MJX_PREP_TARGET_YCC, DcJob, RectJob, TilePrep, check, lib)
 
 _BASE_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
                        14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
@@ -55,6 +55,24 @@ class Geometry420:
         return sum(w * h for w, h in self.array_dims)
 
 
+REGIME_DISC = 5  # A5: tiles of a real overlay (hard-edged disc mask), prepared on the device from pixels
+
+
+def disc_overlay(w, h):
+    """RGBA pixels of a w x h overlay with a real mask: colour ramps with a checker, alpha = a hard-edged
+    disc (one antialiased pixel of rim) — most blocks end up fully inside (1 non-zero alpha-DCT weight)
+    or fully outside (0), the blocks the rim crosses need most of the 64 (7.1 on average)"""
+    y, x = np.mgrid[0:h, 0:w]
+    r = np.hypot(x - (w - 1) / 2.0, y - (h - 1) / 2.0)
+    a = np.clip(0.46 * min(w, h) - r + 0.5, 0.0, 1.0)
+    rgba = np.empty((h, w, 4), np.uint8)
+    rgba[..., 0] = 255 - x * 255 // max(w, 1)
+    rgba[..., 1] = np.where((x // 8 + y // 8) % 2 == 1, 230, 40)
+    rgba[..., 2] = y * 255 // max(h, 1)
+    rgba[..., 3] = np.floor(a * 255.0 + 0.5)
+    return rgba
+
+
 class ComposeBatch:
     """`n` images (global indices image0 .. image0+n-1) of one geometry, one dropon rectangle per
     image at MCU (mcu_x, mcu_y) of dropon_w x dropon_h pixels (multiples of 16), per-image tiles."""
@@ -89,9 +107,31 @@ class ComposeBatch:
             tblocks = self.rect[c][2] * self.rect[c][3]
             qp = self.quant[c].ctypes.data_as(vp)
             check(L.mjx_synth_coef_batch(vp(self.coef[c].data_ptr()), pblocks, self.image0, self.n, c, 0, pblocks, qp, s), "mjx_synth_coef_batch")
-            check(L.mjx_synth_tile_batch(vp(self.tile[c].data_ptr()), tblocks, self.image0, self.n, c, 0, tblocks, s), "mjx_synth_tile_batch")
-            check(L.mjx_synth_alpha_batch(vp(self.alpha[c].data_ptr()), tblocks, self.image0, self.n, c, 0, tblocks, self.regime, s), "mjx_synth_alpha_batch")
+            if self.regime != REGIME_DISC:
+                check(L.mjx_synth_tile_batch(vp(self.tile[c].data_ptr()), tblocks, self.image0, self.n, c, 0, tblocks, s), "mjx_synth_tile_batch")
+                check(L.mjx_synth_alpha_batch(vp(self.alpha[c].data_ptr()), tblocks, self.image0, self.n, c, 0, tblocks, self.regime, s), "mjx_synth_alpha_batch")
+        if self.regime == REGIME_DISC:
+            self._fill_disc_tiles()
         torch.cuda.current_stream().synchronize()
+
+    def _fill_disc_tiles(self):
+        """every image gets (its own copy of) the tiles of one real overlay, prepared from its pixels on
+        the device by mjx_tiles_prepare exactly as the drop-in does on a tile-cache miss"""
+        dh, dw = self.rect[0][2] * 8, self.rect[0][3] * 8
+        rgba = disc_overlay(dw, dh)
+        image = np.ascontiguousarray(rgba[..., :3])
+        alpha = np.ascontiguousarray(np.repeat(rgba[..., 3:4], 3, axis=2))
+        p = TilePrep(image.ctypes.data, alpha.ctypes.data, dw, dh, 0, 0, dw, dh, 0, 0, MJX_PREP_SOURCE_RGB, MJX_PREP_TARGET_YCC, 3)
+        one = []
+        for c, (h, v) in enumerate(self.geo.samp):
+            p.h_samp[c], p.v_samp[c] = h, v
+            t = torch.empty((2, self.rect[c][2] * self.rect[c][3], 64), dtype=torch.float32, device=self.device)
+            p.tile[c], p.alpha_tile[c] = t[0].data_ptr(), t[1].data_ptr()
+            one.append(t)
+        check(lib().mjx_tiles_prepare(ctypes.byref(p)), "mjx_tiles_prepare")
+        for c in range(3):
+            self.tile[c][:] = one[c][0]
+            self.alpha[c][:] = one[c][1]
 
     # ---- launch plan ------------------------------------------------------------------------
     def build_plan(self, group_by_density=True):

@@ -154,6 +154,40 @@ def test_density_grouping_is_only_a_schedule(torch_mod, dims):
                 assert np.array_equal(out[0][c][i].cpu().numpy().reshape(-1), want), (regime, i, c)
 
 
+def test_real_mask_regime_a5(torch_mod):
+    """regime A5: the tiles of a real overlay (hard-edged disc) prepared from pixels on the device;
+    the alpha tiles have the density profile the survey measured for such a mask (bimodal, ~7 non-zero
+    weights per block on average), the grouped plan uses the gather table and equals the plain plan
+    and the oracle fed with the same tiles"""
+    torch = torch_mod
+    from libmodjpeg_amd.batch import ComposeBatch
+    n, out = 64, []
+    for group in (True, False):
+        b = ComposeBatch(n, 1920, 1080, 256, 256, 52, 26, 5)
+        b.fill_synthetic()
+        b.build_plan(group_by_density=group)
+        if group:
+            nnz = (b.alpha[0][0] != 0).sum(dim=1).cpu().numpy()
+            assert 4.0 < nnz.mean() < 12.0 and (nnz <= 1).mean() > 0.6 and (nnz >= 32).mean() > 0.04, (nnz.mean(), np.bincount(nnz, minlength=65))
+            assert b.gather_octets > 0
+            tiles = [(b.tile[c][0].cpu().numpy().reshape(-1).copy(), b.alpha[c][0].cpu().numpy().reshape(-1).copy()) for c in range(3)]
+        b.run()
+        torch.cuda.synchronize()
+        out.append([_rect_view(b, c).clone() for c in range(3)])
+    for c in range(3):
+        assert torch.equal(out[0][c], out[1][c]), c
+    for i in (0, n - 1):
+        for c in range(3):
+            bpr, _ = b.geo.array_dims[c]
+            row0, col0, rows, cols = b.rect[c]
+            want = np.empty((rows, cols * 64), np.int16)
+            for l in range(rows):
+                want[l] = O.synth_coef(i, c, (row0 + l) * bpr + col0, cols, b.quant[c])
+            want = want.reshape(-1)
+            O.compose_rect(want, cols, 0, 0, rows, cols, b.quant[c], tiles[c][0], tiles[c][1])
+            assert np.array_equal(out[0][c][i].cpu().numpy().reshape(-1), want), (i, c)
+
+
 def test_4k_fullframe_vs_oracle(torch_mod):
     """BASELINE configs[1]: one 3840x2160 4:2:0 image, full-frame alpha-masked dropon (194 400 blocks)"""
     torch = torch_mod
