@@ -51,7 +51,7 @@ template <int RD> __global__ __launch_bounds__(256) void mix_kernel(const float4
     if(RD == 0) nts(acc, dst + (size_t)blockIdx.x * 256 + threadIdx.x);
 }
 
-template <bool DENSE> __global__ __launch_bounds__(256) void pattern_kernel(const Job *__restrict__ jobs, int njobs, int runs_per_job) {
+template <bool DENSE, bool MERGED = false> __global__ __launch_bounds__(256) void pattern_kernel(const Job *__restrict__ jobs, int njobs, int runs_per_job) {
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int j = wave / runs_per_job, run = wave - j * runs_per_job;
@@ -71,14 +71,16 @@ template <bool DENSE> __global__ __launch_bounds__(256) void pattern_kernel(cons
     };
     float4 *cp = coef_ptr(0);
     float4  c = ntl(cp);
-    const float4 *tp = reinterpret_cast<const float4 *>(job.tile) + (size_t)first * 16 + lane, *ap = reinterpret_cast<const float4 *>(job.alpha) + (size_t)first * 16 + lane;
+    // MERGED: tile and alpha of an octet interleaved in ONE array (4 KiB contiguous per octet) instead of two arrays
+    const float4 *tp = reinterpret_cast<const float4 *>(job.tile) + (size_t)first * (MERGED ? 32 : 16) + lane;
+    const float4 *ap = MERGED ? tp + 128 : reinterpret_cast<const float4 *>(job.alpha) + (size_t)first * 16 + lane;
     float4 t0 = ntl(tp), t1 = ntl(tp + 64), a0 = ntl(ap), a1 = ntl(ap + 64);
     for(int o = 0; o < noct; ++o) {
         float4 *cn = cp; float4 cc = c, u0 = t0, u1 = t1, b0 = a0, b1 = a1;
         if(o + 1 < noct) {
             cn = coef_ptr(o + 1);
             cc = ntl(cn);
-            tp += 128; ap += 128;
+            tp += MERGED ? 256 : 128; ap += MERGED ? 256 : 128;
             u0 = ntl(tp); u1 = ntl(tp + 64); b0 = ntl(ap); b1 = ntl(ap + 64);
         }
         float4 r = make_float4(c.x + t0.x + t1.x + a0.x + a1.x, c.y + t0.y + t1.y + a0.y + a1.y, c.z + t0.z + t1.z + a0.z + a1.z, c.w + t0.w + t1.w + a0.w + a1.w);
@@ -115,6 +117,12 @@ int main(int argc, char **argv) {
             jobs.push_back(Job{coef[c] + (size_t)i * pb * 64, tile[c] + (size_t)i * tb * 64, alpha[c] + (size_t)i * tb * 64, dims[c][0], rect[c][0], rect[c][1], rect[c][3], (int)tb});
         }
     Job *d_jobs; CK(hipMalloc(&d_jobs, jobs.size() * sizeof(Job))); CK(hipMemcpy(d_jobs, jobs.data(), jobs.size() * sizeof(Job), hipMemcpyHostToDevice));
+    // merged layout: one array per component holding tile+alpha, 512 B per block
+    std::vector<Job> jm = jobs;
+    { float *merged[3];
+      for(int c = 0; c < 3; ++c) { const size_t tb = (size_t)rect[c][2] * rect[c][3]; CK(hipMalloc(&merged[c], tb * 512 * images)); CK(hipMemset(merged[c], 0, tb * 512 * images)); }
+      for(int i = 0; i < images; ++i) for(int c = 0; c < 3; ++c) { const size_t tb = (size_t)rect[c][2] * rect[c][3]; jm[(size_t)i * 3 + c].tile = merged[c] + (size_t)i * tb * 128; } }
+    Job *d_jobsm; CK(hipMalloc(&d_jobsm, jm.size() * sizeof(Job))); CK(hipMemcpy(d_jobsm, jm.data(), jm.size() * sizeof(Job), hipMemcpyHostToDevice));
     const size_t nblocks = (size_t)images * 1536;
     const double gb = nblocks * 768.0 / 1e9;
     float4 *src, *dst; CK(hipMalloc(&src, nblocks * 640)); CK(hipMalloc(&dst, nblocks * 128)); CK(hipMemset(src, 0, nblocks * 640));
@@ -133,6 +141,8 @@ int main(int argc, char **argv) {
         printf("pattern  %.3f ms  %.0f GB/s  (%.3f of 8 TB/s)\n", t, gb / t * 1e3, gb / t * 1e3 / 8000);
         t = time_ms([&] { hipLaunchKernelGGL(pattern_kernel<true>, dim3(grid_p), dim3(256), 0, 0, d_jobs, njobs, rpj); }, 50);
         printf("dense    %.3f ms  %.0f GB/s  (%.3f of 8 TB/s)\n", t, gb / t * 1e3, gb / t * 1e3 / 8000);
+        t = time_ms([&] { hipLaunchKernelGGL((pattern_kernel<false, true>), dim3(grid_p), dim3(256), 0, 0, d_jobsm, njobs, rpj); }, 50);
+        printf("merged   %.3f ms  %.0f GB/s  (%.3f of 8 TB/s)   tile+alpha of an octet in one 4 KiB run\n", t, gb / t * 1e3, gb / t * 1e3 / 8000);
     }
     return 0;
 }
