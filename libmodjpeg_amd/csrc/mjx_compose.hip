@@ -44,7 +44,7 @@ namespace mjx {
 //    banks (8 b + 12 v + u) mod 32: disjoint
 constexpr int kRowStride = 12;
 constexpr int kBlockStride = 104;
-constexpr int kImageDwords = kWaveBlocks * kBlockStride; // 832 dwords = 3328 B
+constexpr int kImageDwords = 960; // z image: 8 x 104 = 832 dwords; the Y image (below) needs 960
 
 template <int... I, class F> MJX_DEV void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -64,28 +64,29 @@ MJX_DEV void lds_get_col(const float *img, int b, int r, float (&a)[8]) {
     const float *p = img + b * kBlockStride + r;
     static_for<8>([&](auto V) { a[V] = p[V * kRowStride]; });
 }
-// Y goes back from column to row layout through an image of its own shape: rows of 8 dwords, block
-// stride 82.  The column writes (ds_write_b32, 32 lanes per cycle, bank = dword mod 32) then fall
-// on every bank at most twice (2-way is free for a 4-byte store), and the row comes back as four
-// ds_read_b64 (32 lanes per cycle over 64 banks, bank pair = (41 b + 4 r + j) mod 32: all different)
-// instead of two ds_read_b128 that conflicted 3-way on the 12/104 image (measured,
-// profiles/r02/lds_patterns_pmc.txt).  Inline asm keeps the four reads from being fused into
-// ds_read2_b64 / ds_read_b128, whose lane grouping differs; the values are needed at once, so the
-// wait is part of the statement.
-constexpr int kYRowStride = 8;
-constexpr int kYBlockStride = 82;
-static_assert(kWaveBlocks * kYBlockStride <= kImageDwords, "the Y image lives in the Z image's storage");
+// Y goes back from column to row layout through an image of its own shape: rows of 16 dwords, block
+// stride 120, and in blocks 2,3,6,7 the two halves of every row swapped (column u is stored at
+// position u ^ 4).  Then both sides are conflict-free: the column stores (ds_write_b32: 32 lanes per
+// cycle, bank = dword mod 32: 120 b + u covers 0..31 once for b = 0..3) and the row reads
+// (ds_read_b128: 16 lanes per cycle over 64 banks; the lanes of a group read their low half at
+// +0 or +4 according to the block's swap, which spreads the 16 x 16 bytes over all 64 banks).
+// The layout was found by exhaustive search over strides and offsets against the LDS banking
+// rules of the microarchitecture guide, which every pattern measured in
+// scripts/ubench/lds_patterns.hip obeys; the 12/104 image used for z has no such solution for
+// this direction (its rows read 3-way conflicted, measured).
+constexpr int kYRowStride = 16;
+constexpr int kYBlockStride = 120;
+static_assert(kWaveBlocks * kYBlockStride <= kImageDwords && kWaveBlocks * kBlockStride <= kImageDwords, "both images live in the same storage");
 MJX_DEV void lds_put_col_y(float *img, int b, int u, const float (&a)[8]) {
-    float *p = img + b * kYBlockStride + u;
+    float *p = img + b * kYBlockStride + (u ^ (((b >> 1) & 1) * 4));
     static_for<8>([&](auto V) { p[V * kYRowStride] = a[V]; });
 }
 MJX_DEV void lds_get_row_y(const float *img, int b, int r, float (&a)[8]) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const unsigned at = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)(img + b * kYBlockStride + r * kYRowStride);
-    f2             v0, v1, v2, v3;
-    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(at) : "memory");
-    a[0] = v0.x; a[1] = v0.y; a[2] = v1.x; a[3] = v1.y; a[4] = v2.x; a[5] = v2.y; a[6] = v3.x; a[7] = v3.y;
+    const int    ph = (b >> 1) & 1;
+    const float *p = img + b * kYBlockStride + r * kYRowStride;
+    const float4 lo = *reinterpret_cast<const float4 *>(p + 4 * ph), hi = *reinterpret_cast<const float4 *>(p + 4 - 4 * ph);
+    a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w;
+    a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
 }
 
 MJX_DEV unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
