@@ -293,31 +293,34 @@ def test_compose_step_time_does_not_depend_on_the_plane_contents(torch_mod):
     not idempotent).  The kernel has one data-dependent path, (int)Y for Y >= 2^31
     (mjx_compose.hip octet_step): with |tile|, |coef*q| <= 2^15 and sum |w| < 64 it cannot be
     reached from this workload, before or after any number of compositions.  Timing the launch on
-    pristine planes and after 60 compositions in place must therefore agree."""
+    pristine planes and on planes composed 200 times must therefore agree."""
     torch = torch_mod
     b = _batch(2).build_plan()
     pristine = b.rect_clone()
 
-    def timed(restore):
-        ms = []
-        for _ in range(12):
-            if restore:
-                b.rect_restore(pristine)
-            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            b.run()
-            e.record()
-            torch.cuda.synchronize()
-            ms.append(a.elapsed_time(e))
-        return float(np.median(ms))
-
-    for _ in range(200):  # clocks up
+    for _ in range(200):  # clocks up; the planes have then been composed 200 times
         b.run()
     torch.cuda.synchronize()
-    t_inplace = timed(False)   # planes composed > 200 times
-    t_pristine = timed(True)
-    t_inplace2 = timed(False)
-    assert abs(t_pristine - t_inplace) <= 0.06 * t_inplace and abs(t_inplace2 - t_inplace) <= 0.06 * t_inplace, (t_pristine, t_inplace, t_inplace2)
+    deep = b.rect_clone()
+
+    def launch_ms(planes):
+        b.rect_restore(planes)  # the same copy before either case: same cache state at launch
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.run()
+        e.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(e)
+
+    # alternate the two cases launch by launch: the device's own drift (several per cent over
+    # seconds on these boxes) then hits both alike
+    t_pristine, t_deep = [], []
+    for _ in range(20):
+        t_pristine.append(launch_ms(pristine))
+        t_deep.append(launch_ms(deep))
+    t_pristine, t_deep = float(np.median(t_pristine)), float(np.median(t_deep))
+    assert abs(t_pristine - t_deep) <= 0.06 * t_deep, (t_pristine, t_deep)
+    b.rect_restore(deep)
     # and the values stay inside the range the bound assumes
     for c in range(3):
         assert int(_rect_view(b, c).to(torch.int32).abs().max()) * int(b.quant[c].max()) < 2 ** 31
