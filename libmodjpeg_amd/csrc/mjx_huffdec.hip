@@ -517,6 +517,9 @@ void run_batch(Request *lead, Request **batch, int n) {
     DecJob     *h_jobs = reinterpret_cast<DecJob *>(pin), *d_jobs = reinterpret_cast<DecJob *>(dev);
     int        *h_flags = reinterpret_cast<int *>(pin + kBatchFlagsAt), *d_flags = reinterpret_cast<int *>(dev + kBatchFlagsAt);
     auto        fail_all = [&](int code) {
+        // whatever was queued for the batch reads and writes the followers' arenas: let it drain
+        // before they are told to go (their leases hand the arenas back at once)
+        (void)hipStreamSynchronize(s);
         for(int i = 0; i < n; ++i)
             if(batch[i]->result < 0) batch[i]->result = code;
     };

@@ -342,6 +342,9 @@ void run_batch(Request *lead, Request **batch, int n) {
     EncJob             *h_jobs = reinterpret_cast<EncJob *>(pin), *d_jobs = reinterpret_cast<EncJob *>(dev);
     unsigned long long *h_misc = reinterpret_cast<unsigned long long *>(pin + kMiscAt), *d_misc = reinterpret_cast<unsigned long long *>(dev + kMiscAt);
     auto                fail_all = [&](int code) {
+        // whatever was queued for the batch reads and writes the followers' arenas: let it drain
+        // before they are told to go (their leases hand the arenas back at once)
+        (void)hipStreamSynchronize(s);
         for(int i = 0; i < n; ++i) batch[i]->result = code;
     };
     unsigned hb = 1, wb = 1, g1 = 1, g2 = 1;
