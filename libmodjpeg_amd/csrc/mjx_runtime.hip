@@ -258,15 +258,20 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
     for(int i = 0; i < nq * 64; ++i) {
         if(qtables[i] == 0) return MJX_ERR_BAD_ARG;
     }
-    // Run length (octets per wave): long runs amortise the un-prefetched first octet, short runs
-    // keep all 256 CUs x 12 resident waves busy when the whole launch is small (one 4K image is
-    // only 24 300 octets).  Aim at >= 1 round of resident waves, within [2, MJX_RUN_OCTETS]
-    // (measured on one 4K image: 8 octets per run 3.75 TB/s, 16 per run 2.70 TB/s).
+    // Run length (octets per wave).  Long runs amortise the un-prefetched first octet; short runs keep
+    // all 256 CUs x 12 resident waves busy when the launch is small and balance its tail when it
+    // is medium.  Measured (MI355X, round 2): a launch that gives every resident wave fewer than 8
+    // octets runs best as ONE round of waves (one 4K image, 24 300 octets: 8 per run 36 us, 4 per run
+    // 37, 2 per run 39; a per-image call of 192 octets: 2 per run); beyond that at least 8 rounds of
+    // 8..16 octets (512 images of the headline workload, i.e. its 8-GPU shard: 8 per run 0.121 ms,
+    // 16 per run 0.126; 1024 images 0.234 against 0.246; 2048 and 4096 images: 16 per run).
     int64_t total_octets = 0;
     for(int i = 0; i < njobs; ++i) {
         if(jobs[i].rows > 0 && jobs[i].cols > 0) total_octets += ((int64_t)jobs[i].rows * jobs[i].cols + kWaveBlocks - 1) / kWaveBlocks;
     }
-    int run_len = (int)((total_octets + 3071) / 3072);
+    const int64_t per_slot = (total_octets + 3071) / 3072; // octets per resident wave
+    int           run_len = per_slot < 8 ? (int)per_slot : (int)(per_slot / 8);
+    if(per_slot >= 8 && run_len < 8) run_len = 8;
     if(run_len < 2) run_len = 2;
     if(run_len > run_octets()) run_len = run_octets();
     if(const char *e = getenv("MJX_RUN_OCTETS")) { // experiments only
