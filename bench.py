@@ -66,6 +66,9 @@ def parse(argv=None):
     ap.add_argument("--images", type=int, default=0, help="images of the whole job (strong) / per GPU (weak); default: the workload's")
     ap.add_argument("--cpu-sample", type=int, default=256, help="images in the CPU baseline / parity sample (0 = skip)")
     ap.add_argument("--pristine-launches", type=int, default=10, help="extra launches from restored planes for roofline.kernel_ms_pristine (0 = skip)")
+    ap.add_argument("--tiles", default="f32", choices=["f32", "i16"],
+                    help="f32 (default, the workload as SURVEY 8d defines it: 768 B per block); i16: the prepared tiles kept as the int16 "
+                         "coefficients they are made from, converted in the kernel (512 B per block; secondary, labelled)")
     ap.add_argument("--no-group", action="store_true", help="compose: keep every octet 8 consecutive blocks (no grouping of blocks by alpha density)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     return ap.parse_args(argv)
@@ -296,7 +299,8 @@ def bench_compose(args, rank, world):
     regime = REGIMES[args.regime]
     image0, images = shard_of(total_images, rank, world, args.scaling)
     assert images > 0, f"rank {rank}: empty shard ({total_images} images over {world} ranks)"
-    batch = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, regime, image0=image0)
+    batch = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, regime, image0=image0, tiles_i16=(args.tiles == "i16"))
+    bytes_per_block = 512 if args.tiles == "i16" else BYTES_PER_BLOCK  # int16 tiles: 128 + 128 + 128 read, 128 written
     batch.fill_synthetic()
     batch.build_plan(group_by_density=not args.no_group)
     blocks_per_step = batch.total_blocks()
@@ -314,7 +318,7 @@ def bench_compose(args, rank, world):
         # the sample: the first images of this rank's shard
         tiles = None
         if regime == 5:  # the oracle gets the device-prepared tiles as its input (their own parity: tests/test_dropin_shim.py)
-            tiles = [(np.ascontiguousarray(batch.tile[c][0].cpu().numpy().reshape(-1)), np.ascontiguousarray(batch.alpha[c][0].cpu().numpy().reshape(-1))) for c in range(3)]
+            tiles = [batch.tiles_as_float(0, c) for c in range(3)]
         info, expected = cpu_baseline_and_expected((width, height, dw, dh, mcu_x, mcu_y), regime, nsample, image0, timing=(world == 1), tiles=tiles)
         cpu_info = info if world == 1 else None
     batch.run()
@@ -363,8 +367,8 @@ def bench_compose(args, rank, world):
     per_rank = gather_objects(mine, world)
 
     if rank == 0:
-        achieved = blocks_per_step * BYTES_PER_BLOCK / (mean_kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = traffic_from_profiles(args.traffic_json, f"{args.workload}:{args.regime}:{images}")
+        achieved = blocks_per_step * bytes_per_block / (mean_kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = traffic_from_profiles(args.traffic_json, f"{args.workload}:{args.regime}:{images}" + (":i16" if args.tiles == "i16" else ""))
         verdicts = {r["parity"] for r in per_rank}
         out = {
             # BASELINE.json's metric string, verbatim, for the workload it is quoted on
@@ -376,14 +380,15 @@ def bench_compose(args, rank, world):
             "dtype": "s16 JCOEF, f32/f64 blend (reference typing)", "data": "synthetic",
             "config": {"workload": args.workload, "images_total": tot_blocks // batch.blocks_per_image, "images_per_gpu": images, "image": f"{width}x{height} 4:2:0",
                        "dropon": f"{dw}x{dh} alpha-masked, per-image tiles, MCU ({mcu_x},{mcu_y})",
-                       "alpha_regime": args.regime, "density_grouping": (not args.no_group), "gather_octets_per_gpu": int(batch.gather_octets),
+                       "alpha_regime": args.regime, "tiles": "float (768 B per block)" if args.tiles == "f32" else "int16 coefficients, converted in the kernel (512 B per block)",
+                       "density_grouping": (not args.no_group), "gather_octets_per_gpu": int(batch.gather_octets),
                        "blocks_per_step_total": tot_blocks, "blocks_per_step_per_gpu": blocks_per_step, "spinup_ms": args.spinup_ms,
                        "parallelism": f"images sharded x{world} ({args.scaling}), no collective, no RCCL"},
             "parity": verdicts.pop() if len(verdicts) == 1 else "mixed: see per_rank",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "mjx::compose_kernel", "kernel_ms_mean": mean_kern_ms,
                          "kernel_ms_min": min(kern_ms), "kernel_ms_pristine": pristine_ms,
-                         "algorithmic_bytes_per_launch": blocks_per_step * BYTES_PER_BLOCK, "rank": 0},
+                         "algorithmic_bytes_per_launch": blocks_per_step * bytes_per_block, "bytes_per_block": bytes_per_block, "rank": 0},
             "per_rank": per_rank,
             "cpu_baseline": cpu_info,
         }

@@ -80,7 +80,15 @@ typedef struct mjx_rect_job {
     int32_t      row0, col0;     /* top-left block of the rectangle inside the plane */
     int32_t      rows, cols;     /* rectangle size in blocks == tile height/width in blocks */
     int32_t      qtable;         /* index into the plan's quant tables */
+    int32_t      flags;          /* MJX_JOB_* (this field occupies what was padding: older callers pass 0) */
 } mjx_rect_job_t;
+/* tile and alpha point at int16_t[rows*cols][64] instead of float: the prepared JCOEFs themselves.  A
+ * prepared tile is nothing but an int16 coefficient turned into a float (reference dropon.c:476-485;
+ * alpha: `coef[0] += 1024` then (float)coef * K, :542-566), so the kernel can do that conversion
+ * itself, bit for bit, and stream 512 instead of 768 bytes per block.  tile[i] holds coef[i], alpha[i]
+ * holds coef[i] with the DC offset already added (as a short).  mjx_tiles_prepare writes this form
+ * with MJX_PREP_TILES_I16.  All jobs of a plan must agree on it. */
+#define MJX_JOB_TILES_I16 1
 
 typedef struct mjx_compose_plan mjx_compose_plan_t;
 
@@ -168,7 +176,12 @@ typedef struct mjx_tileprep {
     int32_t              h_samp[4], v_samp[4];           /* the target image's sampling factors */
     float               *tile[4];                        /* DEVICE out, rows*cols*64 floats each */
     float               *alpha_tile[4];
+    int32_t              flags;                          /* MJX_PREP_* */
+    int32_t              reserved;
 } mjx_tileprep_t;
+/* write the tiles as int16 coefficients (the form MJX_JOB_TILES_I16 consumes): tile[] / alpha_tile[]
+ * then point at int16_t[rows*cols][64] */
+#define MJX_PREP_TILES_I16 1
 int mjx_tiles_prepare(const mjx_tileprep_t *p);
 
 /* ---- one (k,l) term: mj_convolve (reference convolve.c:29), test seam ------------------- */
@@ -313,6 +326,9 @@ int mjx_synth_tile_batch(float *dst, size_t image_stride_blocks, uint64_t image0
                          mjx_stream_t stream);
 int mjx_synth_alpha_batch(float *dst, size_t image_stride_blocks, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first_block, size_t nblocks,
                           int regime, mjx_stream_t stream);
+/* the same tiles as int16 coefficients (MJX_JOB_TILES_I16): kind 0 = image tile, 1 = alpha tile of `regime` */
+int mjx_synth_tiles_i16_batch(int16_t *dst, int kind, size_t image_stride_blocks, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first_block,
+                              size_t nblocks, int regime, mjx_stream_t stream);
 /* one image */
 int mjx_synth_coef(int16_t *dst /* DEVICE */, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks,
                    const uint16_t *q /* HOST[64] */, mjx_stream_t stream);

@@ -16,6 +16,8 @@ MJX_ERR_NULL_DATA = 3
 MJX_ERR_BAD_ARG = 4
 MJX_ERR_LAUNCH = 5
 MJX_PLAN_GROUP_BY_DENSITY = 1
+MJX_JOB_TILES_I16 = 1
+MJX_PREP_TILES_I16 = 1
 
 
 class MjxError(RuntimeError):
@@ -29,7 +31,7 @@ class RectJob(ctypes.Structure):
     _fields_ = [("coef", ctypes.c_void_p), ("tile", ctypes.c_void_p), ("alpha", ctypes.c_void_p),
                 ("blocks_per_row", ctypes.c_int32), ("plane_rows", ctypes.c_int32),
                 ("row0", ctypes.c_int32), ("col0", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
-                ("qtable", ctypes.c_int32)]
+                ("qtable", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 class HostRect(ctypes.Structure):
@@ -50,7 +52,8 @@ class TilePrep(ctypes.Structure):
     _fields_ = [("image", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
                 ("crop_x", ctypes.c_int32), ("crop_y", ctypes.c_int32), ("crop_w", ctypes.c_int32), ("crop_h", ctypes.c_int32),
                 ("off_x", ctypes.c_int32), ("off_y", ctypes.c_int32), ("source", ctypes.c_int32), ("target", ctypes.c_int32), ("ncomp", ctypes.c_int32),
-                ("h_samp", ctypes.c_int32 * 4), ("v_samp", ctypes.c_int32 * 4), ("tile", ctypes.c_void_p * 4), ("alpha_tile", ctypes.c_void_p * 4)]
+                ("h_samp", ctypes.c_int32 * 4), ("v_samp", ctypes.c_int32 * 4), ("tile", ctypes.c_void_p * 4), ("alpha_tile", ctypes.c_void_p * 4),
+                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 MJX_PREP_SOURCE_RGB, MJX_PREP_SOURCE_YCC, MJX_PREP_TARGET_RGB, MJX_PREP_TARGET_YCC = 1, 5, 2, 3
@@ -96,6 +99,7 @@ SYMBOLS = [
     ("mjx_synth_coef_batch", _i, [_vp, _sz, _u64, _u32, _u32, _u64, _sz, _vp, _vp]),
     ("mjx_synth_tile_batch", _i, [_vp, _sz, _u64, _u32, _u32, _u64, _sz, _vp]),
     ("mjx_synth_alpha_batch", _i, [_vp, _sz, _u64, _u32, _u32, _u64, _sz, _i, _vp]),
+    ("mjx_synth_tiles_i16_batch", _i, [_vp, _i, _sz, _u64, _u32, _u32, _u64, _sz, _i, _vp]),
     ("mjx_synth_coef", _i, [_vp, _u64, _u32, _u64, _sz, _vp, _vp]),
     ("mjx_synth_tile", _i, [_vp, _u64, _u32, _u64, _sz, _vp]),
     ("mjx_synth_alpha", _i, [_vp, _u64, _u32, _u64, _sz, _i, _vp]),

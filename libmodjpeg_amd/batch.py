@@ -14,7 +14,8 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import (MJX_PLAN_GROUP_BY_DENSITY, MJX_PREP_SOURCE_RGB, MJX_PREP_TARGET_YCC, DcJob, RectJob, TilePrep, check, lib)
+from ._lib import (MJX_JOB_TILES_I16, MJX_PLAN_GROUP_BY_DENSITY, MJX_PREP_SOURCE_RGB, MJX_PREP_TARGET_YCC, MJX_PREP_TILES_I16, DcJob, RectJob, TilePrep,
+                   check, lib)
 
 _BASE_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
                        14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
@@ -77,9 +78,11 @@ class ComposeBatch:
     """`n` images (global indices image0 .. image0+n-1) of one geometry, one dropon rectangle per
     image at MCU (mcu_x, mcu_y) of dropon_w x dropon_h pixels (multiples of 16), per-image tiles."""
 
-    def __init__(self, n, width, height, dropon_w, dropon_h, mcu_x, mcu_y, regime, image0=0, quality=85, device=None):
+    def __init__(self, n, width, height, dropon_w, dropon_h, mcu_x, mcu_y, regime, image0=0, quality=85, device=None, tiles_i16=False):
+        """tiles_i16: the prepared tiles are kept as the int16 coefficients they are made from
+        (MJX_JOB_TILES_I16: 512 instead of 768 bytes per block, the kernel converts) instead of floats"""
         assert dropon_w % 16 == 0 and dropon_h % 16 == 0
-        self.n, self.image0, self.regime = n, image0, regime
+        self.n, self.image0, self.regime, self.tiles_i16 = n, image0, regime, bool(tiles_i16)
         self.geo = Geometry420(width, height)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.quant = [quant_table(False, quality), quant_table(True, quality), quant_table(True, quality)]
@@ -90,8 +93,9 @@ class ComposeBatch:
             bpr, prow = self.geo.array_dims[c]
             assert row0 + rows <= prow and col0 + cols <= bpr, "dropon rectangle outside the image"
         self.coef = [torch.empty((n, prow, bpr, 64), dtype=torch.int16, device=self.device) for bpr, prow in self.geo.array_dims]
-        self.tile = [torch.empty((n, rows * cols, 64), dtype=torch.float32, device=self.device) for (_, _, rows, cols) in self.rect]
-        self.alpha = [torch.empty((n, rows * cols, 64), dtype=torch.float32, device=self.device) for (_, _, rows, cols) in self.rect]
+        tdt = torch.int16 if self.tiles_i16 else torch.float32
+        self.tile = [torch.empty((n, rows * cols, 64), dtype=tdt, device=self.device) for (_, _, rows, cols) in self.rect]
+        self.alpha = [torch.empty((n, rows * cols, 64), dtype=tdt, device=self.device) for (_, _, rows, cols) in self.rect]
         self.plan = ctypes.c_void_p()
         self.blocks_per_image = sum(r[2] * r[3] for r in self.rect)
 
@@ -107,7 +111,10 @@ class ComposeBatch:
             tblocks = self.rect[c][2] * self.rect[c][3]
             qp = self.quant[c].ctypes.data_as(vp)
             check(L.mjx_synth_coef_batch(vp(self.coef[c].data_ptr()), pblocks, self.image0, self.n, c, 0, pblocks, qp, s), "mjx_synth_coef_batch")
-            if self.regime != REGIME_DISC:
+            if self.regime != REGIME_DISC and self.tiles_i16:
+                check(L.mjx_synth_tiles_i16_batch(vp(self.tile[c].data_ptr()), 0, tblocks, self.image0, self.n, c, 0, tblocks, 0, s), "mjx_synth_tiles_i16_batch")
+                check(L.mjx_synth_tiles_i16_batch(vp(self.alpha[c].data_ptr()), 1, tblocks, self.image0, self.n, c, 0, tblocks, self.regime, s), "mjx_synth_tiles_i16_batch")
+            elif self.regime != REGIME_DISC:
                 check(L.mjx_synth_tile_batch(vp(self.tile[c].data_ptr()), tblocks, self.image0, self.n, c, 0, tblocks, s), "mjx_synth_tile_batch")
                 check(L.mjx_synth_alpha_batch(vp(self.alpha[c].data_ptr()), tblocks, self.image0, self.n, c, 0, tblocks, self.regime, s), "mjx_synth_alpha_batch")
         if self.regime == REGIME_DISC:
@@ -122,10 +129,11 @@ class ComposeBatch:
         image = np.ascontiguousarray(rgba[..., :3])
         alpha = np.ascontiguousarray(np.repeat(rgba[..., 3:4], 3, axis=2))
         p = TilePrep(image.ctypes.data, alpha.ctypes.data, dw, dh, 0, 0, dw, dh, 0, 0, MJX_PREP_SOURCE_RGB, MJX_PREP_TARGET_YCC, 3)
+        p.flags = MJX_PREP_TILES_I16 if self.tiles_i16 else 0
         one = []
         for c, (h, v) in enumerate(self.geo.samp):
             p.h_samp[c], p.v_samp[c] = h, v
-            t = torch.empty((2, self.rect[c][2] * self.rect[c][3], 64), dtype=torch.float32, device=self.device)
+            t = torch.empty((2, self.rect[c][2] * self.rect[c][3], 64), dtype=self.tile[c].dtype, device=self.device)
             p.tile[c], p.alpha_tile[c] = t[0].data_ptr(), t[1].data_ptr()
             one.append(t)
         check(lib().mjx_tiles_prepare(ctypes.byref(p)), "mjx_tiles_prepare")
@@ -144,7 +152,7 @@ class ComposeBatch:
                 bpr, prow = self.geo.array_dims[c]
                 row0, col0, rows, cols = self.rect[c]
                 jobs[j] = RectJob(self.coef[c][i].data_ptr(), self.tile[c][i].data_ptr(), self.alpha[c][i].data_ptr(),
-                                  bpr, prow, row0, col0, rows, cols, c)
+                                  bpr, prow, row0, col0, rows, cols, c, MJX_JOB_TILES_I16 if self.tiles_i16 else 0)
                 j += 1
         qt = np.ascontiguousarray(np.stack(self.quant))
         self.destroy_plan()
@@ -176,6 +184,18 @@ class ComposeBatch:
 
     def total_blocks(self):
         return self.n * self.blocks_per_image
+
+    def tiles_as_float(self, i, c):
+        """(tile, alpha) of image i, component c as the float arrays the reference's mj_compileddropon_t
+        would hold (for the oracle): the arrays themselves, or converted from the int16 form exactly as the
+        reference converts its JCOEFs (dropon.c:476-485, :548-566)"""
+        t, a = self.tile[c][i].cpu().numpy().reshape(-1), self.alpha[c][i].cpu().numpy().reshape(-1)
+        if not self.tiles_i16:
+            return np.ascontiguousarray(t), np.ascontiguousarray(a)
+        c0, c1 = 0.3535534, 0.5
+        k = np.array([(c0 if j // 8 == 0 else c1) * (c0 if j % 8 == 0 else c1) / 1020.0 for j in range(64)], np.float64)
+        af = (a.astype(np.float32).astype(np.float64).reshape(-1, 64) * k).astype(np.float32).reshape(-1)
+        return np.ascontiguousarray(t.astype(np.float32)), np.ascontiguousarray(af)
 
     def rect_clone(self):
         """device copy of every dropon rectangle (compose is in place: the pristine blocks)"""

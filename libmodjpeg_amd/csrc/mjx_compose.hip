@@ -313,12 +313,19 @@ MJX_DEV void dma16_so(const void *sbase, unsigned voff, unsigned lds_base) {
 // gather form (runs of a plan grouped by density, mjx_compose_plan_create_ex): the 8 blocks of the
 // octet are named by the run's gather table in LDS (tile block index, plane block index), so the
 // four tile / alpha pieces are 4 x 256-byte segments each instead of one contiguous KiB
+template <bool I16>
 MJX_DEV int16_t *dma_octet_gather(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned a_in, unsigned dC, unsigned dT, unsigned dA) {
     const int  bq = lane >> 4;
     const int2 e = *reinterpret_cast<const int2 *>(G + (o * kWaveBlocks + (lane >> 3)) * 2);
-    const int  t_lo = G[(o * kWaveBlocks + bq) * 2], t_hi = G[(o * kWaveBlocks + 4 + bq) * 2];
     int16_t   *cptr = job.coef + (size_t)(unsigned)e.y * 64 + (lane & 7) * 8;
     dma16(cptr, dC);
+    if constexpr(I16) { // int16 tiles: one piece each, 8 x 128-byte segments, lane (b, r) <- row r of its block
+        const unsigned off = (unsigned)e.x * 128u + (unsigned)(lane & 7) * 16u;
+        dma16_so(job.tile, off, dT);
+        dma16_so(job.alpha, off, dT + 1024);
+        return cptr;
+    }
+    const int t_lo = G[(o * kWaveBlocks + bq) * 2], t_hi = G[(o * kWaveBlocks + 4 + bq) * 2];
     dma16_so(job.tile, (unsigned)t_lo * 256u + t_in, dT);
     dma16_so(job.tile, (unsigned)t_hi * 256u + t_in, dT + 1024);
     dma16_so(job.alpha, (unsigned)t_lo * 256u + a_in, dA);
@@ -327,7 +334,8 @@ MJX_DEV int16_t *dma_octet_gather(const DevJob &job, int o, int lane, const int 
 }
 
 // generic (slow) form: any octet, lanes past the end of the job clamp to its last block.
-// Issues the 5 pieces and leaves `a` describing this octet.
+// Issues the pieces and leaves `a` describing this octet.
+template <bool I16>
 MJX_DEV int16_t *dma_octet_generic(const DevJob &job, int n0, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
     const int last = job.nblocks - 1;
     int       nb = n0 + (lane >> 3);
@@ -338,6 +346,14 @@ MJX_DEV int16_t *dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
     a.pblk = __umul24((unsigned)(job.row0 + trow), (unsigned)job.bpr) + (unsigned)(job.col0 + a.tcol);
     int16_t *cptr = job.coef + (size_t)a.pblk * 64 + (lane & 7) * 8;
     dma16(cptr, dC);
+    if constexpr(I16) { // int16 tiles: natural order, 16 bytes per lane, the clamped block like the JCOEF piece
+        a.toff = (unsigned)n0 * 128u + (unsigned)lane * 16u;
+        a.aoff = a.toff;
+        const size_t at = (size_t)nb * 128 + (size_t)(lane & 7) * 16;
+        dma16(reinterpret_cast<const char *>(job.tile) + at, dT);
+        dma16(reinterpret_cast<const char *>(job.alpha) + at, dT + 1024);
+        return cptr;
+    }
     const int bq = lane >> 4;
     unsigned  t_in, a_in;
     chunk_in_block(lane, t_in, a_in);
@@ -360,6 +376,7 @@ MJX_DEV int16_t *dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
 }
 
 // fast form: the octet after the one described by `a`, which must be a full octet (no clamping)
+template <bool I16>
 MJX_DEV int16_t *dma_octet_next(const DevJob &job, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
     a.tcol += kWaveBlocks;
     a.pblk += kWaveBlocks;
@@ -370,6 +387,12 @@ MJX_DEV int16_t *dma_octet_next(const DevJob &job, int lane, OctetAddr &a, unsig
     }
     int16_t *cptr = job.coef + (size_t)a.pblk * 64 + (lane & 7) * 8;
     dma16(cptr, dC);
+    if constexpr(I16) {
+        a.toff += kWaveBlocks * 128u;
+        dma16_so(job.tile, a.toff, dT);
+        dma16_so(job.alpha, a.toff, dT + 1024);
+        return cptr;
+    }
     a.toff += kWaveBlocks * 256u;
     a.aoff += kWaveBlocks * 256u;
     dma16x2(job.tile, a.toff, dT);
@@ -385,11 +408,12 @@ struct RunCtx {
     const int *G;       // gather: the run's table in LDS
     unsigned   t_in, a_in;
 };
+template <bool I16>
 MJX_DEV int16_t *dma_octet(const DevJob &job, const RunCtx &rc, int o, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
-    if(rc.gather) return dma_octet_gather(job, o, lane, rc.G, rc.t_in, rc.a_in, dC, dT, dA);
+    if(rc.gather) return dma_octet_gather<I16>(job, o, lane, rc.G, rc.t_in, rc.a_in, dC, dT, dA);
     const int n = rc.first + o * kWaveBlocks;
-    if(o != 0 && n + kWaveBlocks <= job.nblocks) return dma_octet_next(job, lane, a, dC, dT, dA);
-    return dma_octet_generic(job, n, lane, a, dC, dT, dA);
+    if(o != 0 && n + kWaveBlocks <= job.nblocks) return dma_octet_next<I16>(job, lane, a, dC, dT, dA);
+    return dma_octet_generic<I16>(job, n, lane, a, dC, dT, dA);
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
@@ -494,6 +518,13 @@ MJX_DEV void octet_compute(int16_t *cptr, int lane, int b, int r, const float *q
 #ifndef MJX_COMPOSE_MIN_WAVES
 #define MJX_COMPOSE_MIN_WAVES 3
 #endif
+// I16: the tiles are int16 coefficients instead of floats (mjx.h MJX_JOB_TILES_I16): 3 pieces of 1 KiB
+// per octet instead of 5, 512 instead of 768 bytes of HBM traffic per block.  A prepared tile IS an
+// int16 JCOEF converted to float (reference dropon.c:476-485, :542-566), so the conversion moves
+// into the kernel: tile = (float)coef exactly, weight = (float)((double)(float)coef * K) with the
+// reference's double constants, computed by the lane that holds the row and written into the same
+// rotated, half-swapped LDS image the float path's DMA fills.
+template <bool I16>
 __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void compose_kernel(const DevJob *__restrict__ jobs, const Run *__restrict__ runs, int nruns,
                                                                                             const uint16_t *__restrict__ qtab, const float *__restrict__ rqtab,
                                                                                             const GatherEntry *__restrict__ gather) {
@@ -544,33 +575,65 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
     int16_t  *cp[MJX_DEPTH + 1]; // cp[d] = store address of octet i + d
     static_for<MJX_DEPTH>([&](auto D) {
         cp[D] = nullptr;
-        if(D < noct) cp[D] = dma_octet(job, rc, D, lane, addr, lds_addr(L.C[D]), lds_addr(L.T[D]), lds_addr(L.A[D]));
+        if(D < noct) cp[D] = dma_octet<I16>(job, rc, D, lane, addr, lds_addr(L.C[D]), lds_addr(L.T[D]), lds_addr(L.A[D]));
     });
 
-    const int ph = (b >> 1) & 1;
-    int       sc = 0, sa = 0; // LDS slots of octet i: i mod DEPTH, i mod (DEPTH + 1)
+    const int     ph = (b >> 1) & 1;
+    constexpr int kPieces = I16 ? 3 : 5; // VMEM operations per octet before its store
+    // I16: this lane converts the alpha row stored at position r of its block = source row (r - 2b) & 7
+    const int    k_src = (r - 2 * b) & 7;
+    const double kc0 = 0.3535534, kc1 = 0.5; // the reference's literals (dropon.c:548-566)
+    const double k_first = (k_src == 0 ? kc0 : kc1) * kc0 / 1020.0, k_rest = (k_src == 0 ? kc0 : kc1) * kc1 / 1020.0;
+    int          sc = 0, sa = 0; // LDS slots of octet i: i mod DEPTH, i mod (DEPTH + 1)
 #pragma unroll 1
     for(int i = 0; i < noct; ++i) {
         const int ahead = noct - 1 - i < MJX_DEPTH - 1 ? noct - 1 - i : MJX_DEPTH - 1; // octets i+1.. already in flight
-        wait_vmcnt_n(5 * ahead + (i < MJX_DEPTH ? i : MJX_DEPTH));
+        wait_vmcnt_n(kPieces * ahead + (i < MJX_DEPTH ? i : MJX_DEPTH));
 
-        float       *pC = L.C[sc], *pT = L.T[sc];
-        const float *pA = L.A[sa];
-        const uint4  c4 = *reinterpret_cast<const uint4 *>(pC + lane * 4);
-        const float4 t_lo = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4 * ph);
-        const float4 t_hi = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4 - 4 * ph);
-        // the alpha row stored at row position r of this block = source row (r - 2b) & 7: only the
-        // skip ballots of octet_blend look at it (row_mask)
-        const float4 a_lo = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 * ph);
-        const float4 a_hi = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 - 4 * ph);
+        float      *pC = L.C[sc], *pT = L.T[sc];
+        float      *pA = L.A[sa];
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(pC + lane * 4);
+        float4      t_lo, t_hi, a_lo, a_hi;
+        uint4       ti4, ai4;
+        if constexpr(I16) { // tile row r of this block; alpha source row k_src of this block (8 x int16 each)
+            ti4 = *reinterpret_cast<const uint4 *>(pT + lane * 4);
+            ai4 = *reinterpret_cast<const uint4 *>(pT + 256 + (b * 8 + k_src) * 4);
+        }
+        else {
+            t_lo = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4 * ph);
+            t_hi = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4 - 4 * ph);
+            // the alpha row stored at row position r of this block = source row (r - 2b) & 7: only the
+            // skip ballots of octet_blend look at it (row_mask)
+            a_lo = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 * ph);
+            a_hi = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 - 4 * ph);
+        }
         // the JCOEF and tile slots are about to be overwritten by the DMA of octet i + DEPTH
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
         int sn = sa + MJX_DEPTH; // alpha slot of octet i + DEPTH
         sn = sn > MJX_DEPTH ? sn - (MJX_DEPTH + 1) : sn;
         cp[MJX_DEPTH] = cp[0];
-        if(i + MJX_DEPTH < noct) cp[MJX_DEPTH] = dma_octet(job, rc, i + MJX_DEPTH, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(L.A[sn]));
+        if(i + MJX_DEPTH < noct) cp[MJX_DEPTH] = dma_octet<I16>(job, rc, i + MJX_DEPTH, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(L.A[sn]));
 
+        if constexpr(I16) {
+            const unsigned tw[4] = {ti4.x, ti4.y, ti4.z, ti4.w}, aw[4] = {ai4.x, ai4.y, ai4.z, ai4.w};
+            float          t[8], a[8];
+            static_for<4>([&](auto P) {
+                t[2 * P] = s16_lo_to_f32(tw[P]); // dropon.c:476-485: tile = (float)coef
+                t[2 * P + 1] = s16_hi_to_f32(tw[P]);
+                // dropon.c:548-566: weight = (float)((float)coef * K), K a double constant (the DC already carries +1024)
+                a[2 * P] = (float)((double)s16_lo_to_f32(aw[P]) * (P == 0 ? k_first : k_rest));
+                a[2 * P + 1] = (float)((double)s16_hi_to_f32(aw[P]) * k_rest);
+            });
+            t_lo = make_float4(t[0], t[1], t[2], t[3]);
+            t_hi = make_float4(t[4], t[5], t[6], t[7]);
+            a_lo = make_float4(a[0], a[1], a[2], a[3]);
+            a_hi = make_float4(a[4], a[5], a[6], a[7]);
+            // the float image the broadcast weight reads expect: this row at position r, halves swapped per block
+            *reinterpret_cast<float4 *>(pA + lane * 8 + 4 * ph) = a_lo;
+            *reinterpret_cast<float4 *>(pA + lane * 8 + 4 - 4 * ph) = a_hi;
+            wave_sync();
+        }
         octet_compute(cp[0], lane, b, r, qrow, c4, t_lo, t_hi, a_lo, a_hi, pA, L.Z);
 
         static_for<MJX_DEPTH>([&](auto D) { cp[D] = cp[D + 1]; });
@@ -579,10 +642,11 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
     }
 }
 
-int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, const GatherEntry *gather, hipStream_t s) {
+int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, const GatherEntry *gather, bool tiles_i16, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
     const int groups = (nruns + MJX_GROUP_WAVES - 1) / MJX_GROUP_WAVES;
-    hipLaunchKernelGGL(compose_kernel, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, jobs, runs, nruns, qtab, rqtab, gather);
+    if(tiles_i16) hipLaunchKernelGGL(compose_kernel<true>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, jobs, runs, nruns, qtab, rqtab, gather);
+    else hipLaunchKernelGGL(compose_kernel<false>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, jobs, runs, nruns, qtab, rqtab, gather);
     return check_hip(hipGetLastError(), "compose_kernel launch", MJX_ERR_LAUNCH);
 }
 
@@ -591,6 +655,7 @@ int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_
 // similar density into octets.  Walks the consecutive runs of a plan: lane (b, r) counts row r of
 // its block, the 8 lanes of a block add up, lane r == 0 writes the byte.
 // ------------------------------------------------------------------------------------------
+template <bool I16>
 __global__ __launch_bounds__(256) void alpha_nnz_kernel(const DevJob *__restrict__ jobs, const Run *__restrict__ runs, int nruns, uint8_t *__restrict__ nnz) {
     const int lane = threadIdx.x & 63, b = lane >> 3, r = lane & 7;
     const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -600,8 +665,17 @@ __global__ __launch_bounds__(256) void alpha_nnz_kernel(const DevJob *__restrict
     for(int o = 0; o < run.noctets; ++o) {
         const int    n = run.first + o * kWaveBlocks + b;
         const int    nc = n < job.nblocks ? n : job.nblocks - 1;
-        const float4 lo = *reinterpret_cast<const float4 *>(job.alpha + (size_t)nc * 64 + r * 8), hi = *reinterpret_cast<const float4 *>(job.alpha + (size_t)nc * 64 + r * 8 + 4);
-        int          c = (lo.x != 0.0f) + (lo.y != 0.0f) + (lo.z != 0.0f) + (lo.w != 0.0f) + (hi.x != 0.0f) + (hi.y != 0.0f) + (hi.z != 0.0f) + (hi.w != 0.0f);
+        int          c;
+        if constexpr(I16) { // an int16 weight is zero exactly when its float is
+            const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const int16_t *>(job.alpha) + (size_t)nc * 64 + r * 8);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+            c = 0;
+            for(int k = 0; k < 4; ++k) c += ((w[k] & 0xFFFFu) != 0u) + ((w[k] >> 16) != 0u);
+        }
+        else {
+            const float4 lo = *reinterpret_cast<const float4 *>(job.alpha + (size_t)nc * 64 + r * 8), hi = *reinterpret_cast<const float4 *>(job.alpha + (size_t)nc * 64 + r * 8 + 4);
+            c = (lo.x != 0.0f) + (lo.y != 0.0f) + (lo.z != 0.0f) + (lo.w != 0.0f) + (hi.x != 0.0f) + (hi.y != 0.0f) + (hi.z != 0.0f) + (hi.w != 0.0f);
+        }
         c += __shfl_xor(c, 1);
         c += __shfl_xor(c, 2);
         c += __shfl_xor(c, 4);
@@ -609,9 +683,10 @@ __global__ __launch_bounds__(256) void alpha_nnz_kernel(const DevJob *__restrict
     }
 }
 
-int launch_alpha_nnz(const DevJob *jobs, const Run *runs, int nruns, uint8_t *nnz, hipStream_t s) {
+int launch_alpha_nnz(const DevJob *jobs, const Run *runs, int nruns, uint8_t *nnz, bool tiles_i16, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
-    hipLaunchKernelGGL(alpha_nnz_kernel, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, jobs, runs, nruns, nnz);
+    if(tiles_i16) hipLaunchKernelGGL(alpha_nnz_kernel<true>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, jobs, runs, nruns, nnz);
+    else hipLaunchKernelGGL(alpha_nnz_kernel<false>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, jobs, runs, nruns, nnz);
     return check_hip(hipGetLastError(), "alpha_nnz_kernel launch", MJX_ERR_LAUNCH);
 }
 

@@ -83,8 +83,8 @@ struct ArenaLease {
 };
 
 // launchers implemented in the kernel translation units
-int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, const GatherEntry *gather, hipStream_t s);
-int launch_alpha_nnz(const DevJob *jobs, const Run *runs, int nruns, uint8_t *nnz, hipStream_t s);
+int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, const GatherEntry *gather, bool tiles_i16, hipStream_t s);
+int launch_alpha_nnz(const DevJob *jobs, const Run *runs, int nruns, uint8_t *nnz, bool tiles_i16, hipStream_t s);
 int run_octets();
 int launch_convolve(const float *x, float *y, float w, int k, int l, int nblocks, hipStream_t s);
 int launch_effect_dc(const DevDcJob *jobs, int njobs, int64_t max_blocks_per_job, hipStream_t s);
@@ -93,6 +93,7 @@ int launch_effect_zero(int16_t *coef, int bpr, int rows, int cols, int keep_dc, 
 // mjx_synth.hip: one launch per array of a batch (blockIdx.y = image); image_stride in blocks; d_q = DEVICE u16[64]
 int launch_synth_coef(int16_t *dst, size_t image_stride, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first, size_t n, const uint16_t *d_q,
                       hipStream_t s);
+int launch_synth_i16(int kind, int16_t *dst, size_t image_stride, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first, size_t n, int regime, hipStream_t s);
 int launch_synth_f32(int kind, float *dst, size_t image_stride, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first, size_t n, int regime, hipStream_t s);
 
 } // namespace mjx

@@ -91,6 +91,7 @@ struct mjx_compose_plan {
     int          njobs = 0;
     int64_t      blocks = 0;
     int64_t      gather_octets = 0;
+    bool         tiles_i16 = false;
 };
 
 struct mjx_dc_plan {
@@ -190,6 +191,7 @@ struct Tables {
     std::vector<int8_t>      run_class; // density class of each run's first octet (parallel to runs)
     int64_t                  blocks = 0;
     int                      run_len = 0;
+    bool                     tiles_i16 = false; // MJX_JOB_TILES_I16 on every job
 };
 
 // density classes of a block by its number of non-zero weights.  Measured on MI355X:
@@ -293,6 +295,9 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
         if(j.row0 < 0 || j.col0 < 0 || j.blocks_per_row <= 0 || j.col0 + (int64_t)j.cols > j.blocks_per_row) return MJX_ERR_BAD_ARG;
         if(j.plane_rows > 0 && j.row0 + (int64_t)j.rows > j.plane_rows) return MJX_ERR_BAD_ARG;
         if(j.cols > kMaxJobBlocks) return MJX_ERR_BAD_ARG;
+        if((j.flags & ~MJX_JOB_TILES_I16) != 0) return MJX_ERR_BAD_ARG;
+        if(t.jobs.empty()) t.tiles_i16 = (j.flags & MJX_JOB_TILES_I16) != 0;
+        else if(t.tiles_i16 != ((j.flags & MJX_JOB_TILES_I16) != 0)) return MJX_ERR_BAD_ARG; // one tile format per plan
 
         const int max_rows = (int)(kMaxJobBlocks / j.cols);
         for(int r0 = 0; r0 < j.rows; r0 += max_rows) {
@@ -300,8 +305,9 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
             if(t.blocks + (int64_t)rows * j.cols > 0x7FFFFFFFll) return MJX_ERR_BAD_ARG; // one plan: < 2^31 blocks
             DevJob    d;
             d.coef = j.coef;
-            d.tile = j.tile + (size_t)r0 * (size_t)j.cols * 64;
-            d.alpha = j.alpha + (size_t)r0 * (size_t)j.cols * 64;
+            // (a float is two int16: an int16 tile array advances half as fast)
+            d.tile = j.tile + (size_t)r0 * (size_t)j.cols * ((j.flags & MJX_JOB_TILES_I16) ? 32 : 64);
+            d.alpha = j.alpha + (size_t)r0 * (size_t)j.cols * ((j.flags & MJX_JOB_TILES_I16) ? 32 : 64);
             d.bpr = j.blocks_per_row;
             d.row0 = j.row0 + r0;
             d.col0 = j.col0;
@@ -336,6 +342,7 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
     if(p == nullptr) return MJX_ERR_MEMORY;
     p->njobs = (int)t.jobs.size();
     p->blocks = t.blocks;
+    p->tiles_i16 = t.tiles_i16;
 
     do {
         if(p->njobs == 0) break;
@@ -356,7 +363,7 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
             err = check_hip(hipMalloc((void **)&d_tmp, t.runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY);
             if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_nnz, (size_t)t.blocks), "hipMalloc(nnz)", MJX_ERR_MEMORY);
             if(err == MJX_OK) err = check_hip(hipMemcpy(d_tmp, t.runs.data(), t.runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH);
-            if(err == MJX_OK) err = launch_alpha_nnz(p->d_jobs, d_tmp, (int)t.runs.size(), d_nnz, nullptr);
+            if(err == MJX_OK) err = launch_alpha_nnz(p->d_jobs, d_tmp, (int)t.runs.size(), d_nnz, t.tiles_i16, nullptr);
             if(err == MJX_OK) err = check_hip(hipMemcpy(nnz.data(), d_nnz, (size_t)t.blocks, hipMemcpyDeviceToHost), "hipMemcpy(nnz)", MJX_ERR_LAUNCH);
             if(d_tmp) (void)hipFree(d_tmp);
             if(d_nnz) (void)hipFree(d_nnz);
@@ -391,7 +398,7 @@ int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan) { return plan ? 
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
     if(plan->nruns == 0) return MJX_OK;
-    return launch_compose(plan->d_jobs, plan->d_runs, plan->nruns, plan->d_q, plan->d_rq, plan->d_gather, (hipStream_t)stream);
+    return launch_compose(plan->d_jobs, plan->d_runs, plan->nruns, plan->d_q, plan->d_rq, plan->d_gather, plan->tiles_i16, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -674,7 +681,7 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     MJX_HIP(hipMemcpyAsync(base, arena->pin, packet, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
 
     err = launch_compose(reinterpret_cast<const DevJob *>(base + o_jobs), reinterpret_cast<const Run *>(base + o_runs), (int)t.runs.size(),
-                         reinterpret_cast<const uint16_t *>(base + o_q), reinterpret_cast<const float *>(base + o_rq), nullptr, s);
+                         reinterpret_cast<const uint16_t *>(base + o_q), reinterpret_cast<const float *>(base + o_rq), nullptr, false, s);
     if(err == MJX_OK) {
         k = 0;
         for(int i = 0; i < n && err == MJX_OK; ++i) {
@@ -963,6 +970,15 @@ int mjx_synth_alpha_batch(float *dst, size_t image_stride_blocks, uint64_t image
     if(nimages == 0 || nblocks == 0) return MJX_OK;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
     return launch_synth_f32(1, dst, image_stride_blocks, image0, nimages, comp, first_block, nblocks, regime, (hipStream_t)stream);
+}
+
+int mjx_synth_tiles_i16_batch(int16_t *dst, int kind, size_t image_stride_blocks, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first_block,
+                              size_t nblocks, int regime, mjx_stream_t stream) {
+    if(dst == nullptr) return MJX_ERR_NULL_DATA;
+    if(!aligned16(dst) || (kind != 0 && kind != 1) || (kind == 1 && (regime < 1 || regime > 4)) || (nimages > 1 && image_stride_blocks < nblocks)) return MJX_ERR_BAD_ARG;
+    if(nimages == 0 || nblocks == 0) return MJX_OK;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    return launch_synth_i16(kind, dst, image_stride_blocks, image0, nimages, comp, first_block, nblocks, regime, (hipStream_t)stream);
 }
 
 int mjx_synth_coef(int16_t *dst, uint64_t image, uint32_t comp, uint64_t first_block, size_t nblocks, const uint16_t *q, mjx_stream_t stream) {

@@ -49,6 +49,27 @@ __global__ __launch_bounds__(256) void synth_f32_kernel(float *__restrict__ dst,
     p[1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
+// the same tiles as int16 coefficients (MJX_JOB_TILES_I16): the integer the float tile is made from —
+// KIND 0: the tile value itself; KIND 1: the alpha-DCT coefficient with its DC offset, before scaling
+template <int KIND>
+__global__ __launch_bounds__(256) void synth_i16_kernel(int16_t *__restrict__ dst, size_t image_stride, uint64_t image0, uint32_t comp, uint64_t first, size_t nblocks,
+                                                        int regime) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t blk = t >> 3;
+    const int    r = (int)(t & 7);
+    if(blk >= nblocks) return;
+    const uint64_t stream = mjx_stream(KIND == 0 ? MJX_SEED_TILE : MJX_SEED_ALPHA, image0 + blockIdx.y, comp);
+    int            o[8];
+#pragma unroll
+    for(int u = 0; u < 8; ++u) {
+        if(KIND == 0) o[u] = (int)mjx_synth_tile(stream, first + blk, r * 8 + u); // integer-valued by construction
+        else o[u] = mjx_synth_alpha_int(stream, first + blk, r * 8 + u, regime);
+    }
+    int16_t *p = dst + (size_t)blockIdx.y * image_stride * 64 + blk * 64 + r * 8;
+    *reinterpret_cast<uint4 *>(p) = make_uint4(((unsigned)o[0] & 0xFFFFu) | ((unsigned)o[1] << 16), ((unsigned)o[2] & 0xFFFFu) | ((unsigned)o[3] << 16),
+                                               ((unsigned)o[4] & 0xFFFFu) | ((unsigned)o[5] << 16), ((unsigned)o[6] & 0xFFFFu) | ((unsigned)o[7] << 16));
+}
+
 constexpr uint32_t kMaxGridY = 65535;
 
 static unsigned synth_grid_x(size_t nblocks) { return (unsigned)((nblocks * 8 + 255) / 256); }
@@ -62,6 +83,17 @@ int launch_synth_coef(int16_t *dst, size_t image_stride, uint64_t image0, uint32
                            n, d_q);
     }
     return check_hip(hipGetLastError(), "synth_coef_kernel launch", MJX_ERR_LAUNCH);
+}
+
+int launch_synth_i16(int kind, int16_t *dst, size_t image_stride, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first, size_t n, int regime, hipStream_t s) {
+    if(n == 0) return MJX_OK;
+    for(uint32_t i0 = 0; i0 < nimages; i0 += kMaxGridY) {
+        const uint32_t ni = nimages - i0 < kMaxGridY ? nimages - i0 : kMaxGridY;
+        int16_t       *d = dst + (size_t)i0 * image_stride * 64;
+        if(kind == 0) hipLaunchKernelGGL(synth_i16_kernel<0>, dim3(synth_grid_x(n), ni), dim3(256), 0, s, d, image_stride, image0 + i0, comp, first, n, 0);
+        else hipLaunchKernelGGL(synth_i16_kernel<1>, dim3(synth_grid_x(n), ni), dim3(256), 0, s, d, image_stride, image0 + i0, comp, first, n, regime);
+    }
+    return check_hip(hipGetLastError(), "synth_i16_kernel launch", MJX_ERR_LAUNCH);
 }
 
 int launch_synth_f32(int kind, float *dst, size_t image_stride, uint64_t image0, uint32_t nimages, uint32_t comp, uint64_t first, size_t n, int regime, hipStream_t s) {

@@ -45,6 +45,7 @@ struct PrepJob {
     const unsigned char *image, *alpha; // DEVICE: the crop window, 3 bytes per pixel, crop_w per row
     int32_t  crop_w, crop_h, off_x, off_y;
     int32_t  convert;                   // 1: RGB -> YCbCr
+    int32_t  i16;                       // 1: the tiles are written as int16 coefficients (MJX_PREP_TILES_I16)
     int32_t  nblocks;                   // all components
     PrepComp comp[3];
 };
@@ -112,15 +113,14 @@ template <int C, int R> __device__ __forceinline__ void prep_block(const PrepJob
         acc >>= S2[k];
         // quantiser 1, divisor 8 (jcdctmgr.c forward_DCT): round half away from zero
         int q = acc < 0 ? -((-acc + 4) >> 3) : ((acc + 4) >> 3);
-        float v;
-        if(kind == 0) {
-            v = (float)(int)(short)q; // dropon.c:476-485
+        if(kind == 1 && (k | l) == 0) q = (int)(short)(unsigned short)((unsigned)q + 1024u); // dropon.c:542 on a JCOEF
+        if(job.i16) { // the coefficient itself: the compose kernel converts (MJX_JOB_TILES_I16)
+            reinterpret_cast<int16_t *>(out)[k * 8 + l] = (int16_t)q;
         }
         else {
-            if((k | l) == 0) q = (int)(short)(unsigned short)((unsigned)q + 1024u); // dropon.c:542 on a JCOEF
-            v = (float)((double)(float)(int)(short)q * alpha_scale(k, l));             // dropon.c:548-566
+            out[k * 8 + l] = kind == 0 ? (float)(int)(short)q                                   // dropon.c:476-485
+                                       : (float)((double)(float)(int)(short)q * alpha_scale(k, l)); // dropon.c:548-566
         }
-        out[k * 8 + l] = v;
     }
     __syncthreads();
 }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void tileprep_kernel(PrepJob job) {
     if(id >= job.comp[2].first) c = 2;
     const PrepComp pc = job.comp[c];
     const int      blk = id - pc.first, brow = blk / pc.cols, bcol = blk - brow * pc.cols;
-    float         *out = (kind == 0 ? pc.tile : pc.alpha) + (size_t)blk * 64;
+    float         *out = (kind == 0 ? pc.tile : pc.alpha) + (size_t)blk * (job.i16 ? 32 : 64); // an int16 block is 32 floats long
     if(pc.nx == 8 && pc.ny == 8) prep_block<8, 8>(job, c, kind, brow, bcol, out, lane, s, d1);
     else if(pc.nx == 16 && pc.ny == 16) prep_block<16, 16>(job, c, kind, brow, bcol, out, lane, s, d1);
     else if(pc.nx == 16) prep_block<16, 8>(job, c, kind, brow, bcol, out, lane, s, d1);
@@ -151,6 +151,7 @@ using namespace mjx;
 extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
     if(p == nullptr) return MJX_ERR_NULL_DATA;
     if(p->image == nullptr || p->alpha == nullptr) return MJX_ERR_NULL_DATA;
+    if((p->flags & ~MJX_PREP_TILES_I16) != 0) return MJX_ERR_BAD_ARG;
     if(p->ncomp != 3 || p->crop_w <= 0 || p->crop_h <= 0 || p->off_x < 0 || p->off_y < 0 || p->crop_x < 0 || p->crop_y < 0) return MJX_ERR_BAD_ARG;
     if(p->crop_x + (int64_t)p->crop_w > p->width || p->crop_y + (int64_t)p->crop_h > p->height) return MJX_ERR_BAD_ARG;
     int convert;
@@ -205,6 +206,7 @@ extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
     job.off_x = p->off_x;
     job.off_y = p->off_y;
     job.convert = convert;
+    job.i16 = (p->flags & MJX_PREP_TILES_I16) ? 1 : 0;
     job.nblocks = (int32_t)total;
     hipLaunchKernelGGL(tileprep_kernel, dim3((unsigned)(2 * total)), dim3(64), 0, s, job);
     err = check_hip(hipGetLastError(), "tileprep_kernel launch", MJX_ERR_LAUNCH);

@@ -154,6 +154,35 @@ def test_density_grouping_is_only_a_schedule(torch_mod, dims):
                 assert np.array_equal(out[0][c][i].cpu().numpy().reshape(-1), want), (regime, i, c)
 
 
+@pytest.mark.parametrize("regime,group", [(1, True), (2, True), (3, True), (4, True), (4, False), (5, True)])
+def test_int16_tiles_equal_float_tiles(torch_mod, regime, group):
+    """MJX_JOB_TILES_I16: the tiles kept as the int16 coefficients they are made from and converted in
+    the kernel (tile = (float)coef; weight = (float)((float)coef * K) with the reference's double K) give
+    the same planes as the float tiles, in every regime, with and without the gather table, for ragged
+    rectangles too; and the float form derived from the int16 arrays on the host equals the float arrays"""
+    torch = torch_mod
+    from libmodjpeg_amd.batch import ComposeBatch
+    for dw, dh, n in ((256, 256, 128), (48, 80, 16)):
+        out = {}
+        for i16 in (False, True):
+            b = ComposeBatch(n, 1920, 1080, dw, dh, 52, 26, regime, tiles_i16=i16)
+            b.fill_synthetic()
+            b.build_plan(group_by_density=group)
+            if i16:
+                for c in range(3):
+                    tf, af = b.tiles_as_float(3, c)
+                    assert np.array_equal(tf.view(np.uint32), keep[c][0].view(np.uint32)) and np.array_equal(af.view(np.uint32), keep[c][1].view(np.uint32)), (regime, c)
+            else:
+                keep = [b.tiles_as_float(3, c) for c in range(3)]
+            b.run()
+            b.run()  # twice: the second pass starts from composed planes
+            torch.cuda.synchronize()
+            out[i16] = [_rect_view(b, c).clone() for c in range(3)]
+            del b
+        for c in range(3):
+            assert torch.equal(out[False][c], out[True][c]), (regime, group, dw, c)
+
+
 def test_real_mask_regime_a5(torch_mod):
     """regime A5: the tiles of a real overlay (hard-edged disc) prepared from pixels on the device;
     the alpha tiles have the density profile the survey measured for such a mask (bimodal, ~7 non-zero
