@@ -174,7 +174,7 @@ def test_gpu_tile_preparation_equals_libjpeg_on_random_overlays(shim, tmp_path, 
     target = str(tmp_path / "target.jpg")
     _make_input(target, ("200", "120"), sampling)
     probe = os.path.join(HOST, "mjhost_probe")
-    for trial in range(14):
+    for trial in range(int(os.environ.get("MJX_TILEPREP_TRIALS", "14"))):  # a soak run sets more
         w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
         cs = [1, 2, 5, 6][trial % 4]
         bpp = 4 if cs in (2, 6) else 3
