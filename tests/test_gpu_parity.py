@@ -368,3 +368,44 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
         O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 2]), host[j][1].reshape(-1), host[j][2].reshape(-1))
         assert np.array_equal(results[1][j].reshape(-1), want), ("plain plan", j)
         assert np.array_equal(results[0][j].reshape(-1), want), ("grouped plan", j)
+
+
+def test_int16_tile_plans_vs_oracle_on_full_range_values(mj):
+    """MJX_JOB_TILES_I16 on arbitrary int16 contents (tile and alpha coefficients over the whole
+    range, every density, ragged rectangles, grouped by density): the kernel's conversions
+    tile = (float)coef and weight = (float)((double)(float)coef * K) equal the host's, so the planes
+    equal the oracle's fed with the converted float tiles"""
+    import torch
+    from libmodjpeg_amd._lib import MJX_JOB_TILES_I16, MJX_PLAN_GROUP_BY_DENSITY, RectJob, check, lib
+    rng = np.random.default_rng(2027)
+    c0, c1 = 0.3535534, 0.5
+    kk = np.array([(c0 if j // 8 == 0 else c1) * (c0 if j % 8 == 0 else c1) / 1020.0 for j in range(64)], np.float64)
+    shapes = [(40, 50, 3, 5, 13, 21), (9, 33, 2, 30, 7, 3), (8, 8, 1, 1, 1, 1), (30, 30, 0, 0, 30, 30)]
+    quants = np.stack([rng.integers(1, 256, 64), rng.integers(1, 2000, 64)]).astype(np.uint16)
+    host, jobs = [], (RectJob * len(shapes))()
+    for prow, bpr, row0, col0, rows, cols in shapes:
+        n = rows * cols
+        coef = rng.integers(-1024, 1024, (prow, bpr, 64)).astype(np.int16)
+        tile = rng.integers(-32768, 32768, (n, 64)).astype(np.int16)
+        alpha = rng.integers(-32768, 32768, (n, 64)).astype(np.int16)
+        alpha = np.where(rng.random((n, 64)) < rng.choice([0.0, 0.05, 0.3, 1.0], n)[:, None], alpha, np.int16(0)).astype(np.int16)
+        host.append((coef, np.ascontiguousarray(tile), np.ascontiguousarray(alpha)))
+    for flags in (0, MJX_PLAN_GROUP_BY_DENSITY):
+        dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
+        for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
+            jobs[j] = RectJob(dev[j][0].data_ptr(), dev[j][1].data_ptr(), dev[j][2].data_ptr(), bpr, prow, row0, col0, rows, cols, j % 2, MJX_JOB_TILES_I16)
+        plan = ctypes.c_void_p()
+        check(lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 2, flags), "plan")
+        check(lib().mjx_compose_run(plan, None), "run")
+        torch.cuda.synchronize()
+        lib().mjx_compose_plan_destroy(plan)
+        for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
+            want = host[j][0].reshape(-1).copy()
+            tf = host[j][1].astype(np.float32).reshape(-1)
+            af = (host[j][2].astype(np.float32).astype(np.float64) * kk).astype(np.float32).reshape(-1)
+            O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 2]), tf, af)
+            assert np.array_equal(dev[j][0].cpu().numpy().reshape(-1), want), (flags, j)
+    # a plan must not mix the two tile formats
+    jobs[0].flags = 0
+    plan = ctypes.c_void_p()
+    assert lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 2, 0) == mj._lib.MJX_ERR_BAD_ARG
