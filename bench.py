@@ -89,6 +89,8 @@ def init_ranks(world):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
+    if os.path.isdir("/sys/class/net/lo"):  # one node: the ranks talk over the loopback interface, whatever the host name resolves to
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
 
 
