@@ -91,7 +91,18 @@ def init_ranks(world):
     os.environ.setdefault("MASTER_PORT", "29531")
     if os.path.isdir("/sys/class/net/lo"):  # one node: the ranks talk over the loopback interface, whatever the host name resolves to
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+    # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."), and stdout is for the
+    # ONE JSON line: file descriptor 1 points at stderr while the group is set up
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def shard_of(total, rank, world, scaling):

@@ -61,9 +61,12 @@ def test_two_rank_protocol_on_gloo(tmp_path):
     outs = [p.communicate(timeout=240) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
-    def reports(text):  # gloo itself may print "[Gloo] Rank ..." lines
+    def reports(text):
         return [ln for ln in text.splitlines() if ln.startswith("[{")]
     assert reports(outs[1][0]) == []  # only rank 0 reports
+    # stdout carries nothing but that one line: gloo's "[Gloo] Rank 0 is connected to ..." chatter goes to
+    # stderr (bench.init_ranks points file descriptor 1 there while the group is set up)
+    assert outs[1][0].strip() == "" and len(outs[0][0].strip().splitlines()) == 1, (outs[0][0][:300], outs[1][0][:300])
     res = json.loads(reports(outs[0][0])[-1])
     assert [(r["image0"], r["images"]) for r in res] == [(0, 4), (4, 3)]  # the one batch of 7, cut by image index
     assert res[0]["total"] == res[1]["total"] == 7 * 20  # SUM over ranks = the whole job
