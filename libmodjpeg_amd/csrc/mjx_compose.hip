@@ -175,16 +175,17 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
-// compose kernel: per-wave software pipeline with LDS-DMA prefetch, MJX_DEPTH octets ahead.
+// compose kernel: per-wave software pipeline with LDS-DMA prefetch.
 //
-// A wave owns a *run* of consecutive octets of one job and is a workgroup of its own (the kernel
-// has no workgroup barrier; one-wave workgroups let the CU hold as many waves as LDS and registers
-// allow instead of multiples of four).  While it blends octet i, the 5 KiB each of octets i+1 ..
-// i+MJX_DEPTH (1 KiB JCOEF, 2 KiB tile, 2 KiB alpha) are in flight from HBM straight into
+// A wave owns a *run* of octets of one job (the kernel has no workgroup barrier: the four waves of a
+// workgroup only share its LDS allocation).  While it blends octet i, the 5 KiB of octet i+1 (1 KiB
+// JCOEF, 2 KiB tile, 2 KiB alpha; 3 KiB with int16 tiles) are in flight from HBM straight into
 // wave-private LDS buffers by `global_load_lds_dwordx4` (no VGPR destination: the prefetch costs no
-// registers).  Measured on MI355X (profiles/r02/): with the blend compiled out the depth-1 pipeline
-// of round 1 streamed the headline batch at 68 % of the 8 TB/s peak, i.e. bytes in flight, not the
-// VALU, bounded regimes A1/A2; depth 2 on one-wave workgroups holds 10 waves x 10 KiB per CU.
+// registers).  The code is written for MJX_DEPTH octets ahead and MJX_GROUP_WAVES waves per
+// workgroup; the shipped build is depth 1, four waves.  Measured on MI355X (profiles/r02/): the
+// memory system, not the bytes in flight, bounds regimes A1/A2 — depth 2 or 3 on one-wave
+// workgroups (10 x 10 or 7 x 15 KiB in flight per CU instead of 12 x 5) changed nothing at A1 and
+// lost VALU throughput at A2/A3, and one-wave workgroups cost 3-5 % in dispatch.
 //
 // Buffers per wave: JCOEF and tile are copied to registers at the top of a step, so their
 // MJX_DEPTH slots are refilled at once (slot of octet i = i mod DEPTH receives octet i+DEPTH);
@@ -207,10 +208,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 //                blocks per ds_read_b128 lane group) falls on 4 different bank groups.  The row
 //                layout read of alpha (only its zero pattern is used, for the skip ballots) takes
 //                the row at position r, i.e. source row (r - 2b) & 7: row_mask() below.
-// vmcnt bookkeeping (VMEM ops retire in issue order): per octet 5 DMA pieces are issued, later
-// one JCOEF store.  At the top of step i the operations younger than the pieces of octet i are the
-// pieces of the octets i+1 .. i+DEPTH-1 already issued and the stores of the last min(i, DEPTH)
-// steps: wait_vmcnt_n(5 * pending + min(i, DEPTH)) is exactly "octet i has landed".  To keep that
+// vmcnt bookkeeping (VMEM ops retire in issue order): per octet kPieces DMA pieces are issued (5, or
+// 3 with int16 tiles), later one JCOEF store.  At the top of step i the operations younger than the
+// pieces of octet i are the pieces of the octets i+1 .. i+DEPTH-1 already issued and the stores of
+// the last min(i, DEPTH) steps: wait_vmcnt_n(kPieces * pending + min(i, DEPTH)) is exactly "octet i
+// has landed" (depth 1: vmcnt(1) in the steady state).  To keep that
 // count exact the store is unconditional (lanes past the end of the job duplicate the job's last
 // block: same address, same bytes) and the kernel must not spill (a scratch access is a VMEM op):
 // build() checks ScratchSize == 0.
