@@ -109,3 +109,35 @@ def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, cwd=ROOT)
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_eight_rank_rendezvous_and_reductions_on_gloo():
+    """the rank count the driver's scaling run ends with: 8 processes rendezvous over gloo on the loopback
+    interface, cut a 4096-image job by image index, barrier, reduce and gather as bench.py does"""
+    worker = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["MJX_ROOT"])
+import bench
+rank, world, _ = bench.rank_env()
+bench.init_ranks(world)
+image0, images = bench.shard_of(4096, rank, world, "strong")
+elapsed, _ = bench.timed_steps(lambda: None, lambda: None, 3, world)
+total = bench.sum_over_ranks(images, world)
+worst = bench.reduce_scalar(float(rank), world, "max")
+got = bench.gather_objects({"rank": rank, "image0": image0, "images": images}, world)
+if rank == 0:
+    print(json.dumps({"total": total, "worst": worst, "shards": got}))
+import torch.distributed as dist
+dist.destroy_process_group()
+'''
+    port = 31000 + (os.getpid() % 2000)
+    env = dict(os.environ, MJX_ROOT=ROOT, WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-c", worker], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+             for r in range(8)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-1500:]
+    assert all(o[0].strip() == "" for o in outs[1:])
+    res = json.loads(outs[0][0].strip())
+    assert res["total"] == 4096 and res["worst"] == 7.0
+    assert [(s["rank"], s["image0"], s["images"]) for s in res["shards"]] == [(r, 512 * r, 512) for r in range(8)]
