@@ -256,9 +256,19 @@ def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0, timing=True, t
         "value": rate_all, "unit": "blocks/s", "cores": cores, "kind": "port",
         "sample": f"{nsample} images x {nblocks // max(nsample, 1)} blocks of the same synthetic workload, oracle/mjx_oracle.c "
                   f"(-O2 -ffp-contract=off), {cores} pthreads, {reps} repeats",
-        "value_1thread": sub_blocks / t_one, "gbs_equiv": rate_all * BYTES_PER_BLOCK / 1e9,
+        "value_1thread": sub_blocks / t_one, "gbs_equiv": rate_all * BYTES_PER_BLOCK / 1e9, "cpu_model": cpu_model(),
     }
     return info, expected
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def traffic_from_profiles(path, key):
@@ -445,7 +455,7 @@ def effects_cpu_baseline_and_expected(geo, quant, image0, nsample, lum, cb, cr, 
         t_rep += time.perf_counter() - t0
         reps += 1
     dcs = nsample * sum(w * h for w, h in geo.true_dims)
-    info = {"value": dcs * reps / t_rep, "unit": "blocks/s", "cores": 1, "kind": "port",
+    info = {"value": dcs * reps / t_rep, "unit": "blocks/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{nsample} images x {dcs // nsample} DC blocks (3840x2160 4:2:0), oracle/mjx_oracle.c orc_effect_dc, 1 thread "
                       f"(the reference is single-threaded), {reps} repeats"}
     return info, expected
