@@ -326,7 +326,10 @@ print("ok")
     assert "failure injected" in res.stderr
 
 
-@pytest.mark.parametrize("seed", [11, 12])
+_EXTRA_SEEDS = [int(v) for v in os.environ.get("MJX_FUZZ_SEEDS", "").split(",") if v]  # soak runs: MJX_FUZZ_SEEDS=100,101,...
+
+
+@pytest.mark.parametrize("seed", [11, 12] + _EXTRA_SEEDS)
 def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
     """mjx_compose_plan_create_ex(MJX_PLAN_GROUP_BY_DENSITY) on rectangles whose blocks have every
     density from 0 to 64 non-zero weights (signed zeros, denormals and NaN weights included), ragged
@@ -346,7 +349,7 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
         alpha = np.where(rng.random((n, 64)) < dens, alpha, np.float32(0))
         alpha[rng.random((n, 64)) < 0.02] = np.float32(-0.0)
         alpha[rng.random((n, 64)) < 0.002] = np.float32(1e-41)
-        if seed == 12:
+        if seed % 2 == 0:
             alpha[rng.random((n, 64)) < 0.001] = np.float32("nan")
         alpha = np.ascontiguousarray(alpha, np.float32)
         host.append((coef, tile, alpha))
@@ -370,14 +373,15 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
         assert np.array_equal(results[0][j].reshape(-1), want), ("grouped plan", j)
 
 
-def test_int16_tile_plans_vs_oracle_on_full_range_values(mj):
+@pytest.mark.parametrize("seed", [2027] + _EXTRA_SEEDS)
+def test_int16_tile_plans_vs_oracle_on_full_range_values(mj, seed):
     """MJX_JOB_TILES_I16 on arbitrary int16 contents (tile and alpha coefficients over the whole
     range, every density, ragged rectangles, grouped by density): the kernel's conversions
     tile = (float)coef and weight = (float)((double)(float)coef * K) equal the host's, so the planes
     equal the oracle's fed with the converted float tiles"""
     import torch
     from libmodjpeg_amd._lib import MJX_JOB_TILES_I16, MJX_PLAN_GROUP_BY_DENSITY, RectJob, check, lib
-    rng = np.random.default_rng(2027)
+    rng = np.random.default_rng(seed)
     c0, c1 = 0.3535534, 0.5
     kk = np.array([(c0 if j // 8 == 0 else c1) * (c0 if j % 8 == 0 else c1) / 1020.0 for j in range(64)], np.float64)
     shapes = [(40, 50, 3, 5, 13, 21), (9, 33, 2, 30, 7, 3), (8, 8, 1, 1, 1, 1), (30, 30, 0, 0, 30, 30)]
