@@ -141,3 +141,23 @@ dist.destroy_process_group()
     res = json.loads(outs[0][0].strip())
     assert res["total"] == 4096 and res["worst"] == 7.0
     assert [(s["rank"], s["image0"], s["images"]) for s in res["shards"]] == [(r, 512 * r, 512) for r in range(8)]
+
+
+def test_a_dead_rank_takes_the_group_down_instead_of_hanging_it():
+    """bench.py starts its own ranks when no launcher did; a rank that dies before a collective must
+    not leave the others waiting in a gloo barrier (holding their GPUs) until the timeout"""
+    import subprocess
+    import sys
+    import time
+
+    import bench
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"]) for _ in range(3)]
+    procs.insert(1, subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(7)"]))
+    t0 = time.perf_counter()
+    assert bench.wait_ranks(procs, poll_s=0.05, grace_s=3.0) == 7
+    assert time.perf_counter() - t0 < 30
+    assert all(p.poll() is not None for p in procs), "survivors were left running"
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]
+    assert bench.wait_ranks(ok, poll_s=0.05) == 0
+    hw, phys = bench.cpu_topology()
+    assert 1 <= phys <= hw
