@@ -71,7 +71,9 @@ def parse(argv=None):
     ap.add_argument("--tiles", default="f32", choices=["f32", "i16"],
                     help="f32 (default, the workload as SURVEY 8d defines it: 768 B per block); i16: the prepared tiles kept as the int16 "
                          "coefficients they are made from, converted in the kernel (512 B per block; secondary, labelled)")
-    ap.add_argument("--no-group", action="store_true", help="compose: keep every octet 8 consecutive blocks (no grouping of blocks by alpha density)")
+    ap.add_argument("--no-group", action="store_true", help="compose: keep every octet 8 consecutive blocks (no grouping of blocks by what they need)")
+    ap.add_argument("--keep-zero-alpha", action="store_true",
+                    help="compose: blocks without any weight still stream their tile and alpha blocks (no MJX_PLAN_ALPHA_IS_FINAL)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     return ap.parse_args(argv)
 
@@ -160,21 +162,24 @@ def gather_objects(obj, world):
 def timed_steps(step, sync, steps, world, device=None, make_event=None):
     """Exactly `steps` calls of `step()` bracketed by barrier + sync on both sides.  The clock runs
     from after the opening barrier + sync to after the closing sync; the closing barrier follows.
-    Returns (elapsed seconds = MAX over ranks, per-step event pairs or None)."""
-    ev = [(make_event(), make_event()) for _ in range(steps)] if make_event else None
+    Two HIP events (make_event) bracket the K launches on the launch stream: the mean launch duration
+    is their distance / K.  (Round 2 recorded a pair of events around EVERY step: two more packets in
+    the queue between consecutive kernels, 3 us of the 5.5 us a step took beyond its kernel - 2.5 % of
+    the step at the 8-GPU shard size.)  Returns (elapsed seconds = MAX over ranks, event ms or None)."""
+    ev = (make_event(), make_event()) if make_event else None
     barrier(world)
     sync()
     t0 = time.perf_counter()
-    for k in range(steps):
-        if ev:
-            ev[k][0].record()  # on the current stream == the stream the kernels are launched on
+    if ev:
+        ev[0].record()  # on the current stream == the stream the kernels are launched on
+    for _ in range(steps):
         step()
-        if ev:
-            ev[k][1].record()
+    if ev:
+        ev[1].record()
     sync()
     elapsed = time.perf_counter() - t0
     barrier(world)
-    return reduce_scalar(elapsed, world, "max"), ev
+    return reduce_scalar(elapsed, world, "max"), (ev[0].elapsed_time(ev[1]) if ev else None)
 
 
 def spin_up(step, sync, spinup_ms):
@@ -410,7 +415,8 @@ def bench_compose(args, rank, world):
     batch = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, regime, image0=image0, tiles_i16=(args.tiles == "i16"))
     bytes_per_block = 512 if args.tiles == "i16" else BYTES_PER_BLOCK  # int16 tiles: 128 + 128 + 128 read, 128 written
     batch.fill_synthetic()
-    batch.build_plan(group_by_density=not args.no_group)
+    batch.build_plan(group_by_density=not args.no_group, alpha_is_final=not args.keep_zero_alpha)
+    plan_stats = batch.plan_stats()
     blocks_per_step = batch.total_blocks()
     sync = torch.cuda.synchronize
 
@@ -451,16 +457,14 @@ def bench_compose(args, rank, world):
     sync()
 
     # ---- timed region: exactly K steps ----
-    elapsed, ev = timed_steps(batch.run, sync, args.steps, world, make_event=lambda: torch.cuda.Event(enable_timing=True))
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
-    mean_kern_ms = sum(kern_ms) / len(kern_ms)
+    elapsed, ev_ms = timed_steps(batch.run, sync, args.steps, world, make_event=lambda: torch.cuda.Event(enable_timing=True))
+    mean_kern_ms = ev_ms / args.steps  # K launches back to back between two events on the launch stream
     tot_blocks = sum_over_ranks(blocks_per_step, world)
 
     # ---- the same launch on planes restored from the pristine copy before every launch (outside
     # the contract's timed region; the restore is not between the events) ----
-    pristine_ms = None
+    pristine_ms, ms = None, []
     if pristine is not None:
-        ms = []
         for _ in range(args.pristine_launches):
             batch.rect_restore(pristine)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -472,7 +476,7 @@ def bench_compose(args, rank, world):
         pristine_ms = sum(ms) / len(ms)
 
     mine = {"rank": rank, "image0": image0, "images": images, "blocks_per_step": blocks_per_step, "kernel_ms_mean": mean_kern_ms,
-            "kernel_ms_min": min(kern_ms), "kernel_ms_pristine": pristine_ms, "parity": parity, "parity_sample_images": nsample,
+            "kernel_ms_pristine": pristine_ms, "kernel_ms_pristine_min": min(ms) if ms else None, "parity": parity, "parity_sample_images": nsample,
             "device": torch.cuda.get_device_name()}
     per_rank = gather_objects(mine, world)
 
@@ -496,13 +500,15 @@ def bench_compose(args, rank, world):
             "config": {"workload": args.workload, "images_total": tot_blocks // batch.blocks_per_image, "images_per_gpu": images, "image": f"{width}x{height} 4:2:0",
                        "dropon": f"{dw}x{dh} alpha-masked, per-image tiles, MCU ({mcu_x},{mcu_y})",
                        "alpha_regime": args.regime, "tiles": "float (768 B per block)" if args.tiles == "f32" else "int16 coefficients, converted in the kernel (512 B per block)",
-                       "density_grouping": (not args.no_group), "gather_octets_per_gpu": int(batch.gather_octets),
+                       "density_grouping": (not args.no_group), "gather_octets_per_gpu": int(batch.gather_octets), "plan": plan_stats,
                        "blocks_per_step_total": tot_blocks, "blocks_per_step_per_gpu": blocks_per_step, "spinup_ms": args.spinup_ms,
                        "parallelism": f"images sharded x{world} ({args.scaling}), no collective, no RCCL"},
             "parity": verdicts.pop() if len(verdicts) == 1 else "mixed: see per_rank",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "mjx::compose_kernel", "kernel_ms_mean": mean_kern_ms,
-                         "kernel_ms_min": min(kern_ms), "kernel_ms_median": sorted(kern_ms)[len(kern_ms) // 2], "kernel_ms_pristine": pristine_ms,
+                         "kernel_ms_mean_is": "distance of two HIP events around the K timed launches on the launch stream / K",
+                         "kernel_ms_pristine": pristine_ms, "kernel_ms_pristine_min": min(ms) if ms else None,
+                         "kernel_ms_pristine_median": sorted(ms)[len(ms) // 2] if ms else None,
                          "algorithmic_bytes_per_launch": blocks_per_step * bytes_per_block, "bytes_per_block": bytes_per_block,
                          "scope": "rank 0" if world > 1 else "the one rank", "rank": 0,
                          "achieved_min_over_ranks": min(rank_gbs), "achieved_max_over_ranks": max(rank_gbs),
@@ -594,9 +600,8 @@ def bench_effects(args, rank, world):
     for _ in range(max(args.warmup, 1)):
         eb.run()
     sync()
-    elapsed, ev = timed_steps(eb.run, sync, args.steps, world, make_event=lambda: torch.cuda.Event(enable_timing=True))
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
-    mean_ms = sum(kern_ms) / len(kern_ms)
+    elapsed, ev_ms = timed_steps(eb.run, sync, args.steps, world, make_event=lambda: torch.cuda.Event(enable_timing=True))
+    mean_ms = ev_ms / args.steps
     tot = sum_over_ranks(dcs, world)
     per_rank = gather_objects({"rank": rank, "image0": image0, "images": images, "dc_blocks_per_step": dcs, "kernel_ms_mean": mean_ms, "parity": parity}, world)
     if rank == 0:

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MJX_VERSION 100
+#define MJX_VERSION 101
 
 /* error codes (0 = success).  The libmodjpeg.h shim maps them onto MJ_ERR_* (INTEGRATION.md). */
 #define MJX_OK             0
@@ -80,9 +80,12 @@ typedef struct mjx_rect_job {
     int32_t      row0, col0;     /* top-left block of the rectangle inside the plane */
     int32_t      rows, cols;     /* rectangle size in blocks == tile height/width in blocks */
     int32_t      qtable;         /* index into the plan's quant tables */
-    int32_t      flags;          /* MJX_JOB_* (this field occupies what was padding: older callers pass 0) */
+    int32_t      flags;          /* MJX_JOB_*, read by mjx_compose_plan_create_ex ONLY: the field occupies what was tail
+                                    padding before version 101, which a caller that fills the struct member by member
+                                    leaves indeterminate, so mjx_compose_plan_create ignores it.  Zero-initialise the
+                                    struct (memset / = {0}) before handing it to the _ex form. */
 } mjx_rect_job_t;
-/* tile and alpha point at int16_t[rows*cols][64] instead of float: the prepared JCOEFs themselves.  A
+/* (mjx_compose_plan_create_ex only) tile and alpha point at int16_t[rows*cols][64] instead of float: the prepared JCOEFs themselves.  A
  * prepared tile is nothing but an int16 coefficient turned into a float (reference dropon.c:476-485;
  * alpha: `coef[0] += 1024` then (float)coef * K, :542-566), so the kernel can do that conversion
  * itself, bit for bit, and stream 512 instead of 768 bytes per block.  tile[i] holds coef[i], alpha[i]
@@ -97,17 +100,39 @@ typedef struct mjx_compose_plan mjx_compose_plan_t;
  * Rectangles must not overlap each other inside one plan. */
 int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs,
                             const uint16_t *qtables, int nq);
-/* The same with options.  MJX_PLAN_GROUP_BY_DENSITY: the alpha tiles (which must hold their final
- * contents) are scanned once on the device, and inside every rectangle whose blocks differ a lot in
- * their number of non-zero weights (reference convolve.c:32 skips a term per block; a mask with a
- * hard edge has mostly 1-weight blocks and a few 64-weight ones) the blocks that share a wavefront
- * are chosen by density instead of by position, so that a dense block no longer makes seven sparse
- * neighbours wait for its 64 terms.  Purely a schedule: the results are identical. */
+/* The same with options.
+ * MJX_PLAN_GROUP_BY_DENSITY: the alpha tiles (which must hold their final contents) are scanned once
+ * on the device for the zero pattern of every block (which of its 64 weights are not zero: the test of
+ * reference convolve.c:32, made per block there), and inside every rectangle where it pays the blocks
+ * that share a wavefront are chosen by what they need instead of by position: a wavefront executes a
+ * term when ANY of its 8 blocks has a weight for it, so what it pays for is the UNION of their
+ * patterns; blocks are sorted by density, rows and columns used and pattern, and cut into groups of
+ * 8, so that a dense block no longer makes seven sparse neighbours wait for its 64 terms and a
+ * block with a horizontal edge (one column of weights) does not share with one that has a vertical
+ * edge (one row).  Purely a schedule: the results are identical, whatever alpha holds later.
+ * MJX_PLAN_ALPHA_IS_FINAL (with the above): the caller promises that the alpha tiles keep the
+ * contents they have now for as long as the plan is used.  Blocks whose 64 weights are all zero
+ * then travel without their tile and alpha blocks: the reference skips every term of such a block
+ * (Y stays 0), only the de-/re-quantisation of compose.c:277-286 / :327-336 is left, and that still runs.
+ * MJX_PLAN_TILES_I16: every job's tiles are int16 coefficients (the same as MJX_JOB_TILES_I16 on every job). */
 #define MJX_PLAN_GROUP_BY_DENSITY 1
+#define MJX_PLAN_ALPHA_IS_FINAL   2
+#define MJX_PLAN_TILES_I16        4
 int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs,
                                const uint16_t *qtables, int nq, int flags);
-/* octets (8 blocks) of the plan that were formed by density rather than by position */
+/* octets (8 blocks) of the plan that were formed by pattern rather than by position */
 int64_t mjx_compose_plan_gather_octets(const mjx_compose_plan_t *plan);
+/* what a plan looks like: `block_terms` = non-zero weights summed over the blocks, `union_terms` = terms
+ * summed over the octets (size of the union of the 8 patterns), both 0 for plans made without a scan;
+ * mean union size per octet = union_terms / (octets - zero_alpha_octets) */
+typedef struct mjx_plan_stats {
+    int64_t blocks, octets, gather_octets, zero_alpha_octets, runs;
+    int64_t block_terms, union_terms;
+    int32_t resident_waves; /* wavefronts of the compose kernel the device holds at once: what runs are cut for */
+    int32_t run_octets_max, run_octets_min;
+    int32_t reserved;
+} mjx_plan_stats_t;
+int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out);
 void mjx_compose_plan_destroy(mjx_compose_plan_t *plan);
 /* total 8x8 blocks the plan composes per run */
 int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan);
@@ -130,6 +155,7 @@ typedef struct mjx_host_rect {
     int32_t         rows, cols;
     int32_t         flags;          /* MJX_RECT_* */
     int32_t         reserved;
+    const struct mjx_tile_schedule *schedule; /* NULL, or how the blocks of THESE tiles are best shared out (below) */
 } mjx_host_rect_t;
 /* tile and alpha are DEVICE pointers (tiles kept resident across calls, e.g. one dropon composed
  * into many images): only the plane rows cross PCIe */
@@ -137,7 +163,23 @@ typedef struct mjx_host_rect {
 /* rows_ptr is a DEVICE pointer into a plane that lives on the device (an image decoded there and
  * kept there): the rows are blended in place and nothing but the descriptors crosses PCIe */
 #define MJX_RECT_ROWS_ON_DEVICE 2
+/* tile and alpha hold int16 coefficients (MJX_JOB_TILES_I16; what mjx_tiles_prepare writes with
+ * MJX_PREP_TILES_I16): all rectangles of one call must agree */
+#define MJX_RECT_TILES_I16 4
 int mjx_compose_host(const mjx_host_rect_t *rects, int n);
+
+/* A schedule for ONE set of prepared tiles (rows x cols blocks, DEVICE): the zero patterns of the alpha
+ * blocks are read once, and the blocks are grouped as MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL
+ * describe.  It depends on the tiles only, not on the image they are composed into, so whoever keeps
+ * tiles resident (the drop-in's tile cache: one overlay, many images, reference compose.c:155-177) keeps
+ * the schedule with them and hands both to mjx_compose_host.  The alpha tiles must not change while
+ * the schedule is in use.  flags: MJX_JOB_TILES_I16 when the tiles are int16. */
+typedef struct mjx_tile_schedule mjx_tile_schedule_t;
+int     mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha /* DEVICE */, int rows, int cols, int flags);
+void    mjx_tile_schedule_destroy(mjx_tile_schedule_t *sched);
+/* octets formed by pattern (0: the tiles are uniform enough for consecutive octets) */
+int64_t mjx_tile_schedule_gather_octets(const mjx_tile_schedule_t *sched);
+int     mjx_tile_schedule_stats(const mjx_tile_schedule_t *sched, mjx_plan_stats_t *out);
 /* The host-buffer calls borrow a staging arena (grow-only device buffer, pinned descriptor buffer,
  * stream) from a small process-wide pool, so that a steady stream of per-image calls from any
  * number of threads allocates nothing.  mjx_release_thread_cache() frees the idle arenas. */

@@ -16,7 +16,12 @@ MJX_ERR_NULL_DATA = 3
 MJX_ERR_BAD_ARG = 4
 MJX_ERR_LAUNCH = 5
 MJX_PLAN_GROUP_BY_DENSITY = 1
+MJX_PLAN_ALPHA_IS_FINAL = 2
+MJX_PLAN_TILES_I16 = 4
 MJX_JOB_TILES_I16 = 1
+MJX_RECT_TILES_ON_DEVICE = 1
+MJX_RECT_ROWS_ON_DEVICE = 2
+MJX_RECT_TILES_I16 = 4
 MJX_PREP_TILES_I16 = 1
 
 
@@ -38,7 +43,21 @@ class HostRect(ctypes.Structure):
     """struct mjx_host_rect (include/mjx.h)"""
     _fields_ = [("rows_ptr", ctypes.c_void_p), ("tile", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("q", ctypes.c_void_p),
                 ("blocks_per_row", ctypes.c_int32), ("col0", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
-                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32), ("schedule", ctypes.c_void_p)]
+
+
+class PlanStats(ctypes.Structure):
+    """struct mjx_plan_stats (include/mjx.h)"""
+    _fields_ = [("blocks", ctypes.c_int64), ("octets", ctypes.c_int64), ("gather_octets", ctypes.c_int64), ("zero_alpha_octets", ctypes.c_int64),
+                ("runs", ctypes.c_int64), ("block_terms", ctypes.c_int64), ("union_terms", ctypes.c_int64),
+                ("resident_waves", ctypes.c_int32), ("run_octets_max", ctypes.c_int32), ("run_octets_min", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+    def as_dict(self):
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        real = d["octets"] - d["zero_alpha_octets"]
+        d["mean_union_terms_per_octet"] = d["union_terms"] / real if real and d["union_terms"] else None
+        d["mean_terms_per_block"] = d["block_terms"] / d["blocks"] if d["blocks"] and d["block_terms"] else None
+        return d
 
 
 class DcJob(ctypes.Structure):
@@ -73,6 +92,11 @@ SYMBOLS = [
     ("mjx_compose_plan_create", _i, [ctypes.POINTER(_vp), ctypes.POINTER(RectJob), _i, _vp, _i]),
     ("mjx_compose_plan_create_ex", _i, [ctypes.POINTER(_vp), ctypes.POINTER(RectJob), _i, _vp, _i, _i]),
     ("mjx_compose_plan_gather_octets", ctypes.c_int64, [_vp]),
+    ("mjx_compose_plan_stats", _i, [_vp, ctypes.POINTER(PlanStats)]),
+    ("mjx_tile_schedule_create", _i, [ctypes.POINTER(_vp), _vp, _i, _i, _i]),
+    ("mjx_tile_schedule_destroy", None, [_vp]),
+    ("mjx_tile_schedule_gather_octets", ctypes.c_int64, [_vp]),
+    ("mjx_tile_schedule_stats", _i, [_vp, ctypes.POINTER(PlanStats)]),
     ("mjx_compose_plan_destroy", None, [_vp]),
     ("mjx_compose_plan_blocks", ctypes.c_int64, [_vp]),
     ("mjx_compose_run", _i, [_vp, _vp]),

@@ -14,7 +14,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import (MJX_JOB_TILES_I16, MJX_PLAN_GROUP_BY_DENSITY, MJX_PREP_SOURCE_RGB, MJX_PREP_TARGET_YCC, MJX_PREP_TILES_I16, DcJob, RectJob, TilePrep,
+from ._lib import (MJX_JOB_TILES_I16, MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, PlanStats, MJX_PREP_SOURCE_RGB, MJX_PREP_TARGET_YCC, MJX_PREP_TILES_I16, DcJob, RectJob, TilePrep,
                    check, lib)
 
 _BASE_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
@@ -142,9 +142,11 @@ class ComposeBatch:
             self.alpha[c][:] = one[c][1]
 
     # ---- launch plan ------------------------------------------------------------------------
-    def build_plan(self, group_by_density=True):
-        """group_by_density: octets are formed from blocks of similar alpha density where a rectangle
-        mixes sparse and dense blocks (mjx_compose_plan_create_ex); a schedule only, same results"""
+    def build_plan(self, group_by_density=True, alpha_is_final=True):
+        """group_by_density: octets are formed from blocks that need the same terms where a rectangle
+        mixes patterns (mjx_compose_plan_create_ex); a schedule only, same results.  alpha_is_final (with
+        it): the alpha tiles will not change any more, so blocks without any weight leave their tile and
+        alpha blocks behind (the reference skips every term of theirs, convolve.c:32)"""
         jobs = (RectJob * (3 * self.n))()
         j = 0
         for i in range(self.n):
@@ -157,10 +159,16 @@ class ComposeBatch:
         qt = np.ascontiguousarray(np.stack(self.quant))
         self.destroy_plan()
         check(lib().mjx_compose_plan_create_ex(ctypes.byref(self.plan), jobs, 3 * self.n, qt.ctypes.data_as(ctypes.c_void_p), 3,
-                                               MJX_PLAN_GROUP_BY_DENSITY if group_by_density else 0), "mjx_compose_plan_create_ex")
+                                               (MJX_PLAN_GROUP_BY_DENSITY | (MJX_PLAN_ALPHA_IS_FINAL if alpha_is_final else 0)) if group_by_density else 0),
+              "mjx_compose_plan_create_ex")
         assert lib().mjx_compose_plan_blocks(self.plan) == self.n * self.blocks_per_image
         self.gather_octets = lib().mjx_compose_plan_gather_octets(self.plan)
         return self
+
+    def plan_stats(self):
+        st = PlanStats()
+        check(lib().mjx_compose_plan_stats(self.plan, ctypes.byref(st)), "mjx_compose_plan_stats")
+        return st.as_dict()
 
     def run(self):
         """one pass of mj_compose_with_mask over every image of the batch (asynchronous)"""

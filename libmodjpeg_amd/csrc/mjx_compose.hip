@@ -312,22 +312,37 @@ MJX_DEV void dma16_so(const void *sbase, unsigned voff, unsigned lds_base) {
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
 }
 
-// gather form (runs of a plan grouped by density, mjx_compose_plan_create_ex): the 8 blocks of the
-// octet are named by the run's gather table in LDS (tile block index, plane block index), so the
-// four tile / alpha pieces are 4 x 256-byte segments each instead of one contiguous KiB
+// gather form (runs of a schedule that picks the blocks of an octet by what they need, mjx_tile_schedule_create):
+// the 8 blocks of the octet are named by the run's gather table in LDS (tile block indices), so the
+// four tile / alpha pieces are 4 x 256-byte segments each instead of one contiguous KiB.
+// plane block of tile block n of the job (gather runs name their blocks by tile index)
+MJX_DEV unsigned plane_block_of(const DevJob &job, int n) {
+    int trow, tcol;
+    tile_rc(job, n, trow, tcol);
+    return __umul24((unsigned)(job.row0 + trow), (unsigned)job.bpr) + (unsigned)(job.col0 + tcol);
+}
+
+// zero-alpha run: only the JCOEF piece of gather octet o
+MJX_DEV int16_t *dma_octet_coef_only(const DevJob &job, int o, int lane, const int *G, unsigned dC) {
+    const int n = G[o * kWaveBlocks + (lane >> 3)];
+    int16_t  *cptr = job.coef + (size_t)plane_block_of(job, n) * 64 + (lane & 7) * 8;
+    dma16(cptr, dC);
+    return cptr;
+}
+
 template <bool I16>
 MJX_DEV int16_t *dma_octet_gather(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned a_in, unsigned dC, unsigned dT, unsigned dA) {
-    const int  bq = lane >> 4;
-    const int2 e = *reinterpret_cast<const int2 *>(G + (o * kWaveBlocks + (lane >> 3)) * 2);
-    int16_t   *cptr = job.coef + (size_t)(unsigned)e.y * 64 + (lane & 7) * 8;
+    const int bq = lane >> 4;
+    const int n = G[o * kWaveBlocks + (lane >> 3)];
+    int16_t  *cptr = job.coef + (size_t)plane_block_of(job, n) * 64 + (lane & 7) * 8;
     dma16(cptr, dC);
     if constexpr(I16) { // int16 tiles: one piece each, 8 x 128-byte segments, lane (b, r) <- row r of its block
-        const unsigned off = (unsigned)e.x * 128u + (unsigned)(lane & 7) * 16u;
+        const unsigned off = (unsigned)n * 128u + (unsigned)(lane & 7) * 16u;
         dma16_so(job.tile, off, dT);
         dma16_so(job.alpha, off, dT + 1024);
         return cptr;
     }
-    const int t_lo = G[(o * kWaveBlocks + bq) * 2], t_hi = G[(o * kWaveBlocks + 4 + bq) * 2];
+    const int t_lo = G[o * kWaveBlocks + bq], t_hi = G[o * kWaveBlocks + 4 + bq];
     dma16_so(job.tile, (unsigned)t_lo * 256u + t_in, dT);
     dma16_so(job.tile, (unsigned)t_hi * 256u + t_in, dT + 1024);
     dma16_so(job.alpha, (unsigned)t_lo * 256u + a_in, dA);
@@ -460,9 +475,45 @@ struct WaveLds {
     float T[MJX_DEPTH][512];     // tile
     float A[MJX_DEPTH + 1][512]; // alpha of octet i in slot i mod (DEPTH+1): live during the blend
     float Z[kImageDwords];       // transposition image
-    float Q[8 * 12];             // quant row r: 8 x u16 then 8 reciprocals
-    int   G[MJX_RUN_OCTETS * kWaveBlocks * 2]; // gather runs: (tile block, plane block) of every block of the run
+    float Q[256];                // quant row r at r * 12 dwords: 8 x u16 then 8 reciprocals (one LDS-DMA piece lands here: 1 KiB, 384 bytes used)
+    int   G[256];                // gather runs: tile block index of every block of the run (8 per octet; the piece lands as 1 KiB)
 };
+
+// steps A and Q of compose.c:315-336 and the store, given the dequantised coefficients (packed pairs) and Y in row layout
+MJX_DEV void octet_tail(int16_t *cptr, const float *qrow, const unsigned (&cd)[4], const float (&y)[8]) {
+    // A: coef = (short)(coef + (int)Y) (compose.c:315-324).  v_cvt_i32_f32 differs from the x86
+    // conversion of the reference only for Y >= 2^31 (0x7fffffff instead of 0x80000000; NaN and
+    // Y <= -2^31 agree in the low 16 bits), which the wave tests once with a max-reduction.
+    int         ti[8];
+    const float ymax = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
+    if(__builtin_expect(__any(!(ymax < 2147483648.0f)), 0)) {
+        static_for<8>([&](auto U) { ti[U] = f2i_x86(y[U]); });
+    }
+    else {
+        static_for<8>([&](auto U) { ti[U] = cvt_i32_sat(y[U]); });
+    }
+    const float4 rq_lo = *reinterpret_cast<const float4 *>(qrow + 4), rq_hi = *reinterpret_cast<const float4 *>(qrow + 8);
+    const float  rq[8] = {rq_lo.x, rq_lo.y, rq_lo.z, rq_lo.w, rq_hi.x, rq_hi.y, rq_hi.z, rq_hi.w};
+    unsigned     o[4];
+    static_for<4>([&](auto P) {
+        const unsigned s = pk_add_u16(cd[P], pack16(ti[2 * P], ti[2 * P + 1]));
+        // Q: (short)(coef / q) by the exact reciprocal product (compose.c:327-336)
+        const int q_lo = (int)(s16_lo_to_f32(s) * rq[2 * P]);
+        const int q_hi = (int)(s16_hi_to_f32(s) * rq[2 * P + 1]);
+        o[P] = pack16(q_lo, q_hi);
+    });
+    global_store16(cptr, make_uint4(o[0], o[1], o[2], o[3]));
+}
+
+// a block whose 64 weights are all zero: every mj_convolve call returns at convolve.c:32, Y stays +0.0f,
+// (int)Y == 0, and what is left of compose.c:277-336 is coef = (short)((short)(coef * q) / q) - the
+// identity unless coef * q leaves int16, which is why the block is still rewritten
+MJX_DEV void octet_zero_alpha(int16_t *cptr, const float *qrow, const uint4 c4) {
+    const uint4    q4 = *reinterpret_cast<const uint4 *>(qrow);
+    const unsigned cd[4] = {pk_mul_lo_u16(c4.x, q4.x), pk_mul_lo_u16(c4.y, q4.y), pk_mul_lo_u16(c4.z, q4.z), pk_mul_lo_u16(c4.w, q4.w)};
+    const float    y[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    octet_tail(cptr, qrow, cd, y);
+}
 
 // one octet whose operands have landed in (pC, pT, pA): registers, blend, store to cptr
 MJX_DEV void octet_compute(int16_t *cptr, int lane, int b, int r, const float *qrow, const uint4 c4, const float4 t_lo, const float4 t_hi, const float4 a_lo,
@@ -493,28 +544,7 @@ MJX_DEV void octet_compute(int16_t *cptr, int lane, int b, int r, const float *q
                 imgZ, b, r); // compose.c:300-312
 #endif
 
-    // A: coef = (short)(coef + (int)Y) (compose.c:315-324).  v_cvt_i32_f32 differs from the x86
-    // conversion of the reference only for Y >= 2^31 (0x7fffffff instead of 0x80000000; NaN and
-    // Y <= -2^31 agree in the low 16 bits), which the wave tests once with a max-reduction.
-    int         ti[8];
-    const float ymax = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
-    if(__builtin_expect(__any(!(ymax < 2147483648.0f)), 0)) {
-        static_for<8>([&](auto U) { ti[U] = f2i_x86(y[U]); });
-    }
-    else {
-        static_for<8>([&](auto U) { ti[U] = cvt_i32_sat(y[U]); });
-    }
-    const float4 rq_lo = *reinterpret_cast<const float4 *>(qrow + 4), rq_hi = *reinterpret_cast<const float4 *>(qrow + 8);
-    const float  rq[8] = {rq_lo.x, rq_lo.y, rq_lo.z, rq_lo.w, rq_hi.x, rq_hi.y, rq_hi.z, rq_hi.w};
-    unsigned     o[4];
-    static_for<4>([&](auto P) {
-        const unsigned s = pk_add_u16(cd[P], pack16(ti[2 * P], ti[2 * P + 1]));
-        // Q: (short)(coef / q) by the exact reciprocal product (compose.c:327-336)
-        const int q_lo = (int)(s16_lo_to_f32(s) * rq[2 * P]);
-        const int q_hi = (int)(s16_hi_to_f32(s) * rq[2 * P + 1]);
-        o[P] = pack16(q_lo, q_hi);
-    });
-    global_store16(cptr, make_uint4(o[0], o[1], o[2], o[3]));
+    octet_tail(cptr, qrow, cd, y);
 }
 
 #ifndef MJX_COMPOSE_MIN_WAVES
@@ -527,9 +557,7 @@ MJX_DEV void octet_compute(int16_t *cptr, int lane, int b, int r, const float *q
 // reference's double constants, computed by the lane that holds the row and written into the same
 // rotated, half-swapped LDS image the float path's DMA fills.
 template <bool I16>
-__global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void compose_kernel(const DevJob *__restrict__ jobs, const Run *__restrict__ runs, int nruns,
-                                                                                            const uint16_t *__restrict__ qtab, const float *__restrict__ rqtab,
-                                                                                            const GatherEntry *__restrict__ gather) {
+__global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void compose_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
     __shared__ __attribute__((aligned(16))) WaveLds lds[MJX_GROUP_WAVES];
 
     const int lane = threadIdx.x & 63;
@@ -538,38 +566,50 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
     const int ridx = blockIdx.x * MJX_GROUP_WAVES + wave;
     if(ridx >= nruns) return; // wave-uniform; the kernel uses no workgroup barrier
 
+    // ONE scalar read describes the run, its job included (round 2 read a run, then its job, then the
+    // quantisation rows, then asked for the first octet: four dependent round trips before any work)
     const Run    run = runs[ridx];
-    const int    jidx = __builtin_amdgcn_readfirstlane(run.job);
     const int    first = __builtin_amdgcn_readfirstlane(run.first);
     const int    noct = __builtin_amdgcn_readfirstlane(run.noctets);
-    const DevJob job = jobs[jidx];
+    const int    kind = __builtin_amdgcn_readfirstlane(run.kind);
+    const DevJob job = run.job;
     WaveLds     &L = lds[wave];
 
     RunCtx rc;
     rc.first = first;
-    rc.gather = __builtin_amdgcn_readfirstlane(run.gather) != 0;
+    rc.gather = kind != kRunConsecutive;
     rc.G = L.G;
     chunk_in_block(lane, rc.t_in, rc.a_in);
-    if(rc.gather) { // the run's gather table (noct x 64 bytes <= 1 KiB) into LDS: one piece, 16 bytes per lane
-        const int chunk = lane < noct * 4 ? lane : noct * 4 - 1;
-        dma16(reinterpret_cast<const char *>(gather + (size_t)first * kWaveBlocks) + chunk * 16, lds_addr(reinterpret_cast<const float *>(L.G)));
+
+    // The job's quantisation rows (8 x u16 and their 8 reciprocals per row, 384 bytes laid out as the
+    // kernel reads them) come in as one more LDS-DMA piece: nothing the compiler sees as a VMEM load
+    // is left in the kernel, and the piece travels together with the first octet's.
+    float *qrow = L.Q + r * kQuantRowDwords;
+    {
+        const int chunk = lane < kQuantTableBytes / 16 ? lane : kQuantTableBytes / 16 - 1;
+        dma16(reinterpret_cast<const char *>(qrq) + (size_t)(unsigned)job.qidx * kQuantTableBytes + chunk * 16, lds_addr(L.Q));
+    }
+    if(rc.gather) { // the run's gather table (noct x 32 bytes) into LDS: one piece, 16 bytes per lane; it names the first octet's blocks
+        const int chunk = lane < noct * 2 ? lane : noct * 2 - 1;
+        dma16(reinterpret_cast<const char *>(run.gather + (size_t)first * kWaveBlocks) + chunk * 16, lds_addr(reinterpret_cast<const float *>(L.G)));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
-    // Row r of the job's quant table (8 x u16) and of its reciprocals (8 x f32), staged in LDS as
-    // 12 dwords per row.  These are the only compiler-visible VMEM loads of the kernel; writing
-    // them to LDS makes the compiler retire them here, before the first octet's pieces are issued
-    // (the same wait covers the gather table).
-    float *qrow = L.Q + r * 12;
-    {
-        const uint4  q4 = *reinterpret_cast<const uint4 *>(qtab + job.qidx * 64 + r * 8);
-        const float4 rq_lo = *reinterpret_cast<const float4 *>(rqtab + job.qidx * 64 + r * 8);
-        const float4 rq_hi = *reinterpret_cast<const float4 *>(rqtab + job.qidx * 64 + r * 8 + 4);
-        if(b == 0) {
-            *reinterpret_cast<uint4 *>(qrow) = q4;
-            *reinterpret_cast<float4 *>(qrow + 4) = rq_lo;
-            *reinterpret_cast<float4 *>(qrow + 8) = rq_hi;
+    if(kind == kRunZeroAlpha) { // wave-uniform
+        // one JCOEF piece per octet; VMEM order P(0) | P(1) S(0) | P(2) S(1) ...: at the top of step i
+        // only S(i-1) is younger than P(i)
+        int16_t *cp = dma_octet_coef_only(job, 0, lane, rc.G, lds_addr(L.C[0]));
+#pragma unroll 1
+        for(int i = 0; i < noct; ++i) {
+            wait_vmcnt_n(i < 1 ? i : 1);
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(L.C[0] + lane * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int16_t *cn = cp;
+            if(i + 1 < noct) cn = dma_octet_coef_only(job, i + 1, lane, rc.G, lds_addr(L.C[0]));
+            octet_zero_alpha(cp, qrow, c4);
+            cp = cn;
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        return;
     }
 
     // prologue: the first DEPTH octets of the run
@@ -644,52 +684,79 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
     }
 }
 
-int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, const GatherEntry *gather, bool tiles_i16, hipStream_t s) {
+int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
     const int groups = (nruns + MJX_GROUP_WAVES - 1) / MJX_GROUP_WAVES;
-    if(tiles_i16) hipLaunchKernelGGL(compose_kernel<true>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, jobs, runs, nruns, qtab, rqtab, gather);
-    else hipLaunchKernelGGL(compose_kernel<false>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, jobs, runs, nruns, qtab, rqtab, gather);
+    if(tiles_i16) hipLaunchKernelGGL(compose_kernel<true>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
+    else hipLaunchKernelGGL(compose_kernel<false>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
     return check_hip(hipGetLastError(), "compose_kernel launch", MJX_ERR_LAUNCH);
 }
 
+// wavefronts of compose_kernel resident on the current device at once: what the run table is cut for
+// (round 2 assumed 256 CUs x 12 waves)
+int compose_resident_waves(bool tiles_i16) {
+    constexpr int kMaxDev = 64;
+    static int    cached[kMaxDev][2]; // 0 = not asked yet
+    int           dev = 0;
+    if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+    int &c = cached[dev][tiles_i16 ? 1 : 0];
+    if(c == 0) {
+        int             per_cu = 0, cus = 0;
+        const hipError_t e1 = tiles_i16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, compose_kernel<true>, 64 * MJX_GROUP_WAVES, 0)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, compose_kernel<false>, 64 * MJX_GROUP_WAVES, 0);
+        const hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if(e1 != hipSuccess || e2 != hipSuccess || per_cu <= 0 || cus <= 0) {
+            (void)hipGetLastError();
+            per_cu = 3;
+            cus = 256;
+        }
+        c = per_cu * cus * MJX_GROUP_WAVES;
+    }
+    return c;
+}
+
 // ------------------------------------------------------------------------------------------
-// density of the alpha tiles: non-zero weights per block (0..64), for plans that group blocks of
-// similar density into octets.  Walks the consecutive runs of a plan: lane (b, r) counts row r of
-// its block, the 8 lanes of a block add up, lane r == 0 writes the byte.
+// zero pattern of the alpha tiles: which of its 64 weights a block uses (bit 8k + l <=> weight
+// (k, l) != 0, the test of convolve.c:32), for plans that choose the blocks of an octet by what they
+// need.  Walks the consecutive runs of a plan: lane (b, r) looks at row r of its block, the 8 lanes
+// of a block combine their bytes, lane r == 0 writes the word.
 // ------------------------------------------------------------------------------------------
 template <bool I16>
-__global__ __launch_bounds__(256) void alpha_nnz_kernel(const DevJob *__restrict__ jobs, const Run *__restrict__ runs, int nruns, uint8_t *__restrict__ nnz) {
+__global__ __launch_bounds__(256) void alpha_pattern_kernel(const Run *__restrict__ runs, int nruns, uint64_t *__restrict__ pattern) {
     const int lane = threadIdx.x & 63, b = lane >> 3, r = lane & 7;
     const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if(ridx >= nruns) return;
-    const Run    run = runs[ridx];
-    const DevJob job = jobs[run.job];
+    const Run    &run = runs[ridx];
+    const DevJob &job = run.job;
     for(int o = 0; o < run.noctets; ++o) {
-        const int    n = run.first + o * kWaveBlocks + b;
-        const int    nc = n < job.nblocks ? n : job.nblocks - 1;
-        int          c;
+        const int n = run.first + o * kWaveBlocks + b;
+        const int nc = n < job.nblocks ? n : job.nblocks - 1;
+        unsigned  m = 0;
         if constexpr(I16) { // an int16 weight is zero exactly when its float is
             const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const int16_t *>(job.alpha) + (size_t)nc * 64 + r * 8);
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
-            c = 0;
-            for(int k = 0; k < 4; ++k) c += ((w[k] & 0xFFFFu) != 0u) + ((w[k] >> 16) != 0u);
+            for(int k = 0; k < 4; ++k) m |= ((w[k] & 0xFFFFu) != 0u ? 1u << (2 * k) : 0u) | ((w[k] >> 16) != 0u ? 2u << (2 * k) : 0u);
         }
         else {
             const float4 lo = *reinterpret_cast<const float4 *>(job.alpha + (size_t)nc * 64 + r * 8), hi = *reinterpret_cast<const float4 *>(job.alpha + (size_t)nc * 64 + r * 8 + 4);
-            c = (lo.x != 0.0f) + (lo.y != 0.0f) + (lo.z != 0.0f) + (lo.w != 0.0f) + (hi.x != 0.0f) + (hi.y != 0.0f) + (hi.z != 0.0f) + (hi.w != 0.0f);
+            m = (lo.x != 0.0f ? 1u : 0u) | (lo.y != 0.0f ? 2u : 0u) | (lo.z != 0.0f ? 4u : 0u) | (lo.w != 0.0f ? 8u : 0u) | (hi.x != 0.0f ? 16u : 0u) | (hi.y != 0.0f ? 32u : 0u) |
+                (hi.z != 0.0f ? 64u : 0u) | (hi.w != 0.0f ? 128u : 0u);
         }
-        c += __shfl_xor(c, 1);
-        c += __shfl_xor(c, 2);
-        c += __shfl_xor(c, 4);
-        if(r == 0 && n < job.nblocks) nnz[(size_t)(unsigned)job.nnz_off + n] = (uint8_t)c;
+        // byte r of the block's word; rows 0..3 live in the low dword, 4..7 in the high one
+        unsigned lo32 = r < 4 ? m << (8 * r) : 0u, hi32 = r >= 4 ? m << (8 * (r - 4)) : 0u;
+        for(int d = 1; d < 8; d <<= 1) {
+            lo32 |= (unsigned)__shfl_xor((int)lo32, d);
+            hi32 |= (unsigned)__shfl_xor((int)hi32, d);
+        }
+        if(r == 0 && n < job.nblocks) pattern[(size_t)(unsigned)job.nnz_off + n] = ((uint64_t)hi32 << 32) | lo32;
     }
 }
 
-int launch_alpha_nnz(const DevJob *jobs, const Run *runs, int nruns, uint8_t *nnz, bool tiles_i16, hipStream_t s) {
+int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, bool tiles_i16, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
-    if(tiles_i16) hipLaunchKernelGGL(alpha_nnz_kernel<true>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, jobs, runs, nruns, nnz);
-    else hipLaunchKernelGGL(alpha_nnz_kernel<false>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, jobs, runs, nruns, nnz);
-    return check_hip(hipGetLastError(), "alpha_nnz_kernel launch", MJX_ERR_LAUNCH);
+    if(tiles_i16) hipLaunchKernelGGL(alpha_pattern_kernel<true>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, runs, nruns, pattern);
+    else hipLaunchKernelGGL(alpha_pattern_kernel<false>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, runs, nruns, pattern);
+    return check_hip(hipGetLastError(), "alpha_pattern_kernel launch", MJX_ERR_LAUNCH);
 }
 
 // ------------------------------------------------------------------------------------------

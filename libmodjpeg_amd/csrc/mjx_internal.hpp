@@ -21,20 +21,34 @@ struct DevJob {
 };
 static_assert(sizeof(DevJob) == 56, "DevJob layout");
 
-// one wave's share of a launch: up to MJX_RUN_OCTETS octets (8 blocks each) of one job
+// One wave's share of a launch: up to MJX_RUN_OCTETS octets (8 blocks each) of one job.  The
+// descriptor carries its job, so a wave needs ONE (scalar) read before it can ask for its first
+// octet: round 2's table held a job index, i.e. a second dependent read in front of every run.
+enum RunKind : int32_t {
+    kRunConsecutive = 0, // the octets are consecutive tile blocks, `first` = first tile block
+    kRunGather = 1,      // they are listed in the plan's gather table, `first` = first octet there
+    kRunZeroAlpha = 2    // gather octets of blocks whose 64 weights are all zero: the reference skips every
+                         // term of such a block (convolve.c:32), Y stays +0, only the JCOEF block travels
+};
 struct Run {
-    int32_t job;
-    int32_t first;   // consecutive run: first tile block; gather run: its first octet in the plan's gather table
-    int32_t noctets; // >= 1
-    int32_t gather;  // 0 = the octets are consecutive tile blocks, 1 = they are listed in the gather table
+    DevJob         job;
+    int32_t        first;
+    int32_t        noctets; // >= 1
+    int32_t        kind;    // RunKind
+    int32_t        pad;
+    const int32_t *gather;  // gather kinds: the table `first` counts octets in (8 tile block indices per octet)
 };
+static_assert(sizeof(Run) == 80, "Run layout");
 
-// one block of a gather octet
-struct GatherEntry {
-    int32_t  tile; // block index inside the job's tile / alpha arrays
-    uint32_t pblk; // block index inside the component plane
-};
+// one quantisation table as the kernel stages it in LDS: row r = 8 x u16 quantisers, then the 8
+// float reciprocals of that row (48 bytes per row, 384 per table): one LDS-DMA piece of 24 chunks
+constexpr int kQuantRowDwords = 12;
+constexpr int kQuantTableBytes = 8 * kQuantRowDwords * 4;
 
+// A gather table names the 8 blocks of every octet by their index inside the job's tile / alpha arrays
+// (tile row * cols + tile column); the kernel derives the plane block from it, so a table depends only
+// on the tiles and can be kept with them (the tile cache of the drop-in does) whatever image they are
+// composed into.
 constexpr int kWaveBlocks = 8;     // one wavefront = 8 blocks x 8 lanes
 constexpr int kWavesPerGroup = 4;  // 256 threads
 
@@ -83,9 +97,13 @@ struct ArenaLease {
 };
 
 // launchers implemented in the kernel translation units
-int launch_compose(const DevJob *jobs, const Run *runs, int nruns, const uint16_t *qtab, const float *rqtab, const GatherEntry *gather, bool tiles_i16, hipStream_t s);
-int launch_alpha_nnz(const DevJob *jobs, const Run *runs, int nruns, uint8_t *nnz, bool tiles_i16, hipStream_t s);
+// qrq: kQuantTableBytes per quantisation table (see above)
+int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s);
+// pattern[first block of the job in the plan + n] = bit (8k + l) set when weight (k, l) of tile block n is not zero
+int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, bool tiles_i16, hipStream_t s);
 int run_octets();
+// wavefronts of compose_kernel the current device holds at once (CUs x resident waves per CU)
+int compose_resident_waves(bool tiles_i16);
 int launch_convolve(const float *x, float *y, float w, int k, int l, int nblocks, hipStream_t s);
 int launch_effect_dc(const DevDcJob *jobs, int njobs, int64_t max_blocks_per_job, hipStream_t s);
 int launch_effect_dc_vector(int16_t *dc, size_t n, int q0, float rq0, int value, hipStream_t s);

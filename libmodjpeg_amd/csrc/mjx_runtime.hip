@@ -10,6 +10,7 @@
 
 #include <pthread.h>
 
+#include <algorithm>
 #include <atomic>
 #include <new>
 #include <vector>
@@ -81,17 +82,46 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 using namespace mjx;
 
+// ------------------------------------------------------------------------------------------
+// schedules: which blocks share a wavefront, and in which order the wavefronts are dispatched
+// ------------------------------------------------------------------------------------------
+namespace {
+// a stretch of octets of one job that are alike (same kind, same cost class)
+struct Segment {
+    int32_t kind;    // RunKind
+    int32_t cls;     // cost class of its octets: 2 = several times the memory-bound octet, 1, 0 = memory-bound, -1 = zero alpha
+    int32_t first;   // kRunConsecutive: first tile block; gather kinds: first octet in the gather table
+    int32_t noctets;
+};
+
+struct SchedStats {
+    int64_t blocks = 0, octets = 0, gather_octets = 0, zero_octets = 0, block_terms = 0, union_terms = 0;
+    void add(const SchedStats &o) {
+        blocks += o.blocks; octets += o.octets; gather_octets += o.gather_octets; zero_octets += o.zero_octets;
+        block_terms += o.block_terms; union_terms += o.union_terms;
+    }
+};
+} // namespace
+
+struct mjx_tile_schedule {
+    int                  device = -1;
+    int32_t             *d_gather = nullptr; // 8 tile block indices per gather octet
+    int                  rows = 0, cols = 0;
+    bool                 tiles_i16 = false;
+    std::vector<Segment> segs;
+    SchedStats           stats;
+};
+
 struct mjx_compose_plan {
-    DevJob      *d_jobs = nullptr;
-    Run         *d_runs = nullptr;
-    int          nruns = 0;
-    uint16_t    *d_q = nullptr;
-    float       *d_rq = nullptr;
-    GatherEntry *d_gather = nullptr; // plans grouped by density: the blocks of every gather octet
-    int          njobs = 0;
-    int64_t      blocks = 0;
-    int64_t      gather_octets = 0;
-    bool         tiles_i16 = false;
+    Run        *d_runs = nullptr;
+    int         nruns = 0;
+    void       *d_qrq = nullptr;     // kQuantTableBytes per quantisation table
+    int32_t    *d_gather = nullptr;  // plans grouped by pattern: the blocks of every gather octet
+    int         njobs = 0;
+    int64_t     blocks = 0;
+    bool        tiles_i16 = false;
+    SchedStats  stats;
+    int         slots = 0, run_max = 0, run_min = 0;
 };
 
 struct mjx_dc_plan {
@@ -173,112 +203,261 @@ int mjx_stream_synchronize(mjx_stream_t s) {
 // ------------------------------------------------------------------------------------------
 void mjx_compose_plan_destroy(mjx_compose_plan_t *p) {
     if(p == nullptr) return;
-    if(p->d_jobs) (void)hipFree(p->d_jobs);
     if(p->d_runs) (void)hipFree(p->d_runs);
-    if(p->d_q) (void)hipFree(p->d_q);
-    if(p->d_rq) (void)hipFree(p->d_rq);
+    if(p->d_qrq) (void)hipFree(p->d_qrq);
     if(p->d_gather) (void)hipFree(p->d_gather);
     delete p;
 }
 
 // host-side launch tables of a set of rectangles (shared by plans and the host-buffer path)
 namespace {
-struct Tables {
-    std::vector<DevJob>      jobs;
-    std::vector<Run>         runs;
-    std::vector<GatherEntry> gather; // 8 entries per gather octet
-    std::vector<float>       rq;
-    std::vector<int8_t>      run_class; // density class of each run's first octet (parallel to runs)
-    int64_t                  blocks = 0;
-    int                      run_len = 0;
-    bool                     tiles_i16 = false; // MJX_JOB_TILES_I16 on every job
+// one run before it is written out as a device descriptor
+struct RunRef {
+    int32_t job, first, noctets, kind;
+    int32_t sched; // gather kinds: which gather table `first` counts in (-1: the plan's own)
 };
 
-// density classes of a block by its number of non-zero weights.  Measured on MI355X:
-// up to ~16 terms per block the octet is bounded by the HBM stream, beyond that by the VALU, in
-// proportion to the terms the octet's densest block needs; so an octet should not mix classes.
-int density_class(unsigned nnz) { return nnz <= 16 ? 0 : (nnz <= 36 ? 1 : 2); }
+struct Tables {
+    std::vector<DevJob>  jobs;
+    std::vector<RunRef>  runs;
+    std::vector<int32_t> gather; // the plan's own table: 8 tile block indices per gather octet
+    std::vector<uint8_t> qrq;    // kQuantTableBytes per table
+    int64_t              blocks = 0;
+    int                  slots = 0;   // wavefronts the device holds at once
+    int                  run_len = 0; // octets per run in the body of the launch
+    int                  run_min = 0, run_max = 0;
+    bool                 tiles_i16 = false;
+    SchedStats           stats;
+};
 
-// the runs of the jobs in t.jobs.  nnz == nullptr: every job as consecutive octets.  Else nnz[] is
-// the per-block density (DevJob::nnz_off): a job whose blocks fall into more than one class is cut
-// into octets class by class, densest first (the long-running waves start first), through the
-// gather table; a job of one class keeps its consecutive octets.
-void build_runs(Tables &t, const uint8_t *nnz) {
-    const int run_blocks = t.run_len * kWaveBlocks;
-    t.runs.clear();
-    t.gather.clear();
-    t.run_class.clear();
-    std::vector<int> order;
-    for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
-        const DevJob &d = t.jobs[(size_t)jid];
-        bool          mixed = false;
-        if(nnz != nullptr) {
-            const uint8_t *z = nnz + (size_t)(unsigned)d.nnz_off;
-            const int      c0 = density_class(z[0]);
-            for(int n = 1; n < d.nblocks && !mixed; ++n) mixed = density_class(z[n]) != c0;
+// ---- what an octet costs -----------------------------------------------------------------------
+// VALU instructions per octet, fitted to the rocprofv3 counts of round 2 (profiles/r02/README.md: 172 /
+// 505 / 2215 at 1 / 10 / 64 terms in 1 / 4 / 8 columns): 121 fixed + 20.6 per column of weights in use
+// (one H stage and its transposition) + 30.1 per term; an octet cannot be faster than its 5 KiB take
+// to stream, which is what an A2 octet (505) needs as well: below that the memory system is the bound.
+constexpr float kCostFixed = 121.0f, kCostColumn = 20.6f, kCostTerm = 30.1f, kCostMemory = 480.0f, kCostZeroAlpha = 170.0f;
+
+inline unsigned pattern_columns(uint64_t p) { // bit l: some weight (k, l) is used
+    p |= p >> 32;
+    p |= p >> 16;
+    p |= p >> 8;
+    return (unsigned)(p & 0xFFu);
+}
+inline unsigned pattern_rows(uint64_t p) { // bit k: some weight (k, l) is used
+    unsigned m = 0;
+    for(int k = 0; k < 8; ++k) m |= ((p >> (8 * k)) & 0xFFu) ? 1u << k : 0u;
+    return m;
+}
+inline float octet_cost(uint64_t u) {
+    const float c = kCostFixed + kCostColumn * (float)__builtin_popcount(pattern_columns(u)) + kCostTerm * (float)__builtin_popcountll(u);
+    return c > kCostMemory ? c : kCostMemory;
+}
+inline int cost_class(float c) { return c <= kCostMemory ? 0 : (c <= 2.0f * kCostMemory ? 1 : 2); }
+
+// The segments of ONE set of tiles (nblocks blocks, cols wide) given the zero pattern of every alpha
+// block; gather octets are appended to `gather` (segment.first counts octets from its start).
+// pattern == nullptr: one consecutive segment.  skip_zero: blocks without any weight form zero-alpha
+// segments (MJX_PLAN_ALPHA_IS_FINAL).
+void schedule_tiles(const uint64_t *pattern, int nblocks, bool skip_zero, std::vector<int32_t> &gather, std::vector<Segment> &segs, SchedStats &st) {
+    const int noct_all = (nblocks + kWaveBlocks - 1) / kWaveBlocks;
+    st.blocks += nblocks;
+    if(pattern == nullptr) {
+        segs.push_back(Segment{kRunConsecutive, 0, 0, noct_all});
+        st.octets += noct_all;
+        return;
+    }
+    // what the blocks cost as they lie
+    bool     all_same = true;
+    int      nzero = 0;
+    float    cost_cons = 0.0f;
+    int64_t  terms = 0, union_cons = 0;
+    for(int o = 0; o < noct_all; ++o) {
+        uint64_t u = 0;
+        for(int k = 0; k < kWaveBlocks && o * kWaveBlocks + k < nblocks; ++k) {
+            const uint64_t p = pattern[o * kWaveBlocks + k];
+            u |= p;
+            all_same = all_same && p == pattern[0];
+            nzero += p == 0;
+            terms += __builtin_popcountll(p);
         }
-        if(!mixed) {
-            for(int f = 0; f < d.nblocks; f += run_blocks) {
-                const int left = d.nblocks - f;
-                const int nb = left < run_blocks ? left : run_blocks;
-                t.runs.push_back(Run{jid, f, (nb + kWaveBlocks - 1) / kWaveBlocks, 0});
-                t.run_class.push_back(nnz != nullptr ? (int8_t)density_class(nnz[(size_t)(unsigned)d.nnz_off]) : (int8_t)0);
-            }
-            continue;
-        }
-        const uint8_t *z = nnz + (size_t)(unsigned)d.nnz_off;
-        order.clear();
-        for(int c = 2; c >= 0; --c)
-            for(int n = 0; n < d.nblocks; ++n)
-                if(density_class(z[n]) == c) order.push_back(n);
-        while(order.size() % kWaveBlocks != 0) order.push_back(order.back()); // a ragged last octet repeats its last block
-        const int noct = (int)(order.size() / kWaveBlocks);
-        const int g_run = t.run_len < run_octets() ? t.run_len : run_octets(); // a run's table is one LDS-DMA piece
-        for(int o = 0; o < noct; o += g_run) {
-            const int no = noct - o < g_run ? noct - o : g_run;
-            t.runs.push_back(Run{jid, (int)(t.gather.size() / kWaveBlocks), no, 1});
-            t.run_class.push_back((int8_t)density_class(z[order[(size_t)(o * kWaveBlocks)]]));
-            for(int k = 0; k < no * kWaveBlocks; ++k) {
-                const int n = order[(size_t)(o * kWaveBlocks + k)];
-                const int trow = n / d.cols, tcol = n - trow * d.cols;
-                t.gather.push_back(GatherEntry{n, (uint32_t)(d.row0 + trow) * (uint32_t)d.bpr + (uint32_t)(d.col0 + tcol)});
-            }
+        cost_cons += octet_cost(u);
+        union_cons += __builtin_popcountll(u);
+    }
+    st.block_terms += terms;
+    const bool split_zero = skip_zero && nzero >= kWaveBlocks;
+    auto consecutive = [&]() {
+        segs.push_back(Segment{kRunConsecutive, cost_class(cost_cons / (float)noct_all), 0, noct_all});
+        st.octets += noct_all;
+        st.union_terms += union_cons;
+    };
+    if(all_same && !(split_zero && pattern[0] == 0)) return consecutive();
+
+    // sorted order: densest first; among blocks of similar density those that use the same rows and
+    // columns of weights lie together, then equal patterns
+    struct Key {
+        int32_t  bucket;
+        uint32_t rc;
+        uint64_t p;
+        int32_t  n;
+    };
+    std::vector<Key> keys;
+    std::vector<int> zeros;
+    keys.reserve((size_t)nblocks);
+    for(int n = 0; n < nblocks; ++n) {
+        const uint64_t p = pattern[n];
+        if(split_zero && p == 0) { zeros.push_back(n); continue; }
+        const int t = __builtin_popcountll(p);
+        keys.push_back(Key{t <= 12 ? 0 : 1 + (t - 13) / 8, (pattern_rows(p) << 8) | pattern_columns(p), p, n});
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        if(a.bucket != b.bucket) return a.bucket > b.bucket;
+        if(a.rc != b.rc) return a.rc < b.rc;
+        if(a.p != b.p) return a.p < b.p;
+        return a.n < b.n;
+    });
+    const int noct_sorted = (int)((keys.size() + kWaveBlocks - 1) / kWaveBlocks);
+    float     cost_sorted = kCostZeroAlpha * (float)((zeros.size() + kWaveBlocks - 1) / kWaveBlocks);
+    std::vector<uint64_t> unions((size_t)noct_sorted);
+    for(int o = 0; o < noct_sorted; ++o) {
+        uint64_t u = 0;
+        for(size_t k = (size_t)o * kWaveBlocks; k < (size_t)(o + 1) * kWaveBlocks && k < keys.size(); ++k) u |= keys[k].p;
+        unions[(size_t)o] = u;
+        cost_sorted += octet_cost(u);
+    }
+    // a gathered octet fetches its tiles as four 256-byte segments per piece and its table: it has to buy something
+    if(cost_sorted > 0.93f * cost_cons) return consecutive();
+
+    int base = (int)(gather.size() / kWaveBlocks);
+    for(int o = 0; o < noct_sorted;) { // stretches of octets of one cost class
+        const int cls = cost_class(octet_cost(unions[(size_t)o]));
+        int       e = o;
+        while(e < noct_sorted && cost_class(octet_cost(unions[(size_t)e])) == cls) ++e;
+        segs.push_back(Segment{kRunGather, cls, base + o, e - o});
+        o = e;
+    }
+    for(int o = 0; o < noct_sorted; ++o) {
+        st.union_terms += __builtin_popcountll(unions[(size_t)o]);
+        for(int k = 0; k < kWaveBlocks; ++k) { // a ragged last octet repeats its last block: same bytes to the same address
+            const size_t i = (size_t)o * kWaveBlocks + k;
+            gather.push_back(keys[i < keys.size() ? i : keys.size() - 1].n);
         }
     }
-    if(nnz != nullptr) { // the dense runs take several times as long: dispatch them first, the tail of the launch is sparse runs
-        std::vector<Run> sorted;
-        sorted.reserve(t.runs.size());
-        for(int c = 2; c >= 0; --c)
-            for(size_t i = 0; i < t.runs.size(); ++i)
-                if(t.run_class[i] == c) sorted.push_back(t.runs[i]);
-        t.runs.swap(sorted);
+    st.octets += noct_sorted;
+    st.gather_octets += noct_sorted;
+    if(!zeros.empty()) {
+        base = (int)(gather.size() / kWaveBlocks);
+        const int nz = (int)((zeros.size() + kWaveBlocks - 1) / kWaveBlocks);
+        segs.push_back(Segment{kRunZeroAlpha, -1, base, nz});
+        for(int i = 0; i < nz * kWaveBlocks; ++i) gather.push_back(zeros[(size_t)i < zeros.size() ? (size_t)i : zeros.size() - 1]);
+        st.octets += nz;
+        st.gather_octets += nz;
+        st.zero_octets += nz;
     }
 }
 
-int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, Tables &t) {
+// Cut the segments of all jobs into runs.
+//  1. Per job: segments that continue each other in the same table (the cost classes of one gathered
+//     job lie one after the other, densest first) are walked as ONE stretch and cut every t.run_len
+//     octets, whatever the class boundaries: a run costs its wave a start-up of a few microseconds, so
+//     a three-octet class of a small rectangle does not get a wave of its own.  A short rest joins the
+//     run before it.  A run is labelled with the class of its first octet.
+//  2. Runs are ordered by that class, the expensive ones first (a dense octet takes several times as
+//     long as a sparse one: the launch should end on short work).
+//  3. Towards the end of the launch runs are split so that they shrink with the work that is left
+//     (remaining / (2 x the wavefronts the device holds), not below MJX_TAIL_MIN): waves are replaced as
+//     they finish, so the last ones to start would otherwise finish up to a whole run after the first
+//     idle slot appeared.
+struct JobSegment {
+    int32_t job, sched;
+    Segment seg;
+};
+constexpr int kMaxRunOctets = 24; // a gather table piece holds 32 octets; consecutive runs have no limit of their own
+void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
+    struct Labelled {
+        RunRef  r;
+        int32_t cls;
+    };
+    std::vector<Labelled> runs;
+    for(size_t i = 0; i < all.size();) {
+        // the stretch [i, e): same job, same kind, same table, each segment starting where the one before ends
+        size_t e = i + 1;
+        while(e < all.size() && all[e].job == all[i].job && all[e].sched == all[i].sched && all[e].seg.kind == all[i].seg.kind && all[i].seg.kind != kRunConsecutive &&
+              all[e].seg.first == all[e - 1].seg.first + all[e - 1].seg.noctets)
+            ++e;
+        int total = 0;
+        for(size_t k = i; k < e; ++k) total += all[k].seg.noctets;
+        const int kind = all[i].seg.kind, base = all[i].seg.first;
+        size_t    seg = i;       // segment that holds octet f
+        int       seg_end = all[i].seg.noctets;
+        for(int f = 0; f < total;) {
+            int len = t.run_len < total - f ? t.run_len : total - f;
+            const int rest = total - f - len;
+            if(rest > 0 && rest * 2 < t.run_len && len + rest <= kMaxRunOctets) len += rest;
+            while(f >= seg_end) seg_end += all[++seg].seg.noctets;
+            const int first = kind == kRunConsecutive ? base + f * kWaveBlocks : base + f;
+            runs.push_back(Labelled{RunRef{all[i].job, first, len, kind, all[i].sched}, all[seg].seg.cls});
+            f += len;
+        }
+        i = e;
+    }
+    std::stable_sort(runs.begin(), runs.end(), [](const Labelled &a, const Labelled &b) { return a.cls > b.cls; });
+
+    int64_t remaining = 0;
+    for(const Labelled &l : runs) remaining += l.r.noctets;
+    static const int tail_min = [] {
+        const char *e = getenv("MJX_TAIL_MIN"); // experiments; 0 = runs never shrink
+        const int   v = e ? atoi(e) : 4;
+        return v < 0 ? 0 : v;
+    }();
+    const bool one_round = remaining <= (int64_t)t.slots * 8; // every wave gets its share at once: nothing is replaced, nothing to balance
+    t.runs.clear();
+    t.run_min = 1 << 30;
+    t.run_max = 0;
+    for(const Labelled &l : runs) {
+        for(int f = 0; f < l.r.noctets;) {
+            int len = l.r.noctets - f;
+            if(!one_round && tail_min > 0) {
+                int64_t guided = remaining / (2 * (int64_t)t.slots);
+                if(guided < tail_min) guided = tail_min;
+                if(guided < len && len - guided >= (guided + 1) / 2) len = (int)guided; // never leave a crumb behind
+            }
+            RunRef r = l.r;
+            r.first = l.r.kind == kRunConsecutive ? l.r.first + f * kWaveBlocks : l.r.first + f;
+            r.noctets = len;
+            t.runs.push_back(r);
+            t.run_min = len < t.run_min ? len : t.run_min;
+            t.run_max = len > t.run_max ? len : t.run_max;
+            f += len;
+            remaining -= len;
+        }
+    }
+    if(t.runs.empty()) t.run_min = 0;
+}
+
+int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, bool tiles_i16, Tables &t) {
     // the reference divides by quantval (compose.c:327-336): q == 0 is a caller bug there (SIGFPE)
     for(int i = 0; i < nq * 64; ++i) {
         if(qtables[i] == 0) return MJX_ERR_BAD_ARG;
     }
+    t.tiles_i16 = tiles_i16;
     // Run length (octets per wave).  Long runs amortise the un-prefetched first octet; short runs keep
-    // all 256 CUs x 12 resident waves busy when the launch is small and balance its tail when it
-    // is medium.  Measured (MI355X, round 2): a launch that gives every resident wave fewer than 8
-    // octets runs best as ONE round of waves (one 4K image, 24 300 octets: 8 per run 36 us, 4 per run
-    // 37, 2 per run 39; a per-image call of 192 octets: 2 per run); beyond that at least 8 rounds of
-    // 8..16 octets (512 images of the headline workload, i.e. its 8-GPU shard: 8 per run 0.121 ms,
-    // 16 per run 0.126; 1024 images 0.234 against 0.246; 2048 and 4096 images: 16 per run).
+    // every resident wave busy when the launch is small and balance its tail when it is medium.
+    // Measured (MI355X, round 2): a launch that gives every resident wave fewer than 8 octets runs best as
+    // ONE round of waves (one 4K image, 24 300 octets: 8 per run 36 us, 4 per run 37, 2 per run 39; a
+    // per-image call of 192 octets: 2 per run); beyond that at least 8 rounds of 8..16 octets.
     int64_t total_octets = 0;
     for(int i = 0; i < njobs; ++i) {
         if(jobs[i].rows > 0 && jobs[i].cols > 0) total_octets += ((int64_t)jobs[i].rows * jobs[i].cols + kWaveBlocks - 1) / kWaveBlocks;
     }
-    const int64_t per_slot = (total_octets + 3071) / 3072; // octets per resident wave
+    t.slots = compose_resident_waves(tiles_i16);
+    const int64_t per_slot = (total_octets + t.slots - 1) / t.slots; // octets per resident wave
     int           run_len = per_slot < 8 ? (int)per_slot : (int)(per_slot / 8);
     if(per_slot >= 8 && run_len < 8) run_len = 8;
     if(run_len < 2) run_len = 2;
     if(run_len > run_octets()) run_len = run_octets();
     if(const char *e = getenv("MJX_RUN_OCTETS")) { // experiments only
         const int v = atoi(e);
-        if(v >= 1 && v <= 1024) run_len = v;
+        if(v >= 1 && v <= run_octets()) run_len = v;
     }
     t.run_len = run_len;
     // rectangles of >= 2^24 blocks are split by rows so that the kernel's float row/column split
@@ -295,9 +474,6 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
         if(j.row0 < 0 || j.col0 < 0 || j.blocks_per_row <= 0 || j.col0 + (int64_t)j.cols > j.blocks_per_row) return MJX_ERR_BAD_ARG;
         if(j.plane_rows > 0 && j.row0 + (int64_t)j.rows > j.plane_rows) return MJX_ERR_BAD_ARG;
         if(j.cols > kMaxJobBlocks) return MJX_ERR_BAD_ARG;
-        if((j.flags & ~MJX_JOB_TILES_I16) != 0) return MJX_ERR_BAD_ARG;
-        if(t.jobs.empty()) t.tiles_i16 = (j.flags & MJX_JOB_TILES_I16) != 0;
-        else if(t.tiles_i16 != ((j.flags & MJX_JOB_TILES_I16) != 0)) return MJX_ERR_BAD_ARG; // one tile format per plan
 
         const int max_rows = (int)(kMaxJobBlocks / j.cols);
         for(int r0 = 0; r0 < j.rows; r0 += max_rows) {
@@ -306,8 +482,8 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
             DevJob    d;
             d.coef = j.coef;
             // (a float is two int16: an int16 tile array advances half as fast)
-            d.tile = j.tile + (size_t)r0 * (size_t)j.cols * ((j.flags & MJX_JOB_TILES_I16) ? 32 : 64);
-            d.alpha = j.alpha + (size_t)r0 * (size_t)j.cols * ((j.flags & MJX_JOB_TILES_I16) ? 32 : 64);
+            d.tile = j.tile + (size_t)r0 * (size_t)j.cols * (tiles_i16 ? 32 : 64);
+            d.alpha = j.alpha + (size_t)r0 * (size_t)j.cols * (tiles_i16 ? 32 : 64);
             d.bpr = j.blocks_per_row;
             d.row0 = j.row0 + r0;
             d.col0 = j.col0;
@@ -320,10 +496,86 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
             t.blocks += d.nblocks;
         }
     }
-    build_runs(t, nullptr);
-    t.rq.resize((size_t)nq * 64);
-    for(int i = 0; i < nq * 64; ++i) t.rq[(size_t)i] = rq_of(qtables[i]);
+    // quantisation tables as the kernel stages them: row r = 8 quantisers (u16) + their 8 reciprocals (f32)
+    t.qrq.resize((size_t)nq * kQuantTableBytes);
+    for(int q = 0; q < nq; ++q) {
+        for(int r = 0; r < 8; ++r) {
+            uint8_t *row = t.qrq.data() + (size_t)q * kQuantTableBytes + (size_t)r * kQuantRowDwords * 4;
+            memcpy(row, qtables + q * 64 + r * 8, 16);
+            float rq[8];
+            for(int u = 0; u < 8; ++u) rq[u] = rq_of(qtables[q * 64 + r * 8 + u]);
+            memcpy(row + 16, rq, 32);
+        }
+    }
     return MJX_OK;
+}
+
+// every job as consecutive octets (no pattern scan)
+void plain_runs(Tables &t) {
+    std::vector<JobSegment> all;
+    all.reserve(t.jobs.size());
+    for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
+        std::vector<Segment> one;
+        schedule_tiles(nullptr, t.jobs[(size_t)jid].nblocks, false, t.gather, one, t.stats);
+        all.push_back(JobSegment{jid, -1, one[0]});
+    }
+    cut_runs(t, all);
+}
+
+// write the runs out as device descriptors; gather tables: the plan's own (sched < 0) or that of schedule `sched`
+void expand_runs(const Tables &t, Run *out, const int32_t *own, const mjx_tile_schedule_t *const *scheds) {
+    for(size_t i = 0; i < t.runs.size(); ++i) {
+        const RunRef &r = t.runs[i];
+        Run          &d = out[i];
+        d.job = t.jobs[(size_t)r.job];
+        d.first = r.first;
+        d.noctets = r.noctets;
+        d.kind = r.kind;
+        d.pad = 0;
+        d.gather = r.kind == kRunConsecutive ? nullptr : (r.sched < 0 ? own : scheds[r.sched]->d_gather);
+    }
+}
+
+// zero patterns of the alpha tiles of every job in t (one launch over temporary consecutive runs)
+int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern) {
+    std::vector<Run> tmp;
+    for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
+        const DevJob &d = t.jobs[(size_t)jid];
+        const int     noct = (d.nblocks + kWaveBlocks - 1) / kWaveBlocks;
+        for(int o = 0; o < noct; o += 64) {
+            Run r;
+            memset(&r, 0, sizeof(r));
+            r.job = d;
+            r.first = o * kWaveBlocks;
+            r.noctets = noct - o < 64 ? noct - o : 64;
+            tmp.push_back(r);
+        }
+    }
+    pattern.resize((size_t)t.blocks);
+    Run      *d_tmp = nullptr;
+    uint64_t *d_pat = nullptr;
+    int       err = check_hip(hipMalloc((void **)&d_tmp, tmp.size() * sizeof(Run)), "hipMalloc(scan runs)", MJX_ERR_MEMORY);
+    if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_pat, (size_t)t.blocks * sizeof(uint64_t)), "hipMalloc(patterns)", MJX_ERR_MEMORY);
+    if(err == MJX_OK) err = check_hip(hipMemcpy(d_tmp, tmp.data(), tmp.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(scan runs)", MJX_ERR_LAUNCH);
+    if(err == MJX_OK) err = launch_alpha_pattern(d_tmp, (int)tmp.size(), d_pat, t.tiles_i16, nullptr);
+    if(err == MJX_OK) err = check_hip(hipMemcpy(pattern.data(), d_pat, (size_t)t.blocks * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(patterns)", MJX_ERR_LAUNCH);
+    if(d_tmp) (void)hipFree(d_tmp);
+    if(d_pat) (void)hipFree(d_pat);
+    return err;
+}
+
+void fill_stats(mjx_plan_stats_t *out, const SchedStats &st, int64_t runs, int slots, int run_max, int run_min) {
+    memset(out, 0, sizeof(*out));
+    out->blocks = st.blocks;
+    out->octets = st.octets;
+    out->gather_octets = st.gather_octets;
+    out->zero_alpha_octets = st.zero_octets;
+    out->runs = runs;
+    out->block_terms = st.block_terms;
+    out->union_terms = st.union_terms;
+    out->resident_waves = slots;
+    out->run_octets_max = run_max;
+    out->run_octets_min = run_min;
 }
 } // namespace
 
@@ -332,10 +584,25 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
     *plan = nullptr;
     if(njobs < 0 || nq < 0) return MJX_ERR_BAD_ARG;
     if(njobs > 0 && (jobs == nullptr || qtables == nullptr || nq == 0)) return MJX_ERR_NULL_DATA;
+    if(flags & ~(MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_TILES_I16)) return MJX_ERR_BAD_ARG;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
 
+    // one tile format per plan: the plan flag, or MJX_JOB_TILES_I16 on every job
+    bool tiles_i16 = (flags & MJX_PLAN_TILES_I16) != 0;
+    {
+        int with = 0, live = 0;
+        for(int i = 0; i < njobs; ++i) {
+            if(jobs[i].flags & ~MJX_JOB_TILES_I16) return MJX_ERR_BAD_ARG;
+            if(jobs[i].rows <= 0 || jobs[i].cols <= 0) continue;
+            ++live;
+            with += (jobs[i].flags & MJX_JOB_TILES_I16) != 0;
+        }
+        if(with != 0 && with != live) return MJX_ERR_BAD_ARG;
+        tiles_i16 = tiles_i16 || (live > 0 && with == live);
+    }
+
     Tables t;
-    int    err = build_tables(jobs, njobs, qtables, nq, t);
+    int    err = build_tables(jobs, njobs, qtables, nq, tiles_i16, t);
     if(err != MJX_OK) return err;
 
     mjx_compose_plan *p = new(std::nothrow) mjx_compose_plan;
@@ -346,38 +613,40 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
 
     do {
         if(p->njobs == 0) break;
-        if((err = check_hip(hipMalloc((void **)&p->d_jobs, t.jobs.size() * sizeof(DevJob)), "hipMalloc(jobs)", MJX_ERR_MEMORY))) break;
-        if((err = check_hip(hipMalloc((void **)&p->d_q, (size_t)nq * 64 * sizeof(uint16_t)), "hipMalloc(q)", MJX_ERR_MEMORY))) break;
-        if((err = check_hip(hipMalloc((void **)&p->d_rq, (size_t)nq * 64 * sizeof(float)), "hipMalloc(rq)", MJX_ERR_MEMORY))) break;
-        if((err = check_hip(hipMemcpy(p->d_jobs, t.jobs.data(), t.jobs.size() * sizeof(DevJob), hipMemcpyHostToDevice), "hipMemcpy(jobs)", MJX_ERR_LAUNCH))) break;
-        if((err = check_hip(hipMemcpy(p->d_q, qtables, (size_t)nq * 64 * sizeof(uint16_t), hipMemcpyHostToDevice), "hipMemcpy(q)", MJX_ERR_LAUNCH))) break;
-        if((err = check_hip(hipMemcpy(p->d_rq, t.rq.data(), (size_t)nq * 64 * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(rq)", MJX_ERR_LAUNCH))) break;
-
         if(flags & MJX_PLAN_GROUP_BY_DENSITY) {
-            // one pass over the alpha tiles as they are now: non-zero weights per block, then the
-            // octets are formed class by class.  The grouping only decides which blocks share a
-            // wavefront: results do not depend on it, nor on alpha changing afterwards.
-            Run     *d_tmp = nullptr;
-            uint8_t *d_nnz = nullptr;
-            std::vector<uint8_t> nnz((size_t)t.blocks);
-            err = check_hip(hipMalloc((void **)&d_tmp, t.runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY);
-            if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_nnz, (size_t)t.blocks), "hipMalloc(nnz)", MJX_ERR_MEMORY);
-            if(err == MJX_OK) err = check_hip(hipMemcpy(d_tmp, t.runs.data(), t.runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH);
-            if(err == MJX_OK) err = launch_alpha_nnz(p->d_jobs, d_tmp, (int)t.runs.size(), d_nnz, t.tiles_i16, nullptr);
-            if(err == MJX_OK) err = check_hip(hipMemcpy(nnz.data(), d_nnz, (size_t)t.blocks, hipMemcpyDeviceToHost), "hipMemcpy(nnz)", MJX_ERR_LAUNCH);
-            if(d_tmp) (void)hipFree(d_tmp);
-            if(d_nnz) (void)hipFree(d_nnz);
-            if(err != MJX_OK) break;
-            build_runs(t, nnz.data());
+            // one pass over the alpha tiles as they are now; the grouping only decides which blocks share
+            // a wavefront (results do not depend on it) - except that with MJX_PLAN_ALPHA_IS_FINAL blocks
+            // without weights leave their tiles behind, which is why that needs the caller's promise
+            std::vector<uint64_t> pattern;
+            if((err = scan_patterns(t, pattern)) != MJX_OK) break;
+            std::vector<JobSegment> all;
+            std::vector<Segment>    one;
+            for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
+                const DevJob &d = t.jobs[(size_t)jid];
+                one.clear();
+                schedule_tiles(pattern.data() + (size_t)(unsigned)d.nnz_off, d.nblocks, (flags & MJX_PLAN_ALPHA_IS_FINAL) != 0, t.gather, one, t.stats);
+                for(const Segment &sg : one) all.push_back(JobSegment{jid, -1, sg});
+            }
+            cut_runs(t, all);
+        }
+        else {
+            plain_runs(t);
         }
         p->nruns = (int)t.runs.size();
-        p->gather_octets = (int64_t)(t.gather.size() / kWaveBlocks);
-        if((err = check_hip(hipMalloc((void **)&p->d_runs, t.runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
-        if((err = check_hip(hipMemcpy(p->d_runs, t.runs.data(), t.runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
+        p->stats = t.stats;
+        p->slots = t.slots;
+        p->run_max = t.run_max;
+        p->run_min = t.run_min;
+        if((err = check_hip(hipMalloc(&p->d_qrq, t.qrq.size()), "hipMalloc(q)", MJX_ERR_MEMORY))) break;
+        if((err = check_hip(hipMemcpy(p->d_qrq, t.qrq.data(), t.qrq.size(), hipMemcpyHostToDevice), "hipMemcpy(q)", MJX_ERR_LAUNCH))) break;
         if(!t.gather.empty()) {
-            if((err = check_hip(hipMalloc((void **)&p->d_gather, t.gather.size() * sizeof(GatherEntry)), "hipMalloc(gather)", MJX_ERR_MEMORY))) break;
-            if((err = check_hip(hipMemcpy(p->d_gather, t.gather.data(), t.gather.size() * sizeof(GatherEntry), hipMemcpyHostToDevice), "hipMemcpy(gather)", MJX_ERR_LAUNCH))) break;
+            if((err = check_hip(hipMalloc((void **)&p->d_gather, t.gather.size() * sizeof(int32_t)), "hipMalloc(gather)", MJX_ERR_MEMORY))) break;
+            if((err = check_hip(hipMemcpy(p->d_gather, t.gather.data(), t.gather.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(gather)", MJX_ERR_LAUNCH))) break;
         }
+        std::vector<Run> runs(t.runs.size());
+        expand_runs(t, runs.data(), p->d_gather, nullptr);
+        if((err = check_hip(hipMalloc((void **)&p->d_runs, runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
+        if((err = check_hip(hipMemcpy(p->d_runs, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
     } while(0);
     if(err != MJX_OK) {
         mjx_compose_plan_destroy(p);
@@ -387,18 +656,90 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
     return MJX_OK;
 }
 
+// The legacy entry point never looks at mjx_rect_job_t.flags: the field lies in what was tail padding
+// of the struct before version 101, which callers that fill the struct member by member leave
+// indeterminate (a stray bit 0 would make float tiles be read as int16).
 int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq) {
-    return mjx_compose_plan_create_ex(plan, jobs, njobs, qtables, nq, 0);
+    if(plan == nullptr) return MJX_ERR_NULL_DATA;
+    *plan = nullptr;
+    if(njobs > 0 && jobs == nullptr) return MJX_ERR_NULL_DATA;
+    std::vector<mjx_rect_job_t> clean;
+    if(njobs > 0) {
+        clean.assign(jobs, jobs + njobs);
+        for(mjx_rect_job_t &j : clean) j.flags = 0;
+    }
+    return mjx_compose_plan_create_ex(plan, clean.data(), njobs, qtables, nq, 0);
 }
 
-int64_t mjx_compose_plan_gather_octets(const mjx_compose_plan_t *plan) { return plan ? plan->gather_octets : 0; }
+int64_t mjx_compose_plan_gather_octets(const mjx_compose_plan_t *plan) { return plan ? plan->stats.gather_octets : 0; }
 
 int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan) { return plan ? plan->blocks : 0; }
+
+int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out) {
+    if(plan == nullptr || out == nullptr) return MJX_ERR_NULL_DATA;
+    fill_stats(out, plan->stats, plan->nruns, plan->slots, plan->run_max, plan->run_min);
+    return MJX_OK;
+}
 
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
     if(plan->nruns == 0) return MJX_OK;
-    return launch_compose(plan->d_jobs, plan->d_runs, plan->nruns, plan->d_q, plan->d_rq, plan->d_gather, plan->tiles_i16, (hipStream_t)stream);
+    return launch_compose(plan->d_runs, plan->nruns, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
+}
+
+// ---- schedules kept with resident tiles ------------------------------------------------------------
+void mjx_tile_schedule_destroy(mjx_tile_schedule_t *s) {
+    if(s == nullptr) return;
+    if(s->d_gather) (void)hipFree(s->d_gather);
+    delete s;
+}
+
+int mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha, int rows, int cols, int flags) {
+    if(sched == nullptr) return MJX_ERR_NULL_DATA;
+    *sched = nullptr;
+    if(rows <= 0 || cols <= 0 || (int64_t)rows * cols >= (1ll << 24) || (flags & ~MJX_JOB_TILES_I16)) return MJX_ERR_BAD_ARG;
+    if(alpha == nullptr) return MJX_ERR_NULL_DATA;
+    if(!aligned16(alpha)) return MJX_ERR_BAD_ARG;
+    if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    Tables t;
+    t.tiles_i16 = (flags & MJX_JOB_TILES_I16) != 0;
+    DevJob d;
+    memset(&d, 0, sizeof(d));
+    d.alpha = static_cast<const float *>(alpha);
+    d.cols = cols;
+    d.nblocks = rows * cols;
+    d.inv_cols = 1.0f / (float)cols;
+    t.jobs.push_back(d);
+    t.blocks = d.nblocks;
+    std::vector<uint64_t> pattern;
+    int                   err = scan_patterns(t, pattern);
+    if(err != MJX_OK) return err;
+    mjx_tile_schedule *s = new(std::nothrow) mjx_tile_schedule;
+    if(s == nullptr) return MJX_ERR_MEMORY;
+    s->rows = rows;
+    s->cols = cols;
+    s->tiles_i16 = t.tiles_i16;
+    (void)hipGetDevice(&s->device);
+    std::vector<int32_t> gather;
+    schedule_tiles(pattern.data(), d.nblocks, true, gather, s->segs, s->stats);
+    if(!gather.empty()) {
+        err = check_hip(hipMalloc((void **)&s->d_gather, gather.size() * sizeof(int32_t)), "hipMalloc(schedule)", MJX_ERR_MEMORY);
+        if(err == MJX_OK) err = check_hip(hipMemcpy(s->d_gather, gather.data(), gather.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(schedule)", MJX_ERR_LAUNCH);
+        if(err != MJX_OK) {
+            mjx_tile_schedule_destroy(s);
+            return err;
+        }
+    }
+    *sched = s;
+    return MJX_OK;
+}
+
+int64_t mjx_tile_schedule_gather_octets(const mjx_tile_schedule_t *sched) { return sched ? sched->stats.gather_octets : 0; }
+
+int mjx_tile_schedule_stats(const mjx_tile_schedule_t *sched, mjx_plan_stats_t *out) {
+    if(sched == nullptr || out == nullptr) return MJX_ERR_NULL_DATA;
+    fill_stats(out, sched->stats, 0, 0, 0, 0);
+    return MJX_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -558,21 +899,29 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     if(n < 0) return MJX_ERR_BAD_ARG;
     if(n == 0) return MJX_OK;
     if(rects == nullptr) return MJX_ERR_NULL_DATA;
-    int live = 0;
+    int live = 0, with_i16 = 0;
     for(int i = 0; i < n; ++i) {
         const mjx_host_rect_t &r = rects[i];
         if(r.rows < 0 || r.cols < 0 || r.col0 < 0 || r.blocks_per_row <= 0 || r.col0 + (int64_t)r.cols > r.blocks_per_row) return MJX_ERR_BAD_ARG;
+        if(r.flags & ~(MJX_RECT_TILES_ON_DEVICE | MJX_RECT_ROWS_ON_DEVICE | MJX_RECT_TILES_I16)) return MJX_ERR_BAD_ARG;
         if(r.rows == 0 || r.cols == 0) continue;
         if(r.rows_ptr == nullptr || r.tile == nullptr || r.alpha == nullptr || r.q == nullptr) return MJX_ERR_NULL_DATA;
+        if(r.schedule != nullptr && (r.schedule->rows != r.rows || r.schedule->cols != r.cols || r.schedule->tiles_i16 != ((r.flags & MJX_RECT_TILES_I16) != 0)))
+            return MJX_ERR_BAD_ARG; // a schedule belongs to the tiles it was made from
         ++live;
+        with_i16 += (r.flags & MJX_RECT_TILES_I16) != 0;
     }
     if(live == 0) return MJX_OK;
+    if(with_i16 != 0 && with_i16 != live) return MJX_ERR_BAD_ARG; // one tile format per launch
+    const bool   tiles_i16 = with_i16 != 0;
+    const size_t tile_block_bytes = tiles_i16 ? 128 : 256;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
 
     // device layout: [descriptor packet | per rectangle: plane rows, tile, alpha (unless resident)]
     std::vector<mjx_rect_job_t> jobs;
     std::vector<uint16_t>       qt;
     std::vector<size_t>         coef_off;
+    std::vector<const mjx_tile_schedule_t *> scheds;
     size_t                      data_bytes = 0, stage_bytes = 0;
     // a rectangle much narrower than the plane travels alone, gathered into pinned memory (a 256x256
     // overlay on a 1080p image: 0.2 MB instead of 1.5 MB of whole rows each way, 0.17 instead of
@@ -589,9 +938,8 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         else if(!(r.flags & MJX_RECT_ROWS_ON_DEVICE)) {
             data_bytes += round256((size_t)r.rows * r.blocks_per_row * 128);
         }
-        if(!(r.flags & MJX_RECT_TILES_ON_DEVICE)) data_bytes += 2 * round256((size_t)r.rows * r.cols * 256);
+        if(!(r.flags & MJX_RECT_TILES_ON_DEVICE)) data_bytes += 2 * round256((size_t)r.rows * r.cols * tile_block_bytes);
     }
-    // upper bound of the packet: jobs may be split (never for real JPEG sizes) -> size after build
     // first pass with placeholder pointers to learn the table sizes
     for(int i = 0; i < n; ++i) {
         const mjx_host_rect_t &r = rects[i];
@@ -609,13 +957,16 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         j.cols = r.cols;
         j.qtable = (int)jobs.size();
         jobs.push_back(j);
+        scheds.push_back(r.schedule);
         qt.insert(qt.end(), r.q, r.q + 64);
     }
     const int    nq = (int)jobs.size();
-    // runs hold at least two octets of 8 blocks each, plus a ragged one per (possibly split) job
+    // runs hold at least two octets of 8 blocks each (one when a segment of a schedule is that short),
+    // plus a ragged one per (possibly split) job
     size_t max_runs = 16;
-    for(const mjx_rect_job_t &j : jobs) max_runs += (size_t)j.rows * (size_t)j.cols / (kWaveBlocks * 2) + 4;
-    const size_t packet_cap = round256(2 * jobs.size() * sizeof(DevJob)) + round256((size_t)nq * 64 * 6) + round256(max_runs * sizeof(Run));
+    for(size_t k = 0; k < jobs.size(); ++k)
+        max_runs += (size_t)jobs[k].rows * (size_t)jobs[k].cols / (kWaveBlocks * 2) + 4 + (scheds[k] ? 2 * scheds[k]->segs.size() : 0);
+    const size_t packet_cap = round256((size_t)nq * kQuantTableBytes) + round256(max_runs * sizeof(Run));
     ArenaLease arena;
     int        err = arena->prepare(packet_cap + data_bytes, packet_cap + stage_bytes);
     if(err != MJX_OK) return err;
@@ -628,7 +979,7 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     for(int i = 0; i < n; ++i) {
         const mjx_host_rect_t &r = rects[i];
         if(r.rows == 0 || r.cols == 0) continue;
-        const size_t cb = (size_t)r.rows * r.cols * 128, tb = (size_t)r.rows * r.cols * 256;
+        const size_t cb = (size_t)r.rows * r.cols * 128, tb = (size_t)r.rows * r.cols * tile_block_bytes;
         mjx_rect_job_t &j = jobs[k++];
         if(r.flags & MJX_RECT_ROWS_ON_DEVICE) {
             j.coef = r.rows_ptr;
@@ -667,21 +1018,36 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         }
     }
     Tables t;
-    err = build_tables(jobs.data(), (int)jobs.size(), qt.data(), nq, t);
+    err = build_tables(jobs.data(), (int)jobs.size(), qt.data(), nq, tiles_i16, t);
     if(err != MJX_OK) return err;
+    {   // runs: the segments of a rectangle's schedule where it has one (made for exactly these tiles:
+        // a job is never split for real JPEG sizes, and a split one falls back to consecutive octets)
+        std::vector<JobSegment> all;
+        std::vector<Segment>    one;
+        const bool              one_to_one = t.jobs.size() == jobs.size();
+        for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
+            const mjx_tile_schedule_t *sc = one_to_one ? scheds[(size_t)jid] : nullptr;
+            if(sc != nullptr) {
+                for(const Segment &sg : sc->segs) all.push_back(JobSegment{jid, jid, sg});
+                t.stats.add(sc->stats);
+            }
+            else {
+                one.clear();
+                schedule_tiles(nullptr, t.jobs[(size_t)jid].nblocks, false, t.gather, one, t.stats);
+                all.push_back(JobSegment{jid, -1, one[0]});
+            }
+        }
+        cut_runs(t, all);
+    }
 
-    // descriptor packet in pinned memory: [DevJob[] | Run[] | q | rq], one copy
-    const size_t o_jobs = 0, o_runs = round256(t.jobs.size() * sizeof(DevJob)), o_q = o_runs + round256(t.runs.size() * sizeof(Run)),
-                 o_rq = o_q + round256((size_t)nq * 128), packet = o_rq + round256((size_t)nq * 256);
+    // descriptor packet in pinned memory: [Run[] | quantisation tables], one copy
+    const size_t o_runs = 0, o_q = round256(t.runs.size() * sizeof(Run)), packet = o_q + round256(t.qrq.size());
     if(packet > packet_cap) return MJX_ERR_BAD_ARG; // cannot happen for rectangles below 2^24 blocks
-    memcpy(arena->pin + o_jobs, t.jobs.data(), t.jobs.size() * sizeof(DevJob));
-    memcpy(arena->pin + o_runs, t.runs.data(), t.runs.size() * sizeof(Run));
-    memcpy(arena->pin + o_q, qt.data(), (size_t)nq * 128);
-    memcpy(arena->pin + o_rq, t.rq.data(), (size_t)nq * 256);
+    expand_runs(t, reinterpret_cast<Run *>(arena->pin + o_runs), nullptr, scheds.data());
+    memcpy(arena->pin + o_q, t.qrq.data(), t.qrq.size());
     MJX_HIP(hipMemcpyAsync(base, arena->pin, packet, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
 
-    err = launch_compose(reinterpret_cast<const DevJob *>(base + o_jobs), reinterpret_cast<const Run *>(base + o_runs), (int)t.runs.size(),
-                         reinterpret_cast<const uint16_t *>(base + o_q), reinterpret_cast<const float *>(base + o_rq), nullptr, false, s);
+    err = launch_compose(reinterpret_cast<const Run *>(base + o_runs), (int)t.runs.size(), base + o_q, tiles_i16, s);
     if(err == MJX_OK) {
         k = 0;
         for(int i = 0; i < n && err == MJX_OK; ++i) {
@@ -724,6 +1090,7 @@ int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, in
     r.cols = cols;
     r.flags = 0;
     r.reserved = 0;
+    r.schedule = nullptr;
     return mjx_compose_host(&r, 1);
 }
 

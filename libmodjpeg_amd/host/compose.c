@@ -15,9 +15,11 @@
 typedef struct {
     int          rows, cols;   /* tile grid */
     const float *tile, *alpha; /* host or device memory, as the caller of blend_components says */
+    const mjx_tile_schedule_t *schedule; /* resident tiles: how their blocks are shared out (NULL: consecutive octets) */
 } comp_tiles_t;
 
-static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int tiles_on_device, int block_x, int block_y);
+/* tiles_flags: MJX_RECT_TILES_ON_DEVICE, MJX_RECT_TILES_I16 */
+static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int tiles_flags, int block_x, int block_y);
 
 /* one axis of the placement: where the overlay starts on the image and what survives cropping */
 typedef struct {
@@ -78,8 +80,11 @@ int mj_compose(mj_jpeg_t *m, mj_dropon_t *d, unsigned int align, int offset_x, i
         comp_tiles_t ct[4];
         int          c, n = mjh_tiles_ncomp(cached);
         memset(ct, 0, sizeof(ct));
-        for(c = 0; c < n && c < 4; c++) mjh_tiles_component(cached, c, &ct[c].rows, &ct[c].cols, &ct[c].tile, &ct[c].alpha);
-        rv = blend_components(m, n, ct, 1, mcu_x, mcu_y);
+        for(c = 0; c < n && c < 4; c++) {
+            mjh_tiles_component(cached, c, &ct[c].rows, &ct[c].cols, &ct[c].tile, &ct[c].alpha);
+            ct[c].schedule = mjh_tiles_schedule(cached, c);
+        }
+        rv = blend_components(m, n, ct, MJX_RECT_TILES_ON_DEVICE | (mjh_tiles_i16(cached) ? MJX_RECT_TILES_I16 : 0), mcu_x, mcu_y);
         mjh_tiles_release(cached);
         return rv;
     }
@@ -111,7 +116,11 @@ static const float *contiguous_tiles(const mj_component_t *t, float **owned) {
  * the plane rows under the rectangle go to the GPU (straight out of libjpeg's pool when the plane
  * is one contiguous chunk, else through a gathered copy), tiles come from the host or are already
  * resident on the device. */
-static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int tiles_on_device, int block_x, int block_y) {
+/* statistics (tests, diagnostics): rectangles that went to the kernel with int16 tiles / with a schedule
+ * that picks the blocks of an octet by what they need / all rectangles */
+long mjh_stat_rects, mjh_stat_rects_i16, mjh_stat_rects_scheduled;
+
+static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int tiles_flags, int block_x, int block_y) {
     enum { MAXC = 4 };
     mjx_host_rect_t rect[MAXC];
     uint16_t        q[MAXC][64];
@@ -131,7 +140,8 @@ static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int til
         rect[c].cols = ct[c].cols;
         rect[c].col0 = block_x * ci->h_samp_factor; /* compose.c:264 */
         row0[c] = block_y * ci->v_samp_factor;      /* compose.c:265 */
-        rect[c].flags = tiles_on_device ? MJX_RECT_TILES_ON_DEVICE : 0;
+        rect[c].flags = tiles_flags;
+        rect[c].schedule = ct[c].schedule;
         if(rect[c].rows <= 0 || rect[c].cols <= 0) {
             rect[c].rows = rect[c].cols = 0;
             continue;
@@ -172,7 +182,15 @@ static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int til
             rect[c].rows_ptr = staged[c];
         }
     }
-    if(rv == MJ_OK) rv = mjh_from_mjx(mjx_compose_host(rect, n));
+    if(rv == MJ_OK) {
+        for(c = 0; c < n; c++) {
+            if(rect[c].rows == 0 || rect[c].cols == 0) continue;
+            __sync_fetch_and_add(&mjh_stat_rects, 1);
+            if(rect[c].flags & MJX_RECT_TILES_I16) __sync_fetch_and_add(&mjh_stat_rects_i16, 1);
+            if(rect[c].schedule != NULL && mjx_tile_schedule_gather_octets(rect[c].schedule) > 0) __sync_fetch_and_add(&mjh_stat_rects_scheduled, 1);
+        }
+        rv = mjh_from_mjx(mjx_compose_host(rect, n));
+    }
     for(c = 0; c < MAXC; c++) {
         if(staged[c] != NULL) {
             if(rv == MJ_OK) mjh_rows_scatter(m, c, row0[c], rect[c].rows, staged[c]);

@@ -78,6 +78,7 @@ typedef struct mjh_shadow {
     int      pitch[4], rows[4];
     void    *buffer;
     size_t   bytes;
+    int      device; /* HIP ordinal the planes live on */
 } mjh_shadow_t;
 void          mjh_set_device_resident(int on);
 int           mjh_device_count(void);
@@ -97,6 +98,8 @@ int  mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs,
 void mjh_tiles_release(struct mjh_tiles *t);
 int  mjh_tiles_ncomp(const struct mjh_tiles *t);
 void mjh_tiles_component(const struct mjh_tiles *t, int c, int *rows, int *cols, const float **dev_tile, const float **dev_alpha);
+int  mjh_tiles_i16(const struct mjh_tiles *t); /* the tile arrays hold int16 coefficients (MJX_RECT_TILES_I16) */
+const mjx_tile_schedule_t *mjh_tiles_schedule(const struct mjh_tiles *t, int c); /* NULL: consecutive octets */
 
 /* MJX_* -> MJ_ERR_* (INTEGRATION.md "error mapping"); prints once when the GPU is unusable */
 int mjh_from_mjx(int mjx_err);

@@ -31,6 +31,13 @@
  *        distribution (0: Fibonacci-like counts, code lengths beyond 16 bits; 1: many equal counts;
  *        2: random), lets libjpeg write it with optimised Huffman tables and compares the DHT tables
  *        in that file with mjx_huff_optimal_table() on the same symbol histograms.
+ *   mjhost_probe composepath <image.jpg> <dropon.png> <times>
+ *        mj_compose of the overlay, `times` times, through the public API; prints which kernel path
+ *        the calls took: "<rectangles> <with int16 tiles> <with a pattern schedule> <tiles prepared on the device>".
+ *   mjhost_probe shadowpool <image.jpg>
+ *        (two devices needed, real or simulated) the recycled device buffers of device-resident images
+ *        (shadow.c) belong to their device: a buffer released on GPU 0 must not be handed to an image
+ *        of GPU 1, and is reused on GPU 0.  Prints "ok".
  *   mjhost_probe nodevice <image.jpg>
  *        prints the return codes of mj_effect_luminance and mj_compose (expects MJ_ERR_MEMORY
  *        on a machine without a GPU: there is no CPU fallback).
@@ -83,9 +90,17 @@ static uint64_t compose_hash(int placement) {
     return h;
 }
 
+/* MJ_STRESS_DEVICES=n: worker t works on GPU t mod n (cached tiles, schedules and staging arenas of the
+ * n devices interleave in the same cache / pool; nothing of one device may reach a thread of another) */
+extern int mjh_use_device(int ordinal);
 static void *stress_worker(void *arg) {
-    const int id = (int)(intptr_t)arg;
-    int       k;
+    const int   id = (int)(intptr_t)arg;
+    const char *e = getenv("MJ_STRESS_DEVICES");
+    int         k;
+    if(e != NULL && atoi(e) > 1 && mjh_use_device(id % atoi(e)) != MJ_OK) {
+        __sync_fetch_and_add(&g_bad, 1000);
+        return NULL;
+    }
     for(k = 0; k < g_iters; k++) {
         const int placement = (id * 5 + k * 7) % 12;
         if(compose_hash(placement) != g_want[placement]) __sync_fetch_and_add(&g_bad, 1);
@@ -366,6 +381,7 @@ int main(int argc, char **argv) {
         extern int  mjh_tiles_ncomp(const struct mjh_tiles *t);
         extern void mjh_tiles_component(const struct mjh_tiles *t, int c, int *rows, int *cols, const float **dev_tile, const float **dev_alpha);
         extern int  mjh_download(void *host, const void *dev, size_t bytes);
+        extern int  mjh_tiles_i16(const struct mjh_tiles *t);
         extern int  mjh_tiles_gpu_prepared;
         mj_jpeg_t         m;
         mj_dropon_t       d;
@@ -393,6 +409,27 @@ int main(int argc, char **argv) {
             dims[1] = rows;
             buf = malloc((size_t)rows * cols * 256 + 16);
             fwrite(dims, sizeof(int), 2, f);
+            if(mjh_tiles_i16(t)) {
+                /* the cache keeps the int16 coefficients: written out as the floats the reference makes of them
+                 * (dropon.c:476-485 tile = (float)coef; :542-566 weight = (float)((float)coef * K), K double,
+                 * the DC offset already added), which is also what the compose kernel does with them */
+                const double c0 = 0.3535534, c1 = 0.5;
+                int16_t     *raw16 = malloc((size_t)rows * cols * 128 + 16);
+                size_t       i, n = (size_t)rows * cols * 64;
+                if(mjh_download(raw16, dt, n * 2) != 0) return 41;
+                for(i = 0; i < n; i++) buf[i] = (float)raw16[i];
+                fwrite(buf, 256, (size_t)rows * cols, f);
+                if(mjh_download(raw16, da, n * 2) != 0) return 42;
+                for(i = 0; i < n; i++) {
+                    const int    v = (int)(i % 64) / 8, u = (int)(i % 8);
+                    const double k = (v == 0 ? c0 : c1) * (u == 0 ? c0 : c1) / 1020.0;
+                    buf[i] = (float)((float)raw16[i] * k);
+                }
+                fwrite(buf, 256, (size_t)rows * cols, f);
+                free(raw16);
+                free(buf);
+                continue;
+            }
             if(mjh_download(buf, dt, (size_t)rows * cols * 256) != 0) return 41;
             fwrite(buf, 256, (size_t)rows * cols, f);
             if(mjh_download(buf, da, (size_t)rows * cols * 256) != 0) return 42;
@@ -489,6 +526,54 @@ int main(int argc, char **argv) {
         return count[2] ? 1 : 0;
     }
     if(argc == 5 && strcmp(argv[1], "opttables") == 0) return opttables(argv[2], atoi(argv[3]), (uint32_t)atoi(argv[4]));
+    if(argc == 3 && strcmp(argv[1], "shadowpool") == 0) {
+        /* drop-in internals (shadow.c); mjh_shadow_t is not visible here: its `buffer` field is read through the accessor below */
+        extern void  mjh_set_device_resident(int on);
+        extern void *mjh_shadow_create(mj_jpeg_t * m);
+        extern void  mjh_shadow_drop(mj_jpeg_t * m);
+        extern void *mjh_shadow_buffer(const mj_jpeg_t *m);
+        extern int   mjh_download(void *host, const void *dev, size_t bytes);
+        mj_jpeg_t m;
+        void     *p0, *p1, *p2;
+        char      probe16[16];
+        mj_init_jpeg(&m);
+        setenv("MJ_GPU_DECODE", "0", 1);
+        if(mj_read_jpeg_from_file(&m, argv[2], 0) != MJ_OK) return 10;
+        mjh_set_device_resident(1);
+        if(mjh_use_device(0) != MJ_OK || mjh_shadow_create(&m) == NULL) return 11;
+        p0 = mjh_shadow_buffer(&m);
+        mjh_shadow_drop(&m); /* the buffer goes back to the pool, tagged GPU 0 */
+        if(mjh_use_device(1) != MJ_OK || mjh_shadow_create(&m) == NULL) return 12;
+        p1 = mjh_shadow_buffer(&m);
+        if(p1 == p0) return 20;                                   /* GPU 1 was handed GPU 0's buffer */
+        if(mjh_download(probe16, p1, 16) != MJ_OK) return 21;     /* ... and can use its own */
+        mjh_shadow_drop(&m);
+        if(mjh_use_device(0) != MJ_OK || mjh_shadow_create(&m) == NULL) return 13;
+        p2 = mjh_shadow_buffer(&m);
+        if(p2 != p0) return 22;                                   /* GPU 0 gets its buffer back */
+        if(mjh_download(probe16, p2, 16) != MJ_OK) return 23;
+        mjh_shadow_drop(&m);
+        mj_free_jpeg(&m);
+        printf("ok\n");
+        return 0;
+    }
+    if(argc == 5 && strcmp(argv[1], "composepath") == 0) {
+        extern long mjh_stat_rects, mjh_stat_rects_i16, mjh_stat_rects_scheduled;
+        extern int  mjh_tiles_gpu_prepared;
+        mj_jpeg_t   m;
+        mj_dropon_t d;
+        int         i, rv;
+        mj_init_jpeg(&m);
+        mj_init_dropon(&d);
+        if((rv = mj_read_jpeg_from_file(&m, argv[2], 0)) != MJ_OK) return 10 + rv;
+        if((rv = mj_read_dropon_from_file(&d, argv[3], NULL, 255)) != MJ_OK) return 20 + rv;
+        for(i = 0; i < atoi(argv[4]); i++)
+            if((rv = mj_compose(&m, &d, MJ_ALIGN_TOP | MJ_ALIGN_LEFT, 16 * i, 8 * i)) != MJ_OK) return 30 + rv;
+        printf("%ld %ld %ld %d\n", mjh_stat_rects, mjh_stat_rects_i16, mjh_stat_rects_scheduled, mjh_tiles_gpu_prepared);
+        mj_free_dropon(&d);
+        mj_free_jpeg(&m);
+        return 0;
+    }
     if(argc == 3 && strcmp(argv[1], "nodevice") == 0) {
         mj_jpeg_t     m;
         mj_dropon_t   d;

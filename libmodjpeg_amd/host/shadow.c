@@ -45,20 +45,24 @@ int mjh_device_resident(void) {
     return g_resident;
 }
 
-/* ---- device buffers, recycled: hipMalloc/hipFree synchronise the device ------------------ */
+/* ---- device buffers, recycled: hipMalloc/hipFree synchronise the device ------------------
+ * A buffer belongs to the device it was allocated on: a worker of GPU 1 must never be handed a buffer
+ * of GPU 0 (no peer access is set up), so the pool is searched by device. */
 enum { POOL_SLOTS = 64 };
 static struct {
     void  *ptr;
     size_t bytes;
+    int    device;
 } g_pool[POOL_SLOTS];
 static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void *pool_get(size_t bytes, size_t *got) {
     void *p = NULL;
-    int   i;
+    int   i, device = 0;
+    if(mjx_get_device(&device) != MJX_OK) return NULL;
     pthread_mutex_lock(&g_pool_lock);
     for(i = 0; i < POOL_SLOTS; i++) {
-        if(g_pool[i].ptr != NULL && g_pool[i].bytes >= bytes && g_pool[i].bytes <= bytes + bytes / 2) {
+        if(g_pool[i].ptr != NULL && g_pool[i].device == device && g_pool[i].bytes >= bytes && g_pool[i].bytes <= bytes + bytes / 2) {
             p = g_pool[i].ptr;
             *got = g_pool[i].bytes;
             g_pool[i].ptr = NULL;
@@ -73,13 +77,16 @@ static void *pool_get(size_t bytes, size_t *got) {
     return p;
 }
 
-static void pool_put(void *p, size_t bytes) {
+/* `device`: where the buffer lives (the shadow remembers: an image may be freed by another thread than
+ * the one that read it) */
+static void pool_put(void *p, size_t bytes, int device) {
     int i;
     pthread_mutex_lock(&g_pool_lock);
     for(i = 0; i < POOL_SLOTS; i++) {
         if(g_pool[i].ptr == NULL) {
             g_pool[i].ptr = p;
             g_pool[i].bytes = bytes;
+            g_pool[i].device = device;
             p = NULL;
             break;
         }
@@ -107,6 +114,7 @@ mjh_shadow_t *mjh_shadow_create(mj_jpeg_t *m) {
         s->rows[c] = mjh_row_count(m, c);
         total += ((size_t)s->pitch[c] * (size_t)s->rows[c] * sizeof(JBLOCK) + 255) & ~(size_t)255;
     }
+    if(mjx_get_device(&s->device) != MJX_OK) s->device = 0;
     s->buffer = pool_get(total, &s->bytes);
     if(s->buffer == NULL) {
         free(s);
@@ -122,12 +130,18 @@ mjh_shadow_t *mjh_shadow_create(mj_jpeg_t *m) {
     return s;
 }
 
+/* test support (mjhost_probe shadowpool) */
+void *mjh_shadow_buffer(const mj_jpeg_t *m) {
+    mjh_shadow_t *s = mjh_shadow_of(m);
+    return s != NULL ? s->buffer : NULL;
+}
+
 void mjh_shadow_drop(mj_jpeg_t *m) {
     mjh_shadow_t *s = mjh_shadow_of(m);
     if(s == NULL) return;
     m->cinfo.client_data = NULL;
     s->magic = 0;
-    pool_put(s->buffer, s->bytes);
+    pool_put(s->buffer, s->bytes, s->device);
     free(s);
 }
 
@@ -153,7 +167,7 @@ int mjh_host_sync(mj_jpeg_t *m) {
         }
     }
     s->magic = 0;
-    pool_put(s->buffer, s->bytes);
+    pool_put(s->buffer, s->bytes, s->device);
     free(s);
     return rv;
 }

@@ -15,12 +15,26 @@
  * byte, so a hash collision can never hand out another overlay's tiles.  It is transparent (same
  * results as without it; MJ_TILE_CACHE=0 disables it), bounded (8 entries, 1 GiB including the
  * pixel copies), process-wide and mutex-protected; entries in use are never evicted, and the lock
- * is held only for table look-ups and pointer moves: tile preparation, hipMalloc, the upload and
- * every hipFree happen outside it.
+ * is held only for table look-ups and pointer moves: the byte-for-byte comparison of the window (tens
+ * of MB for a 4K overlay), tile preparation, hipMalloc, the upload and every hipFree happen outside it.
+ *
+ * What a slot holds (round 3): the tiles as the int16 coefficients they are made from when the device
+ * prepared them (MJX_PREP_TILES_I16: 512 instead of 768 bytes of traffic per composed block, the
+ * kernel converts them bit for bit; MJ_TILES_I16=0 keeps floats), and per component a schedule
+ * (mjx_tile_schedule_create: which blocks share a wavefront, from the zero patterns of the alpha
+ * blocks, read once; MJ_TILE_SCHEDULE=0 disables).  Both are what mj_compose hands to
+ * mjx_compose_host, so the reference's API runs the same kernel paths as the batch plans.
+ *
+ * The device preparation reproduces ONE library's arithmetic (IJG libjpeg 9d's forward DCTs with DCT
+ * scaling, csrc/mjx_fdct_tables.h).  It is therefore compiled in only against that API generation
+ * (JPEG_LIB_VERSION >= 90) and, at run time, used for a target format only after ONE small overlay has
+ * been prepared both ways for that format and the results were identical (device_prep_verified);
+ * otherwise every miss goes to libjpeg, as in the reference.
  */
 #include "mjhost.h"
 
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -34,7 +48,9 @@ struct mjh_tiles {
     size_t   bytes;    /* device bytes + the host copy of the window */
     int      ncomp;
     int      rows[4], cols[4];
-    float   *dev_tile[4], *dev_alpha[4];
+    float   *dev_tile[4], *dev_alpha[4]; /* float[n][64], or int16_t[n][64] when i16 */
+    int      i16;
+    mjx_tile_schedule_t *sched[4];
     /* what the key stands for, compared on every hit: a hash decides where to look, never what is equal */
     int            device;     /* HIP ordinal the tiles live on */
     int            params[16]; /* colour spaces, in-MCU offset, crop size, sampling */
@@ -52,7 +68,7 @@ static int cache_enabled(void) {
 }
 
 /* two independent multiply-xorshift lanes over 8-byte words: an index into the cache, not an
- * identity (see matches()) */
+ * identity (see same_window()) */
 typedef struct {
     uint64_t a, b;
 } hash128_t;
@@ -112,12 +128,17 @@ static void make_key(uint64_t key[2], const int params[16], int device, const mj
     key[1] = h.b;
 }
 
-/* a slot holds exactly these tiles: same device, same parameters, same visible pixels byte for byte */
-static int matches(const struct mjh_tiles *t, const uint64_t key[2], const int params[16], int device, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
+/* a slot that may hold these tiles: same key, device and parameters (cheap: what is tested under the lock) */
+static int candidate(const struct mjh_tiles *t, const uint64_t key[2], const int params[16], int device, int cw, int ch) {
+    if(!t->valid || t->key[0] != key[0] || t->key[1] != key[1] || t->device != device) return 0;
+    return memcmp(t->params, params, 16 * sizeof(int)) == 0 && t->win_bytes == 2 * (size_t)cw * 3 * (size_t)ch;
+}
+
+/* ... and does: same visible pixels byte for byte (tens of MB for a 4K overlay: the caller holds the slot
+ * pinned by users++, never the lock; a slot's window is immutable while it is pinned) */
+static int same_window(const struct mjh_tiles *t, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
     const size_t row = (size_t)cw * 3;
     int          y;
-    if(!t->valid || t->key[0] != key[0] || t->key[1] != key[1] || t->device != device) return 0;
-    if(memcmp(t->params, params, 16 * sizeof(int)) != 0 || t->win_bytes != 2 * row * (size_t)ch) return 0;
     for(y = 0; y < ch; y++) {
         const size_t off = ((size_t)(y + cy) * (size_t)d->width + (size_t)cx) * 3;
         if(memcmp(t->window + (size_t)y * row, d->image + off, row) != 0) return 0;
@@ -126,36 +147,61 @@ static int matches(const struct mjh_tiles *t, const uint64_t key[2], const int p
     return 1;
 }
 
+/* look the tiles up: candidates are pinned under the lock and compared outside it.  Returns the slot
+ * with users already incremented, or NULL. */
+static struct mjh_tiles *lookup(const uint64_t key[2], const int params[16], int device, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
+    int i;
+    for(i = 0; i < CACHE_SLOTS; i++) {
+        struct mjh_tiles *t = &g_slots[i];
+        int               hit;
+        pthread_mutex_lock(&g_lock);
+        hit = candidate(t, key, params, device, cw, ch);
+        if(hit) t->users++;
+        pthread_mutex_unlock(&g_lock);
+        if(!hit) continue;
+        if(same_window(t, d, cx, cy, cw, ch)) {
+            pthread_mutex_lock(&g_lock);
+            t->stamp = ++g_clock;
+            pthread_mutex_unlock(&g_lock);
+            return t;
+        }
+        mjh_tiles_release(t); /* a hash collision: not ours */
+    }
+    return NULL;
+}
+
 /* device buffers and window copy of an entry that has left the table (called WITHOUT the lock) */
 static void contents_free(struct mjh_tiles *t) {
     int c;
     for(c = 0; c < 4; c++) {
         if(t->dev_tile[c]) (void)mjx_free(t->dev_tile[c]);
         if(t->dev_alpha[c]) (void)mjx_free(t->dev_alpha[c]);
+        if(t->sched[c]) mjx_tile_schedule_destroy(t->sched[c]);
     }
     free(t->window);
     memset(t, 0, sizeof(*t));
 }
 
-/* upload freshly compiled tiles into `t` and keep a copy of the window (called WITHOUT the lock,
- * on a private struct) */
-static int contents_fill(struct mjh_tiles *t, const mj_compileddropon_t *cd, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
-    const size_t row = (size_t)cw * 3;
-    int          c, y;
-    t->ncomp = cd->image_ncomponents;
-    t->bytes = 0;
+static int env_on(const char *name) { /* switches that default to on */
+    const char *e = getenv(name);
+    return !(e != NULL && e[0] == '0');
+}
+
+/* the schedules of a filled slot (which blocks share a wavefront: read once from the alpha tiles, kept with them) */
+static int contents_schedule(struct mjh_tiles *t) {
+    int c, e;
+    if(!env_on("MJ_TILE_SCHEDULE")) return MJX_OK;
     for(c = 0; c < t->ncomp; c++) {
-        const size_t bytes = (size_t)cd->image[c].nblocks * 64 * sizeof(float);
-        int          e;
-        t->rows[c] = cd->image[c].height_in_blocks;
-        t->cols[c] = cd->image[c].width_in_blocks;
-        if(cd->image[c].nblocks == 0) continue;
-        if((e = mjx_malloc((void **)&t->dev_tile[c], bytes)) != MJX_OK) return e;
-        if((e = mjx_malloc((void **)&t->dev_alpha[c], bytes)) != MJX_OK) return e;
-        if((e = mjx_memcpy_h2d(t->dev_tile[c], cd->image[c].blocks[0], bytes, NULL)) != MJX_OK) return e;
-        if((e = mjx_memcpy_h2d(t->dev_alpha[c], cd->alpha[c].blocks[0], bytes, NULL)) != MJX_OK) return e;
-        t->bytes += 2 * bytes;
+        if(t->rows[c] <= 0 || t->cols[c] <= 0 || t->dev_alpha[c] == NULL) continue;
+        if((int64_t)t->rows[c] * t->cols[c] >= (1 << 24)) continue; /* beyond what one schedule covers: consecutive octets */
+        if((e = mjx_tile_schedule_create(&t->sched[c], t->dev_alpha[c], t->rows[c], t->cols[c], t->i16 ? MJX_JOB_TILES_I16 : 0)) != MJX_OK) return e;
     }
+    return MJX_OK;
+}
+
+static int window_copy(struct mjh_tiles *t, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
+    const size_t row = (size_t)cw * 3;
+    int          y;
     t->win_bytes = 2 * row * (size_t)ch;
     t->window = (unsigned char *)malloc(t->win_bytes ? t->win_bytes : 1);
     if(t->window == NULL) return MJX_ERR_MEMORY;
@@ -168,21 +214,45 @@ static int contents_fill(struct mjh_tiles *t, const mj_compileddropon_t *cd, con
     return MJX_OK;
 }
 
+/* upload freshly compiled tiles into `t` and keep a copy of the window (called WITHOUT the lock,
+ * on a private struct).  Tiles that libjpeg prepared stay floats, as mj_compileddropon_t holds them. */
+static int contents_fill(struct mjh_tiles *t, const mj_compileddropon_t *cd, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
+    int c, e;
+    t->ncomp = cd->image_ncomponents;
+    t->bytes = 0;
+    t->i16 = 0;
+    for(c = 0; c < t->ncomp; c++) {
+        const size_t bytes = (size_t)cd->image[c].nblocks * 64 * sizeof(float);
+        t->rows[c] = cd->image[c].height_in_blocks;
+        t->cols[c] = cd->image[c].width_in_blocks;
+        if(cd->image[c].nblocks == 0) continue;
+        if((e = mjx_malloc((void **)&t->dev_tile[c], bytes)) != MJX_OK) return e;
+        if((e = mjx_malloc((void **)&t->dev_alpha[c], bytes)) != MJX_OK) return e;
+        if((e = mjx_memcpy_h2d(t->dev_tile[c], cd->image[c].blocks[0], bytes, NULL)) != MJX_OK) return e;
+        if((e = mjx_memcpy_h2d(t->dev_alpha[c], cd->alpha[c].blocks[0], bytes, NULL)) != MJX_OK) return e;
+        t->bytes += 2 * bytes;
+    }
+    if((e = contents_schedule(t)) != MJX_OK) return e;
+    return window_copy(t, d, cx, cy, cw, ch);
+}
+
 /* MJ_GPU_TILEPREP=0: always prepare tiles with libjpeg on the host */
 static int device_prep_enabled(void) {
-    const char *e = getenv("MJ_GPU_TILEPREP");
-    return !(e != NULL && e[0] == '0');
+#if JPEG_LIB_VERSION >= 90
+    return env_on("MJ_GPU_TILEPREP");
+#else
+    return 0; /* the integer forms of csrc/mjx_fdct_tables.h are IJG 9's transforms: not this library's */
+#endif
 }
 
 /* the tiles of a miss prepared on the device (mjx_tiles_prepare: forward DCT, colour conversion and
  * DCT-scaled chroma of the linked libjpeg as exact integer forms), nothing but the overlay's visible
  * pixels crossing PCIe.  MJX_ERR_BAD_ARG: this overlay / target combination is libjpeg's (gray,
- * CMYK, 4:1:1 ...), the caller takes the host path. */
+ * CMYK, 4:1:1 ...), the caller takes the host path.  want_i16: the tiles stay the int16 coefficients. */
 static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_sampling_t *s, int bx, int by, int cx, int cy, int cw,
-                                int ch) {
-    const size_t   row = (size_t)cw * 3;
+                                int ch, int want_i16) {
     mjx_tileprep_t p;
-    int            c, y, e, w, h;
+    int            c, e, w, h;
     if(cs != JCS_YCbCr && cs != JCS_RGB) return MJX_ERR_BAD_ARG;
     if(d->colorspace != MJ_COLORSPACE_RGB && d->colorspace != MJ_COLORSPACE_YCC) return MJX_ERR_BAD_ARG;
     if(s->h_factor <= 0 || s->v_factor <= 0) return MJX_ERR_BAD_ARG;
@@ -196,10 +266,12 @@ static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COL
     p.source = d->colorspace == MJ_COLORSPACE_RGB ? MJX_PREP_SOURCE_RGB : MJX_PREP_SOURCE_YCC;
     p.target = cs == JCS_RGB ? MJX_PREP_TARGET_RGB : MJX_PREP_TARGET_YCC;
     p.ncomp = 3;
+    p.flags = want_i16 ? MJX_PREP_TILES_I16 : 0;
     w = (cw + bx + s->h_factor - 1) / s->h_factor * s->h_factor; /* whole MCUs (dropon.c:340-350) */
     h = (ch + by + s->v_factor - 1) / s->v_factor * s->v_factor;
     t->ncomp = 3;
     t->bytes = 0;
+    t->i16 = want_i16 != 0;
     for(c = 0; c < 3; c++) {
         const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
         size_t    bytes;
@@ -209,7 +281,7 @@ static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COL
         p.v_samp[c] = vs;
         t->cols[c] = w / (8 * (s->max_h_samp_factor / hs));
         t->rows[c] = h / (8 * (s->max_v_samp_factor / vs));
-        bytes = (size_t)t->rows[c] * (size_t)t->cols[c] * 64 * sizeof(float);
+        bytes = (size_t)t->rows[c] * (size_t)t->cols[c] * 64 * (want_i16 ? sizeof(int16_t) : sizeof(float));
         if((e = mjx_malloc((void **)&t->dev_tile[c], bytes)) != MJX_OK) return e;
         if((e = mjx_malloc((void **)&t->dev_alpha[c], bytes)) != MJX_OK) return e;
         p.tile[c] = t->dev_tile[c];
@@ -217,16 +289,92 @@ static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COL
         t->bytes += 2 * bytes;
     }
     if((e = mjx_tiles_prepare(&p)) != MJX_OK) return e;
-    t->win_bytes = 2 * row * (size_t)ch;
-    t->window = (unsigned char *)malloc(t->win_bytes ? t->win_bytes : 1);
-    if(t->window == NULL) return MJX_ERR_MEMORY;
-    for(y = 0; y < ch; y++) {
-        const size_t off = ((size_t)(y + cy) * (size_t)d->width + (size_t)cx) * 3;
-        memcpy(t->window + (size_t)y * row, d->image + off, row);
-        memcpy(t->window + ((size_t)ch + (size_t)y) * row, d->alpha + off, row);
+    if((e = contents_schedule(t)) != MJX_OK) return e;
+    return window_copy(t, d, cx, cy, cw, ch);
+}
+
+/* ---- is the device preparation THIS libjpeg's arithmetic? ----------------------------------------
+ * Asked once per target format (colour spaces + sampling): a 40x24 overlay with every kind of content
+ * (noise, ramps, flat areas, hard alpha edges) at an odd in-MCU offset is prepared by libjpeg through
+ * mj_compile_dropon and by mjx_tiles_prepare, and the float tiles are compared bit for bit.  A library
+ * whose forward DCT, downsampling or colour conversion differs from the tables (libjpeg-turbo, IJG 6b/8)
+ * cannot pass; the device path is then never used for that format and libjpeg prepares every miss. */
+#define VERIFY_SLOTS 16
+static struct {
+    int params[16];
+    int state; /* 0 free, 1 verified equal, -1 differs */
+} g_verified[VERIFY_SLOTS];
+
+static int device_prep_verified(const mj_dropon_t *like, J_COLOR_SPACE cs, mj_sampling_t *s) {
+    enum { W = 40, H = 24 };
+    unsigned char       img[W * H * 3], alp[W * H * 3];
+    mj_dropon_t         probe;
+    mj_compileddropon_t cd;
+    struct mjh_tiles    dev;
+    int                 params[16], i, c, x, y, state = 0, equal = 1;
+    unsigned            r = 12345u;
+
+    memset(&probe, 0, sizeof(probe));
+    probe.width = W;
+    probe.height = H;
+    probe.colorspace = like->colorspace;
+    probe.blend = 255;
+    probe.image = img;
+    probe.alpha = alp;
+    make_params(params, &probe, cs, s, 3, 5, W, H);
+    pthread_mutex_lock(&g_lock);
+    for(i = 0; i < VERIFY_SLOTS; i++)
+        if(g_verified[i].state != 0 && memcmp(g_verified[i].params, params, sizeof(params)) == 0) state = g_verified[i].state;
+    pthread_mutex_unlock(&g_lock);
+    if(state != 0) return state > 0;
+
+    for(y = 0; y < H; y++) {
+        for(x = 0; x < W; x++) {
+            unsigned char *p = img + (y * W + x) * 3, *a = alp + (y * W + x) * 3;
+            unsigned char  v;
+            r = r * 1664525u + 1013904223u;
+            p[0] = x < 16 ? (unsigned char)(r >> 24) : (unsigned char)(x * 6);
+            p[1] = y < 12 ? (unsigned char)(r >> 16) : (unsigned char)(255 - y * 10);
+            p[2] = (x + y) & 8 ? 250 : (unsigned char)(r >> 8);
+            v = x < 8 ? 0 : (x < 20 ? 255 : (unsigned char)((r >> 12) | (y < 8 ? 0xF0 : 0)));
+            a[0] = a[1] = a[2] = v;
+        }
     }
-    t->bytes += t->win_bytes;
-    return MJX_OK;
+    memset(&dev, 0, sizeof(dev));
+    if(mj_compile_dropon(&cd, &probe, cs, s, 3, 5, 0, 0, W, H) != MJ_OK) return 0;
+    if(contents_fill_device(&dev, &probe, cs, s, 3, 5, 0, 0, W, H, 0) != MJX_OK) equal = 0;
+    for(c = 0; equal && c < 3; c++) {
+        const size_t n = (size_t)cd.image[c].nblocks * 64;
+        float       *got;
+        if(cd.image[c].nblocks != dev.rows[c] * dev.cols[c] || cd.alpha[c].nblocks != cd.image[c].nblocks) {
+            equal = 0;
+            break;
+        }
+        got = (float *)malloc(n * sizeof(float) + 4);
+        if(got == NULL) {
+            equal = 0;
+            break;
+        }
+        if(mjh_download(got, dev.dev_tile[c], n * sizeof(float)) != MJ_OK || memcmp(got, cd.image[c].blocks[0], n * sizeof(float)) != 0) equal = 0;
+        if(equal && (mjh_download(got, dev.dev_alpha[c], n * sizeof(float)) != MJ_OK || memcmp(got, cd.alpha[c].blocks[0], n * sizeof(float)) != 0)) equal = 0;
+        free(got);
+    }
+    mj_free_compileddropon(&cd);
+    contents_free(&dev);
+    if(!equal) {
+        fprintf(stderr, "libmodjpeg (MI355X): tiles prepared on the device differ from the linked libjpeg's for this target format "
+                        "(not IJG libjpeg 9?): libjpeg prepares them from now on\n");
+    }
+    pthread_mutex_lock(&g_lock);
+    for(i = 0; i < VERIFY_SLOTS; i++) {
+        if(g_verified[i].state == 0) {
+            memcpy(g_verified[i].params, params, sizeof(params));
+            g_verified[i].state = equal ? 1 : -1;
+            break;
+        }
+    }
+    pthread_mutex_unlock(&g_lock);
+    return equal; /* table full (16 target formats in one process): verified again next time, still correct */
 }
 
 int mjh_tiles_gpu_prepared; /* statistics: misses whose tiles were prepared on the device */
@@ -246,22 +394,18 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
     make_params(params, d, cs, s, bx, by, cw, ch);
     make_key(key, params, device, d, cx, cy, cw, ch);
 
-    pthread_mutex_lock(&g_lock);
-    for(i = 0; i < CACHE_SLOTS; i++) {
-        if(matches(&g_slots[i], key, params, device, d, cx, cy, cw, ch)) {
-            g_slots[i].users++;
-            g_slots[i].stamp = ++g_clock;
-            *out = &g_slots[i];
-            pthread_mutex_unlock(&g_lock);
-            return MJ_OK;
-        }
+    if((t = lookup(key, params, device, d, cx, cy, cw, ch)) != NULL) {
+        *out = t;
+        return MJ_OK;
     }
-    pthread_mutex_unlock(&g_lock);
 
     /* miss: prepare with no lock held, then publish.  On the device when the combination is one it
-     * reproduces (the usual colour cases); else by libjpeg on the host, uploaded afterwards */
+     * reproduces (the usual colour cases) and the linked libjpeg is the one it reproduces; else by
+     * libjpeg on the host, uploaded afterwards */
     memset(&fresh, 0, sizeof(fresh));
-    rv = device_prep_enabled() ? contents_fill_device(&fresh, d, cs, s, bx, by, cx, cy, cw, ch) : MJX_ERR_BAD_ARG;
+    rv = MJX_ERR_BAD_ARG;
+    if(device_prep_enabled() && (cs == JCS_YCbCr || cs == JCS_RGB) && device_prep_verified(d, cs, s))
+        rv = contents_fill_device(&fresh, d, cs, s, bx, by, cx, cy, cw, ch, env_on("MJ_TILES_I16"));
     if(rv == MJX_OK) {
         __sync_fetch_and_add(&mjh_tiles_gpu_prepared, 1);
         rv = MJ_OK;
@@ -284,12 +428,15 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
     fresh.device = device;
     memcpy(fresh.params, params, sizeof(params));
 
-    pthread_mutex_lock(&g_lock);
-    /* somebody else may have published the same tiles meanwhile */
-    for(i = 0; i < CACHE_SLOTS; i++) {
-        if(matches(&g_slots[i], key, params, device, d, cx, cy, cw, ch)) t = &g_slots[i];
+    /* somebody else may have published the same tiles meanwhile (two threads that miss at the same
+     * moment and both get past this look-up leave two equal entries behind: a wasted slot, nothing worse) */
+    if((t = lookup(key, params, device, d, cx, cy, cw, ch)) != NULL) {
+        contents_free(&fresh);
+        *out = t;
+        return MJ_OK;
     }
-    if(t == NULL) {
+    pthread_mutex_lock(&g_lock);
+    {
         for(i = 0; i < CACHE_SLOTS; i++) total += g_slots[i].valid ? g_slots[i].bytes : 0;
         for(i = 0; i < CACHE_SLOTS; i++) { /* a free slot, else the least recently used idle one */
             if(!g_slots[i].valid) {
@@ -324,7 +471,7 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
     }
     pthread_mutex_unlock(&g_lock);
     for(i = 0; i < nevicted; i++) contents_free(&evicted[i]);
-    contents_free(&fresh); /* lost the race, or every slot busy: nothing is kept */
+    contents_free(&fresh); /* every slot busy: nothing is kept */
     *out = t;              /* NULL: the caller takes the uncached path */
     return MJ_OK;
 }
@@ -343,3 +490,5 @@ void mjh_tiles_component(const struct mjh_tiles *t, int c, int *rows, int *cols,
     *dev_tile = t->dev_tile[c];
     *dev_alpha = t->dev_alpha[c];
 }
+int mjh_tiles_i16(const struct mjh_tiles *t) { return t->i16; }
+const mjx_tile_schedule_t *mjh_tiles_schedule(const struct mjh_tiles *t, int c) { return t->sched[c]; }

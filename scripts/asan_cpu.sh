@@ -6,6 +6,8 @@
 #      option parsing) linked against a stub of include/mjx.h that answers "no device" — the
 #      library's own behaviour on a machine without a GPU — so that every path that does not
 #      need the device runs to completion and every path that does stops at MJ_ERR_MEMORY
+#   3. the same host code on SIMULATED devices (MJX_STUB_DEVICES=2/3): batch CLI sharded over two
+#      devices, tile cache and buffer pools under a 3-device stress, every cross-device hand-over aborts
 # GPU-side sanitizers are not available on the pool, and ASan cannot map its shadow next to the
 # HIP runtime on the GPU box; the GPU paths of the host code run under UBSan there (ubsan_host.sh).
 # (libjpeg/libpng are linked by path: a -L/opt/conda/lib would pick up conda's older libasan)
@@ -21,16 +23,8 @@ gcc $SAN -fPIC -ffp-contract=off -std=c99 -pthread -shared -o $O/libmjx_oracle.s
 MJX_ORACLE_SO=$O/libmjx_oracle.so LD_PRELOAD=$ASAN_RT python -m pytest tests/test_oracle_golden.py -x -q -p no:cacheprovider 2>&1 | tail -2
 
 echo "== 2. host C code against a no-device stub of mjx.h"
-python3 - "$R/include/mjx.h" > $O/mjx_stub.c <<'PY'
-import re, sys
-h = re.sub(r"/\*.*?\*/", "", open(sys.argv[1]).read(), flags=re.S)
-print('#include "mjx.h"')
-for m in re.finditer(r"\n\s*((?:const\s+)?[a-z_0-9]+\s*\*?)\s*(mjx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", h):
-    ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
-    body = "return 0;" if name == "mjx_device_count" else ('return "stub";' if "char" in ret else ("return;" if ret == "void" else ("return 0;" if ret == "int64_t" else "return MJX_ERR_NO_DEVICE;")))
-    print(f"{ret} {name}({args}) {{ {body} }}")
-PY
-gcc $SAN -fPIC -std=gnu99 -I$R/include -shared -o $O/libmjx_hip.so $O/mjx_stub.c -Wno-unused-parameter
+# tests/tools/mjx_stub.c (tracked): with MJX_STUB_DEVICES unset it answers "no device" to everything
+gcc $SAN -fPIC -std=gnu99 -I$R/include -shared -o $O/libmjx_hip.so tests/tools/mjx_stub.c -Wno-unused-parameter
 ( cd $H && gcc $SAN -fPIC -std=gnu99 -Wall -I/opt/conda/include -DWITH_LIBPNG -I/opt/conda/include/libpng16 -shared -Wl,-soname,libmodjpeg.so.1 -o $O/libmodjpeg.so.1 \
     jpegio.c dropon.c tiles.c tilecache.c compose.c effects.c gpuencode.c gpudecode.c shadow.c /opt/conda/lib/libjpeg.so /opt/conda/lib/libpng16.so -Wl,-rpath,/opt/conda/lib -L$O -Wl,-rpath,$O -lmjx_hip -lm -lpthread
   ln -sf libmodjpeg.so.1 $O/libmodjpeg.so
@@ -64,4 +58,6 @@ $O/modjpeg -i /nonexistent.jpg -o $O/out/g.jpg 2>&1 | tail -1 || true
 $O/modjpeg -i $I/dropon.png -o $O/out/h.jpg 2>&1 | tail -1 || true
 printf '%s\n' $I/image.jpg $I/image_dropon.jpg /nonexistent.jpg > $O/list.txt
 $O/modjpeg --batch $O/list.txt --outdir $O/out --jobs 3 --devices 2 -O 2>&1 | tail -1 || true
+echo "== 3. in-process multi-device operation on simulated devices (tests/test_multidevice_stub.py) under ASan+UBSan"
+MJX_STUB_SANITIZE=1 python -m pytest tests/test_multidevice_stub.py -x -q -p no:cacheprovider 2>&1 | tail -2
 echo "asan+ubsan: all clean"

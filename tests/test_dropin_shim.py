@@ -138,12 +138,15 @@ def _read_tiles(path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tiles", ["i16", "f32"])
 @pytest.mark.parametrize("case", ["tl", "br", "crop"])
-def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case):
+def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case, tiles):
     """tiles prepared ON THE DEVICE on a tile-cache miss (mjx_tiles_prepare: libjpeg 9d's forward DCTs
     as exact integer forms, its colour conversion, DCT-scaled chroma) == the tiles the reference's
     mj_compile_dropon prepared through libjpeg, as float bit patterns: image tiles, alpha DC offset
-    and scaling, padding, in-MCU offsets"""
+    and scaling, padding, in-MCU offsets.  The cache keeps them as int16 coefficients by default
+    (converted with the reference's expressions by the probe, as the kernel does) or, with
+    MJ_TILES_I16=0, as the floats themselves."""
     g = np.load(os.path.join(golden_dir, "compose_kat.npz"))
     w, h, cs, blend = [int(v) for v in g[f"{case}_dropon_meta"]]
     img = g[f"{case}_dropon_image"].reshape(h, w, 3)
@@ -154,7 +157,8 @@ def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case
     bx, by, cx, cy, cw, ch = _placement(g, case)
     out = tmp_path / "tiles.bin"
     res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "tilesgpu", os.path.join(IMAGES, "image.jpg"), str(raw), str(w), str(h), "2", "255",
-                          str(bx), str(by), str(cx), str(cy), str(cw), str(ch), str(out)], capture_output=True, text=True)
+                          str(bx), str(by), str(cx), str(cy), str(cw), str(ch), str(out)], capture_output=True, text=True,
+                         env=dict(os.environ, MJ_TILES_I16="1" if tiles == "i16" else "0"))
     assert res.returncode == 0 and res.stdout.strip() == "gpu", (res.returncode, res.stdout, res.stderr[-300:])
     for c, (hib, wib, tile, alpha) in enumerate(_read_tiles(out)):
         rows, cols = int(g[f"{case}_rect_c{c}"][2]), int(g[f"{case}_rect_c{c}"][3])
@@ -492,3 +496,22 @@ def test_files_from_another_encoder(shim, tmp_path):
     img.save(prog, quality=80, progressive=True)
     res = subprocess.run([probe, "decodecmp", str(prog)], capture_output=True, text=True, env=env)
     assert res.stdout.strip() == "same fallback", res.stdout
+
+
+@pytest.mark.gpu
+def test_mj_compose_takes_the_pattern_schedule_and_int16_tiles(shim):
+    """the public API runs the kernel paths the batch plans do: an mj_compose of
+    the reference's own logo overlay (tests/golden/images/dropon.png: text, i.e. blocks with very
+    different zero patterns) reaches the compose kernel with the tiles as int16 coefficients and a
+    schedule that picks the blocks of an octet by pattern; MJ_TILES_I16=0 / MJ_TILE_SCHEDULE=0 switch
+    each off.  (That the files stay byte-identical to the reference's is tests/test_cli.py and
+    test_example_program_matches_reference, which run through this default.)"""
+    probe = os.path.join(HOST, "mjhost_probe")
+    args = [probe, "composepath", os.path.join(IMAGES, "image.jpg"), os.path.join(IMAGES, "dropon.png"), "3"]
+    rects, i16, sched, gpu = [int(v) for v in subprocess.check_output(args, text=True).split()]
+    assert rects == 9 and i16 == 9 and gpu >= 1, (rects, i16, sched, gpu)
+    assert sched >= 3, "the luma rectangle of a text overlay has blocks of very different patterns"
+    rects, i16, sched, gpu = [int(v) for v in subprocess.check_output(args, text=True, env=dict(os.environ, MJ_TILES_I16="0")).split()]
+    assert rects == 9 and i16 == 0 and sched >= 3
+    rects, i16, sched, gpu = [int(v) for v in subprocess.check_output(args, text=True, env=dict(os.environ, MJ_TILE_SCHEDULE="0")).split()]
+    assert rects == 9 and i16 == 9 and sched == 0

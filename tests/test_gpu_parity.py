@@ -335,7 +335,7 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
     density from 0 to 64 non-zero weights (signed zeros, denormals and NaN weights included), ragged
     sizes, several jobs per plan sharing quant tables: grouped plan == plain plan == oracle"""
     import torch
-    from libmodjpeg_amd._lib import MJX_PLAN_GROUP_BY_DENSITY, RectJob, check, lib
+    from libmodjpeg_amd._lib import MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, PlanStats, RectJob, check, lib
     rng = np.random.default_rng(seed)
     shapes = [(40, 50, 3, 5, 13, 21), (20, 25, 0, 0, 20, 25), (9, 33, 2, 30, 7, 3), (64, 16, 10, 4, 37, 9), (8, 8, 1, 1, 1, 1)]  # prow, bpr, row0, col0, rows, cols
     quants = np.stack([rng.integers(1, 256, 64), rng.integers(1, 65536, 64)]).astype(np.uint16)
@@ -354,14 +354,22 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
         alpha = np.ascontiguousarray(alpha, np.float32)
         host.append((coef, tile, alpha))
     results = []
-    for flags in (MJX_PLAN_GROUP_BY_DENSITY, 0):
+    # the zero pattern the device scan must find: a weight counts when `w != 0` (convolve.c:32): -0.0 does not, denormals and NaN do
+    terms = sum(int(np.count_nonzero(a != 0)) for _, _, a in host)
+    for flags in (MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, 0):
         dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
         for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
             jobs[j] = RectJob(dev[j][0].data_ptr(), dev[j][1].data_ptr(), dev[j][2].data_ptr(), bpr, prow, row0, col0, rows, cols, j % 2)
         plan = ctypes.c_void_p()
         check(lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 2, flags), "plan")
+        st = PlanStats()
+        check(lib().mjx_compose_plan_stats(plan, ctypes.byref(st)), "stats")
+        assert st.blocks == sum(s[4] * s[5] for s in shapes)
         if flags:
             assert lib().mjx_compose_plan_gather_octets(plan) > 0
+            assert st.block_terms == terms, "zero patterns of the alpha blocks"
+            assert st.union_terms >= (st.block_terms + 7) // 8
+            assert (st.zero_alpha_octets > 0) == bool(flags & MJX_PLAN_ALPHA_IS_FINAL)
         check(lib().mjx_compose_run(plan, None), "run")
         torch.cuda.synchronize()
         lib().mjx_compose_plan_destroy(plan)
@@ -369,8 +377,9 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
     for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
         want = host[j][0].reshape(-1).copy()
         O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 2]), host[j][1].reshape(-1), host[j][2].reshape(-1))
-        assert np.array_equal(results[1][j].reshape(-1), want), ("plain plan", j)
-        assert np.array_equal(results[0][j].reshape(-1), want), ("grouped plan", j)
+        assert np.array_equal(results[2][j].reshape(-1), want), ("plain plan", j)
+        assert np.array_equal(results[1][j].reshape(-1), want), ("grouped plan", j)
+        assert np.array_equal(results[0][j].reshape(-1), want), ("grouped plan, zero-alpha blocks without their tiles", j)
 
 
 @pytest.mark.parametrize("seed", [2027] + _EXTRA_SEEDS)
@@ -380,7 +389,7 @@ def test_int16_tile_plans_vs_oracle_on_full_range_values(mj, seed):
     tile = (float)coef and weight = (float)((double)(float)coef * K) equal the host's, so the planes
     equal the oracle's fed with the converted float tiles"""
     import torch
-    from libmodjpeg_amd._lib import MJX_JOB_TILES_I16, MJX_PLAN_GROUP_BY_DENSITY, RectJob, check, lib
+    from libmodjpeg_amd._lib import MJX_JOB_TILES_I16, MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, RectJob, check, lib
     rng = np.random.default_rng(seed)
     c0, c1 = 0.3535534, 0.5
     kk = np.array([(c0 if j // 8 == 0 else c1) * (c0 if j % 8 == 0 else c1) / 1020.0 for j in range(64)], np.float64)
@@ -394,7 +403,7 @@ def test_int16_tile_plans_vs_oracle_on_full_range_values(mj, seed):
         alpha = rng.integers(-32768, 32768, (n, 64)).astype(np.int16)
         alpha = np.where(rng.random((n, 64)) < rng.choice([0.0, 0.05, 0.3, 1.0], n)[:, None], alpha, np.int16(0)).astype(np.int16)
         host.append((coef, np.ascontiguousarray(tile), np.ascontiguousarray(alpha)))
-    for flags in (0, MJX_PLAN_GROUP_BY_DENSITY):
+    for flags in (0, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL):
         dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
         for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
             jobs[j] = RectJob(dev[j][0].data_ptr(), dev[j][1].data_ptr(), dev[j][2].data_ptr(), bpr, prow, row0, col0, rows, cols, j % 2, MJX_JOB_TILES_I16)
@@ -413,3 +422,76 @@ def test_int16_tile_plans_vs_oracle_on_full_range_values(mj, seed):
     jobs[0].flags = 0
     plan = ctypes.c_void_p()
     assert lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 2, 0) == mj._lib.MJX_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("i16", [False, True])
+def test_tile_schedules_travel_with_resident_tiles_through_the_host_buffer_call(mj, i16):
+    """What the drop-in's tile cache does (reference compose.c:155-177: one overlay, many images):
+    tiles stay on the device, mjx_tile_schedule_create reads the zero patterns of their alpha blocks
+    once, and every mjx_compose_host call hands tiles + schedule over.  Masks with structure (rows of
+    weights, columns of weights, dense, a single weight, none at all), three rectangles per call (narrow,
+    wide, ragged), two different images per schedule, quantisers that make coef * q wrap in the
+    blocks without weights: == oracle, and == the same call without the schedules."""
+    from libmodjpeg_amd._lib import (MJX_JOB_TILES_I16, MJX_RECT_TILES_I16, MJX_RECT_TILES_ON_DEVICE, HostRect, PlanStats, check, lib)
+    vp = ctypes.c_void_p
+    rng = np.random.default_rng(5 + i16)
+    c0, c1 = 0.3535534, 0.5
+    kk = np.array([(c0 if j // 8 == 0 else c1) * (c0 if j % 8 == 0 else c1) / 1020.0 for j in range(64)], np.float64)
+    wib, hib = 60, 40
+    shapes = [(3, 2, 19, 17), (1, 10, 30, 45), (33, 7, 3, 5)]  # row0, col0, rows, cols
+    quants = [rng.integers(1, 256, 64).astype(np.uint16), rng.integers(1, 65536, 64).astype(np.uint16), rng.integers(1, 40, 64).astype(np.uint16)]
+    tiles, scheds, dev = [], [], []
+    for (row0, col0, rows, cols) in shapes:
+        n = rows * cols
+        kind = rng.integers(0, 6, n)  # 0 none, 1 DC only, 2 one column, 3 one row, 4 low-frequency triangle, 5 dense
+        mask = np.zeros((n, 8, 8), bool)
+        mask[kind == 1, 0, 0] = True
+        mask[kind == 2, :, 0] = True
+        mask[kind == 3, 0, :] = True
+        kk8, ll8 = np.mgrid[0:8, 0:8]
+        mask[kind == 4] = (kk8 + ll8) <= 3
+        mask[kind == 5] = True
+        mask = mask.reshape(n, 64)
+        if i16:
+            tile = rng.integers(-2000, 2000, (n, 64)).astype(np.int16)
+            alpha = np.where(mask, rng.integers(1, 2040, (n, 64)), 0).astype(np.int16)
+            tf = tile.astype(np.float32)
+            af = (alpha.astype(np.float32).astype(np.float64) * kk).astype(np.float32)
+        else:
+            tile = np.round(rng.standard_normal((n, 64)) * 200).astype(np.float32)
+            alpha = np.where(mask, (rng.random((n, 64)) * 0.2 + 0.001), 0).astype(np.float32)
+            tf, af = tile, alpha
+        d_t, d_a = _t(tile), _t(alpha)
+        sc = vp()
+        check(lib().mjx_tile_schedule_create(ctypes.byref(sc), vp(d_a.data_ptr()), rows, cols, MJX_JOB_TILES_I16 if i16 else 0), "mjx_tile_schedule_create")
+        st = PlanStats()
+        check(lib().mjx_tile_schedule_stats(sc, ctypes.byref(st)), "mjx_tile_schedule_stats")
+        assert st.blocks == n and st.block_terms == int(mask.sum())
+        if n >= 64:
+            assert lib().mjx_tile_schedule_gather_octets(sc) > 0 and st.zero_alpha_octets > 0
+            assert st.union_terms < 2 * st.block_terms / 8 + 64 * 8, "octets of like blocks: the unions stay close to the blocks' own patterns"
+        tiles.append((tf.reshape(-1), af.reshape(-1)))
+        scheds.append(sc)
+        dev.append((d_t, d_a))
+    flag = MJX_RECT_TILES_ON_DEVICE | (MJX_RECT_TILES_I16 if i16 else 0)
+    for image in (1, 2):
+        for use_sched in (True, False):
+            rects = (HostRect * 3)()
+            planes, want = [], []
+            for c, (row0, col0, rows, cols) in enumerate(shapes):
+                plane = rng.integers(-1024, 1024, wib * hib * 64).astype(np.int16)
+                ref = plane.copy()
+                O.compose_rect(ref, wib, row0, col0, rows, cols, quants[c], tiles[c][0], tiles[c][1])
+                rects[c] = HostRect(plane.ctypes.data + row0 * wib * 128, dev[c][0].data_ptr(), dev[c][1].data_ptr(), quants[c].ctypes.data, wib, col0, rows, cols,
+                                    flag, 0, scheds[c] if use_sched else None)
+                planes.append(plane)
+                want.append(ref)
+            check(lib().mjx_compose_host(rects, 3), "mjx_compose_host")
+            for c in range(3):
+                assert np.array_equal(planes[c], want[c]), (image, use_sched, c)
+    # a schedule belongs to the tiles it was made from
+    bad = (HostRect * 1)()
+    bad[0] = HostRect(planes[0].ctypes.data, dev[0][0].data_ptr(), dev[0][1].data_ptr(), quants[0].ctypes.data, wib, 0, shapes[0][2] + 1, shapes[0][3], flag, 0, scheds[0])
+    assert lib().mjx_compose_host(bad, 1) == mj._lib.MJX_ERR_BAD_ARG
+    for sc in scheds:
+        lib().mjx_tile_schedule_destroy(sc)
