@@ -286,7 +286,17 @@ typedef struct mjx_huff_component {
     int32_t        height_in_blocks;
     int32_t        h_samp, v_samp;  /* blocks per MCU in x and y (1,1 for a single-component scan) */
     int32_t        dc_tbl, ac_tbl;  /* indices into dc[] / ac[] */
+    /* DC effects still pending on this plane (an image that stays on the device between read and write:
+     * mj_effect_luminance / mj_effect_tint there only note their value): the encoder applies them, in
+     * order, to the DC of every real block as it reads it - DC' = fx(value[n-1], .. fx(value[0], DC)),
+     * fx = the arithmetic of mjx_effect_dc with quantiser dc_fx_q0 (reference effect.c:207-217) - so the
+     * separate pass over the plane (one 128-byte line read and written per 2-byte DC) never runs.  The
+     * plane itself is not changed.  dc_fx_n = 0: none. */
+    int32_t        dc_fx_n;         /* 0 .. MJX_HUFF_MAX_DC_FX */
+    int32_t        dc_fx_value[4];
+    uint16_t       dc_fx_q0, dc_fx_reserved;
 } mjx_huff_component_t;
+#define MJX_HUFF_MAX_DC_FX 4
 
 typedef struct mjx_huff_scan {
     int32_t                 ncomp;          /* 1..4 */

@@ -18,6 +18,7 @@
 // to shrink the D2H transfer from 6.3 MB of coefficients to the compressed bytes.  Eight small
 // launches per image is a latency chain, so concurrent callers are combined into one launch set
 // (mjx_combiner.hpp; blockIdx.y = image).
+#include "mjx_block_math.hpp"
 #include "mjx_combiner.hpp"
 #include "mjx_internal.hpp"
 #include "mjx_scan.hpp"
@@ -32,7 +33,21 @@ constexpr int kMaxSlots = 10; // C_MAX_BLOCKS_IN_MCU
 struct HuffComp {
     const int16_t *plane;
     int            bpr, wib, hib, hs, vs, dc_tbl, ac_tbl, first_slot, nslots;
+    int            fx_n, fx_value[MJX_HUFF_MAX_DC_FX], fx_q0; // DC effects pending on the plane (mjx_huff_component_t.dc_fx_*)
+    float          fx_rq0;
 };
+
+// the DC as it would stand in the plane had the pending effects been run over it (mjx_effects.hip
+// effect_dc_kernel, reference effect.c:207-217: c *= q0; c += value; clamp to +-2047; c /= q0, every step on a short)
+__device__ __forceinline__ int dc_with_pending(const HuffComp &c, int dc) {
+    for(int i = 0; i < c.fx_n; ++i) {
+        int d = dequant(dc, c.fx_q0);
+        d = wrap16((int)((unsigned)d + (unsigned)c.fx_value[i]));
+        d = d > 2047 ? 2047 : (d < -2047 ? -2047 : d);
+        dc = (int)(int16_t)requant(d, c.fx_rq0);
+    }
+    return dc;
+}
 
 struct HuffScan {
     int      ncomp, mcus_x, mcus_y, bpm, max_coef_bits;
@@ -100,7 +115,7 @@ __device__ __forceinline__ int effective_dc(const HuffScan &S, long long t) {
         const Slot sl = decode_slot(S, t);
         if(sl.real) {
             const HuffComp &c = S.c[sl.comp];
-            return (int)c.plane[((size_t)sl.by * (size_t)c.bpr + (size_t)sl.bx) * 64];
+            return dc_with_pending(c, (int)c.plane[((size_t)sl.by * (size_t)c.bpr + (size_t)sl.bx) * 64]);
         }
         t = prev_in_component(S, t);
     }
@@ -180,6 +195,7 @@ __device__ __forceinline__ void stage_block(const HuffScan &S, const Slot &sl, s
     uint4          *d = reinterpret_cast<uint4 *>(dst);
 #pragma unroll
     for(int i = 0; i < 8; ++i) d[i] = src[i];
+    if(c.fx_n > 0) dst[0] = (short)dc_with_pending(c, (int)dst[0]);
 }
 
 constexpr int kHuffThreads = 128; // 128 x 128 B of LDS staging
@@ -497,6 +513,11 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
         d.vs = h.v_samp;
         d.dc_tbl = h.dc_tbl;
         d.ac_tbl = h.ac_tbl;
+        if(h.dc_fx_n < 0 || h.dc_fx_n > MJX_HUFF_MAX_DC_FX || (h.dc_fx_n > 0 && h.dc_fx_q0 == 0)) return MJX_ERR_BAD_ARG;
+        d.fx_n = h.dc_fx_n;
+        for(int i = 0; i < MJX_HUFF_MAX_DC_FX; ++i) d.fx_value[i] = i < h.dc_fx_n ? h.dc_fx_value[i] : 0;
+        d.fx_q0 = h.dc_fx_q0;
+        d.fx_rq0 = h.dc_fx_n > 0 ? rq_of(h.dc_fx_q0) : 0.0f;
         d.first_slot = S.bpm;
         d.nslots = h.h_samp * h.v_samp;
         if(S.bpm + d.nslots > kMaxSlots) return MJX_ERR_BAD_ARG;

@@ -44,7 +44,8 @@ class HuffTable(ctypes.Structure):
 class HuffComponent(ctypes.Structure):
     """struct mjx_huff_component"""
     _fields_ = [("plane", ctypes.c_void_p), ("blocks_per_row", ctypes.c_int32), ("width_in_blocks", ctypes.c_int32), ("height_in_blocks", ctypes.c_int32),
-                ("h_samp", ctypes.c_int32), ("v_samp", ctypes.c_int32), ("dc_tbl", ctypes.c_int32), ("ac_tbl", ctypes.c_int32)]
+                ("h_samp", ctypes.c_int32), ("v_samp", ctypes.c_int32), ("dc_tbl", ctypes.c_int32), ("ac_tbl", ctypes.c_int32),
+                ("dc_fx_n", ctypes.c_int32), ("dc_fx_value", ctypes.c_int32 * 4), ("dc_fx_q0", ctypes.c_uint16), ("dc_fx_reserved", ctypes.c_uint16)]
 
 
 class HuffSpec(ctypes.Structure):

@@ -130,6 +130,7 @@ static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int til
     mjh_shadow_t   *shadow = mjh_shadow_of(m);
 
     if(n > MAXC || n > m->cinfo.num_components) return MJ_ERR_DROPON_DIMENSIONS;
+    if(shadow != NULL && (rv = mjh_shadow_settle(m, -1)) != MJ_OK) return rv; /* the blend reads the DCs: pending effects first, in argv order */
     memset(rect, 0, sizeof(rect));
     for(c = 0; c < n && rv == MJ_OK; c++) {
         jpeg_component_info *ci = &m->cinfo.comp_info[c];

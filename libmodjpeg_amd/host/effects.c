@@ -13,6 +13,11 @@ typedef int (*plane_op_t)(int16_t *plane, int bpr, int rows, int cols, const jpe
 static int op_dc(int16_t *plane, int bpr, int rows, int cols, const jpeg_component_info *ci, int value);
 static int op_zero(int16_t *plane, int bpr, int rows, int cols, const jpeg_component_info *ci, int keep_dc);
 
+static int fold_effects(void) {
+    const char *e = getenv("MJ_FOLD_EFFECTS");
+    return !(e != NULL && e[0] == '0');
+}
+
 static int on_component(mj_jpeg_t *m, int c, plane_op_t op, int arg) {
     jpeg_component_info *ci = &m->cinfo.comp_info[c];
     const int            rows = (int)ci->height_in_blocks, cols = (int)ci->width_in_blocks;
@@ -20,10 +25,29 @@ static int on_component(mj_jpeg_t *m, int c, plane_op_t op, int arg) {
     int                  rv;
 
     if(rows == 0 || cols == 0) return MJ_OK;
-    if(mjh_shadow_of(m) != NULL) { /* device-resident image: one launch on the plane where it is */
+    if(mjh_shadow_of(m) != NULL) { /* device-resident image */
         mjh_shadow_t *s = mjh_shadow_of(m);
-        if(op == op_zero) return mjh_from_mjx(mjx_effect_zero_device(s->plane[c], s->pitch[c], rows, cols, arg));
+        if(op == op_zero) {
+            /* pixelate (keep_dc) leaves the DCs alone and the DC effects leave everything else alone: the
+             * pending ones may stay pending; grayscale zeroes the DCs as well, so what was pending on
+             * them is moot */
+            if(!arg) s->fx_n[c] = 0;
+            return mjh_from_mjx(mjx_effect_zero_device(s->plane[c], s->pitch[c], rows, cols, arg));
+        }
         if(ci->quant_table == NULL || ci->quant_table->quantval[0] == 0) return MJ_ERR_NULL_DATA;
+        /* A DC effect touches 2 bytes of every 128-byte block: as a pass of its own it moves a whole line
+         * in and out per DC (profiles/r02: 64 + 32 bytes per DC for 4 algorithmic ones).  The image is
+         * going to be read block by block by the entropy encoder anyway, so the value is only NOTED here
+         * and applied there (mjx_huff_component_t.dc_fx_*); whatever else looks at the plane before that
+         * runs the pending effects first (mjh_shadow_settle).  MJ_FOLD_EFFECTS=0: one launch now. */
+        if(fold_effects()) {
+            if(s->fx_n[c] == MJX_HUFF_MAX_DC_FX) {
+                rv = mjh_shadow_settle(m, c);
+                if(rv != MJ_OK) return rv;
+            }
+            s->fx_value[c][s->fx_n[c]++] = arg;
+            return MJ_OK;
+        }
         return mjh_from_mjx(mjx_effect_dc_device(s->plane[c], s->pitch[c], rows, cols, ci->quant_table->quantval[0], arg));
     }
     {

@@ -210,6 +210,13 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len, int
         sc.comp[i].v_samp = ns == 1 ? 1 : ci->v_samp_factor;
         sc.comp[i].dc_tbl = td[i];
         sc.comp[i].ac_tbl = ta[i];
+        if(shadow != NULL && shadow->fx_n[c] > 0) { /* DC effects that were only noted: applied as the encoder reads the blocks */
+            int k;
+            if(ci->quant_table == NULL || ci->quant_table->quantval[0] == 0) BAIL("pending DC effect without a quantiser");
+            sc.comp[i].dc_fx_n = shadow->fx_n[c];
+            for(k = 0; k < shadow->fx_n[c]; k++) sc.comp[i].dc_fx_value[k] = shadow->fx_value[c][k];
+            sc.comp[i].dc_fx_q0 = ci->quant_table->quantval[0];
+        }
     }
     for(i = 0; i < 4; i++) {
         sc.dc[i] = have_dc[i] ? &dc[i] : NULL;

@@ -79,6 +79,10 @@ typedef struct mjh_shadow {
     void    *buffer;
     size_t   bytes;
     int      device; /* HIP ordinal the planes live on */
+    /* DC effects noted but not yet run over plane c (effects.c): the GPU encoder applies them while it reads
+     * the blocks (mjx_huff_component_t.dc_fx_*); anything else that looks at the plane first runs them
+     * (mjh_shadow_settle) */
+    int      fx_n[4], fx_value[4][4];
 } mjh_shadow_t;
 void          mjh_set_device_resident(int on);
 int           mjh_device_count(void);
@@ -89,6 +93,7 @@ mjh_shadow_t *mjh_shadow_of(const mj_jpeg_t *m); /* NULL: an ordinary host image
 mjh_shadow_t *mjh_shadow_create(mj_jpeg_t *m);
 void          mjh_shadow_drop(mj_jpeg_t *m);
 int           mjh_host_sync(mj_jpeg_t *m);
+int           mjh_shadow_settle(mj_jpeg_t *m, int c); /* run the pending DC effects of component c (c < 0: all) over the device planes; MJ_OK or an error */
 
 /* prepared tiles resident on the device, cached across mj_compose calls (tilecache.c).
  * acquire() sets *out = NULL (and returns MJ_OK) when the cache is disabled or full of busy

@@ -145,11 +145,32 @@ void mjh_shadow_drop(mj_jpeg_t *m) {
     free(s);
 }
 
+/* the DC effects that were only noted (effects.c) run over the plane now, in the order they were asked for:
+ * whoever is about to look at the coefficients other than the GPU encoder calls this first */
+int mjh_shadow_settle(mj_jpeg_t *m, int only) {
+    mjh_shadow_t *s = mjh_shadow_of(m);
+    int           c, i;
+    if(s == NULL) return MJ_OK;
+    for(c = 0; c < s->ncomp; c++) {
+        jpeg_component_info *ci = &m->cinfo.comp_info[c];
+        if(only >= 0 && c != only) continue;
+        for(i = 0; i < s->fx_n[c]; i++) {
+            int rv;
+            if(ci->quant_table == NULL || ci->quant_table->quantval[0] == 0) return MJ_ERR_NULL_DATA;
+            rv = mjh_from_mjx(mjx_effect_dc_device(s->plane[c], s->pitch[c], (int)ci->height_in_blocks, (int)ci->width_in_blocks, ci->quant_table->quantval[0], s->fx_value[c][i]));
+            if(rv != MJ_OK) return rv;
+        }
+        s->fx_n[c] = 0;
+    }
+    return MJ_OK;
+}
+
 /* fill libjpeg's arrays from the shadow and let the image go on as a host image */
 int mjh_host_sync(mj_jpeg_t *m) {
     mjh_shadow_t *s = mjh_shadow_of(m);
     int           c, rv = MJ_OK;
     if(s == NULL) return MJ_OK;
+    rv = mjh_shadow_settle(m, -1);
     m->cinfo.client_data = NULL; /* the array accessors below must not come back here */
     for(c = 0; c < s->ncomp && rv == MJ_OK; c++) {
         const size_t bytes = (size_t)s->pitch[c] * (size_t)s->rows[c] * sizeof(JBLOCK);

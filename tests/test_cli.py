@@ -85,6 +85,11 @@ BATCH_SCRIPTS = [
     ["-p", "cc", "-d", JPG, "-O"],                                # optimised output: statistics and tables for the image, still on the device
     ["-y", "10", "-P"],                                           # progressive output
     ["-p", "cc", "-m", "5,-3", "-d", os.path.join(IMAGES, "image_dropon.jpg"), "-d", PNG],  # a 256x256 dropon (thousands of blocks per launch), then a small one
+    # DC effects on a device-resident image are only noted and applied by the encoder as it reads the blocks (effects.c):
+    ["-y", "10", "-y", "-20", "-y", "35", "-y", "5", "-y", "-60", "-b", "7", "-r", "-9"],   # more pending values than the encoder takes: the oldest are run first
+    ["-y", "30", "-b", "-12", "-p", "tl", "-d", PNG, "-y", "-10", "-r", "4"],               # pending, then a compose that has to see them, then pending again
+    ["-b", "20", "-g", "-r", "5", "-x", "-y", "2000", "-y", "-3000"],                       # grayscale drops what was pending on chroma; pixelate keeps; clamps at +-2047
+    ["-y", "25", "-b", "3", "-P"],                                                          # libjpeg has to write: the pending effects run before the download
 ]
 
 

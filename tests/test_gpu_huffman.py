@@ -24,19 +24,7 @@ ZIGZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33
           29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
 
 
-class HuffTable(ctypes.Structure):
-    _fields_ = [("code", ctypes.c_uint32 * 256), ("size", ctypes.c_uint8 * 256)]
-
-
-class HuffComponent(ctypes.Structure):
-    _fields_ = [("plane", ctypes.c_void_p), ("blocks_per_row", ctypes.c_int32), ("width_in_blocks", ctypes.c_int32), ("height_in_blocks", ctypes.c_int32),
-                ("h_samp", ctypes.c_int32), ("v_samp", ctypes.c_int32), ("dc_tbl", ctypes.c_int32), ("ac_tbl", ctypes.c_int32)]
-
-
-class HuffScan(ctypes.Structure):
-    _fields_ = [("ncomp", ctypes.c_int32), ("mcus_x", ctypes.c_int32), ("mcus_y", ctypes.c_int32), ("comp", HuffComponent * 4),
-                ("dc", ctypes.POINTER(HuffTable) * 4), ("ac", ctypes.POINTER(HuffTable) * 4), ("max_coef_bits", ctypes.c_int32), ("flags", ctypes.c_int32),
-                ("optimal_dc", ctypes.c_void_p * 4), ("optimal_ac", ctypes.c_void_p * 4)]
+from libmodjpeg_amd.entropy import HuffComponent, HuffScan, HuffTable  # the ctypes mirrors of include/mjx.h (layout pinned by tests/test_abi.py)
 
 
 def derive(bits, vals):
@@ -164,3 +152,60 @@ def test_coefficient_outside_the_alphabet_is_an_error():
     p[1, 1, 5] = 1023
     rc, got = gpu_encode([p], geom, 2, 2, dc, ac)
     assert rc == 0 and got == py_encode([p], geom, 2, 2, dc, ac)
+
+
+def test_pending_dc_effects_are_applied_while_the_encoder_reads():
+    """mjx_huff_component_t.dc_fx_*: a device-resident image whose luminance / tint calls were only noted
+    (host/effects.c) is written with them applied by the encoder, block by block; the bytes must equal
+    those of a plane the effects were run over (oracle orc_effect_dc, reference effect.c:207-217) -
+    clamps and int16 wraps included - for real blocks, dummy blocks (which repeat the PREVIOUS block's
+    effective DC) and pitch padding; the plane handed in stays untouched"""
+    from tests import oracle_lib as O
+    rng = np.random.default_rng(77)
+    wy, hy = 7, 5
+    mcus_x, mcus_y = -(-wy // 2), -(-hy // 2)
+    geom = [(wy, hy, 2, 2), (mcus_x, mcus_y, 1, 1), (mcus_x, mcus_y, 1, 1)]
+    q0 = [3, 17, 255]
+    pending = [[40, -2500, 7, 9000], [-30], []]  # luma: four values incl. a clamp and an int16 wrap; Cb: one; Cr: none
+    planes, applied = [], []
+    for (wib, hib, hs, vs), q, values in zip(geom, q0, pending):
+        bpr = -(-wib // hs) * hs + 2
+        p = np.zeros((hib, bpr, 64), np.int16)
+        p[:, :, 0] = rng.integers(-1023, 1024, (hib, bpr))
+        p[:, :, 1:] = np.where(rng.random((hib, bpr, 63)) < 0.2, rng.integers(-300, 300, (hib, bpr, 63)), 0)
+        planes.append(p)
+        e = p.copy().reshape(-1)
+        for v in values:
+            O.effect_dc(e, bpr, hib, wib, q, v)
+        applied.append(e.reshape(p.shape))
+    dc, ac = derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS)
+
+    def encode(ps, with_pending):
+        import torch  # noqa: F401
+        from libmodjpeg_amd._lib import lib
+        sc = HuffScan()
+        sc.ncomp, sc.mcus_x, sc.mcus_y, sc.max_coef_bits = 3, mcus_x, mcus_y, 11  # a shifted DC may need the 11-bit category
+        keep = []
+        for c, ((wib, hib, hs, vs), p) in enumerate(zip(geom, ps)):
+            p = np.ascontiguousarray(p)
+            keep.append(p)
+            sc.comp[c] = HuffComponent(p.ctypes.data, p.shape[1], wib, hib, hs, vs, 0, 0)
+            if with_pending and pending[c]:
+                sc.comp[c].dc_fx_n = len(pending[c])
+                for i, v in enumerate(pending[c]):
+                    sc.comp[c].dc_fx_value[i] = v
+                sc.comp[c].dc_fx_q0 = q0[c]
+        sc.dc[0], sc.ac[0] = ctypes.pointer(dc), ctypes.pointer(ac)
+        out, n = ctypes.c_void_p(), ctypes.c_size_t()
+        rc = lib().mjx_huff_encode_host(ctypes.byref(sc), ctypes.byref(out), ctypes.byref(n))
+        assert rc == 0, rc
+        data = ctypes.string_at(out, n.value)
+        ctypes.CDLL(None).free(out)
+        return data
+
+    before = [p.copy() for p in planes]
+    got = encode(planes, True)
+    assert all(np.array_equal(a, b) for a, b in zip(planes, before)), "the encoder changed the plane it was handed"
+    assert got == encode(applied, False)
+    assert got == py_encode(applied, geom, mcus_x, mcus_y, dc, ac)
+    assert got != encode(planes, False)
