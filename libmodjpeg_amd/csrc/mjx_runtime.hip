@@ -17,10 +17,14 @@
 
 namespace mjx {
 
-// MJX_INJECT_FAILURE="<substring>[:N]" (tests only): the N-th (default first) successful HIP call whose
+// Compiled only with -DMJX_FAULT_INJECTION (the variant library tests/test_gpu_parity.py builds for itself).
+// MJX_INJECT_FAILURE="<substring>[:N]": the N-th (default first) successful HIP call whose
 // description contains the substring is reported as failed, once.  This is how the early-return
 // paths of the host-buffer entry points are exercised (work queued on the arena's stream, arena
 // handed back): tests/test_gpu_parity.py::test_host_buffer_call_survives_an_injected_failure.
+#ifndef MJX_FAULT_INJECTION
+static bool injected_failure(const char *) { return false; } // production builds carry no injector (build with -DMJX_FAULT_INJECTION for the test)
+#else
 static bool injected_failure(const char *what) {
     static const char *pattern = getenv("MJX_INJECT_FAILURE");
     static std::atomic<int> countdown{[] {
@@ -35,6 +39,7 @@ static bool injected_failure(const char *what) {
     for(const char *w = what; *w && !match; ++w) match = strncmp(w, pattern, len) == 0;
     return match && countdown.fetch_sub(1) == 1;
 }
+#endif
 
 int check_hip(hipError_t e, const char *what, int err_code) {
     if(e == hipSuccess && injected_failure(what)) {

@@ -10,8 +10,8 @@ SAN="-O1 -g -fsanitize=undefined -fno-sanitize-recover=undefined -fno-omit-frame
 ( cd $H && gcc $SAN -fPIC -std=gnu99 -I/opt/conda/include -DWITH_LIBPNG -I/opt/conda/include/libpng16 -shared -Wl,-soname,libmodjpeg.so.1 -o $O/libmodjpeg.so.1 \
     jpegio.c dropon.c tiles.c tilecache.c compose.c effects.c gpuencode.c gpudecode.c shadow.c -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -ljpeg -L$R/libmodjpeg_amd -Wl,-rpath,$R/libmodjpeg_amd -lmjx_hip -lm -lpthread -lpng16
   ln -sf libmodjpeg.so.1 $O/libmodjpeg.so
-  for p in probe modjpeg bench_dropin; do
-    gcc $SAN -std=gnu99 -I$R/include -I/opt/conda/include -o $O/$p $p.c -L$O -Wl,-rpath,$O -Wl,--allow-shlib-undefined -lmodjpeg -lpthread -ldl -lm -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -ljpeg
+  for p in $R/tests/tools/probe.c modjpeg.c $R/tests/tools/bench_dropin.c; do
+    gcc $SAN -std=gnu99 -I$R/include -I/opt/conda/include -o $O/$(basename $p .c) $p -L$O -Wl,-rpath,$O -Wl,--allow-shlib-undefined -lmodjpeg -lpthread -ldl -lm -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -ljpeg
   done )
 I=tests/golden/images
 BENCH_DUMP_INPUT=$O/in.jpg MJ_GPU_DECODE=0 MJ_GPU_ENCODE=0 $O/bench_dropin $O/libmodjpeg.so.1 800 600 16 16 1 > /dev/null

@@ -10,6 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "libmodjpeg_amd", "host")
+TOOLS = os.path.join(ROOT, "tests", "tools")  # mjhost_probe, bench_dropin: test harnesses, built by tests/tools/Makefile
 IMAGES = os.path.join(ROOT, "tests", "golden", "images")
 REF_CLI = os.path.join(ROOT, "oracle", "_ref", "modjpeg_ref")
 
@@ -107,7 +108,7 @@ def test_batch_pipeline_keeps_images_on_the_device_and_matches_the_reference(cli
     for k in range(6):
         p = src / f"img{k}.jpg"
         env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DUMP_INPUT=str(p), BENCH_QUALITY=str(60 + 7 * k), MJ_GPU_DECODE="0", MJ_GPU_ENCODE="0")
-        subprocess.check_output([os.path.join(HOST, "bench_dropin"), os.path.join(HOST, "libmodjpeg.so.1"), str(400 + 33 * k), str(300 + 17 * k), "16", "16", "1"], env=env)
+        subprocess.check_output([os.path.join(TOOLS, "bench_dropin"), os.path.join(HOST, "libmodjpeg.so.1"), str(400 + 33 * k), str(300 + 17 * k), "16", "16", "1"], env=env)
         names.append(str(p))
     (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
     out = tmp_path / "out"

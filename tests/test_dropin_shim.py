@@ -12,6 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "libmodjpeg_amd", "host")
+TOOLS = os.path.join(ROOT, "tests", "tools")  # mjhost_probe, bench_dropin: test harnesses, built by tests/tools/Makefile
 IMAGES = os.path.join(ROOT, "tests", "golden", "images")
 
 PUBLIC_API = ["mj_init_dropon", "mj_read_dropon_from_raw", "mj_read_dropon_from_memory", "mj_read_dropon_from_file", "mj_init_jpeg",
@@ -60,7 +61,7 @@ def test_exports(shim):
 def test_jpeg_roundtrip_on_host(shim, golden_dir, tmp_path):
     g = np.load(os.path.join(golden_dir, "compose_kat.npz"))
     out = tmp_path / "rt.bin"
-    subprocess.check_call([os.path.join(HOST, "mjhost_probe"), "roundtrip", os.path.join(IMAGES, "image.jpg"), str(out)])
+    subprocess.check_call([os.path.join(TOOLS, "mjhost_probe"), "roundtrip", os.path.join(IMAGES, "image.jpg"), str(out)])
     a, b = _planes(out, g["meta"], 2)
     for c in range(3):
         assert np.array_equal(a[c].reshape(-1), g[f"before_c{c}"])  # same coefficients as the reference read
@@ -103,7 +104,7 @@ def test_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case):
     rgba.tofile(raw)
     bx, by, cx, cy, cw, ch = _placement(g, case)
     out = tmp_path / "tiles.bin"
-    subprocess.check_call([os.path.join(HOST, "mjhost_probe"), "tiles", os.path.join(IMAGES, "image.jpg"), str(raw), str(w), str(h), "2", "255",
+    subprocess.check_call([os.path.join(TOOLS, "mjhost_probe"), "tiles", os.path.join(IMAGES, "image.jpg"), str(raw), str(w), str(h), "2", "255",
                            str(bx), str(by), str(cx), str(cy), str(cw), str(ch), str(out)])
     buf = open(out, "rb").read()
     off = 0
@@ -156,7 +157,7 @@ def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case
     rgba.tofile(raw)
     bx, by, cx, cy, cw, ch = _placement(g, case)
     out = tmp_path / "tiles.bin"
-    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "tilesgpu", os.path.join(IMAGES, "image.jpg"), str(raw), str(w), str(h), "2", "255",
+    res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "tilesgpu", os.path.join(IMAGES, "image.jpg"), str(raw), str(w), str(h), "2", "255",
                           str(bx), str(by), str(cx), str(cy), str(cw), str(ch), str(out)], capture_output=True, text=True,
                          env=dict(os.environ, MJ_TILES_I16="1" if tiles == "i16" else "0"))
     assert res.returncode == 0 and res.stdout.strip() == "gpu", (res.returncode, res.stdout, res.stderr[-300:])
@@ -177,7 +178,7 @@ def test_gpu_tile_preparation_equals_libjpeg_on_random_overlays(shim, tmp_path, 
     rng = np.random.default_rng(int(sampling) if sampling.isdigit() else 7)
     target = str(tmp_path / "target.jpg")
     _make_input(target, ("200", "120"), sampling)
-    probe = os.path.join(HOST, "mjhost_probe")
+    probe = os.path.join(TOOLS, "mjhost_probe")
     for trial in range(int(os.environ.get("MJX_TILEPREP_TRIALS", "14"))):  # a soak run sets more
         w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
         cs = [1, 2, 5, 6][trial % 4] if sampling != "rgb" else [1, 2][trial % 2]  # (libjpeg cannot turn YCbCr pixels into an RGB JPEG)
@@ -213,7 +214,7 @@ def test_block_loops_fail_loudly_without_device(shim):
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
-    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "nodevice", os.path.join(IMAGES, "image.jpg")], capture_output=True, text=True, check=True)
+    res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "nodevice", os.path.join(IMAGES, "image.jpg")], capture_output=True, text=True, check=True)
     lum, compose, null, pix = [int(v) for v in res.stdout.split()]
     assert (lum, compose, null, pix) == (1, 1, 2, 1)  # MJ_ERR_MEMORY, MJ_ERR_MEMORY, MJ_ERR_NULL_DATA, MJ_ERR_MEMORY
     assert "no CPU fallback" in res.stderr
@@ -275,7 +276,7 @@ def test_gpu_entropy_encoder_byte_identical(shim, size, sampling):
     (row f-4) and must equal libjpeg's byte for byte - odd sizes exercise the dummy blocks libjpeg
     inserts at the right/bottom edge, the samplings the MCU layouts, gray the non-interleaved scan"""
     import json
-    exe = os.path.join(HOST, "bench_dropin")
+    exe = os.path.join(TOOLS, "bench_dropin")
     args = [*size, "16", "16", "3", "9", "-4", "6"]
     env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_VARY_POSITION="1")
     gpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))
@@ -294,7 +295,7 @@ def test_optimal_huffman_tables_equal_libjpegs(shim, mode):
     ones libjpeg 9d writes for the same coefficients (DHT segments compared) - Fibonacci-like counts
     that push code lengths past 16 bits, equal counts (ties everywhere), random counts.  No GPU."""
     for seed in ("1", "2", "3"):
-        res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "opttables", os.path.join(IMAGES, "image.jpg"), mode, seed], capture_output=True, text=True)
+        res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "opttables", os.path.join(IMAGES, "image.jpg"), mode, seed], capture_output=True, text=True)
         assert res.returncode == 0 and "DIFFERENT" not in res.stdout and res.stdout.count("same") == 4, (res.stdout, res.stderr[-300:])
 
 
@@ -306,7 +307,7 @@ def test_gpu_entropy_encoder_with_optimised_tables_byte_identical(shim, size, sa
     built as libjpeg's optimize_coding builds them, DHT segments rewritten, scan encoded on the GPU:
     the same bytes as libjpeg writing the file, and as the reference"""
     import json
-    exe = os.path.join(HOST, "bench_dropin")
+    exe = os.path.join(TOOLS, "bench_dropin")
     args = [*size, "16", "16", "2", "9", "-4", "6"]
     env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_WRITE_OPTIONS="1")
     gpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))
@@ -329,7 +330,7 @@ def test_written_jpegs_byte_identical_to_reference(shim, args):
     ref = os.path.join(ROOT, "oracle", "_ref", "libmodjpeg_ref.so")
     if not os.path.exists(ref):
         pytest.skip("oracle/_ref not present")
-    exe = os.path.join(HOST, "bench_dropin")
+    exe = os.path.join(TOOLS, "bench_dropin")
     for env in (dict(os.environ, BENCH_VARY_POSITION="1"), dict(os.environ), dict(os.environ, MJ_TILE_CACHE="0")):
         a = json.loads(subprocess.check_output([exe, ref, *args], text=True, env=env))
         b = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))  # tile cache: misses, hits, disabled
@@ -347,7 +348,7 @@ def test_dropon_colour_spaces_match_reference(shim, sampling, dropon):
     ref = os.path.join(ROOT, "oracle", "_ref", "libmodjpeg_ref.so")
     if not os.path.exists(ref):
         pytest.skip("oracle/_ref not present")
-    exe = os.path.join(HOST, "bench_dropin")
+    exe = os.path.join(TOOLS, "bench_dropin")
     args = ["200", "120", "48", "40", "2"]
     env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DROPON=dropon)
     a = subprocess.run([exe, ref, *args], capture_output=True, text=True, env=env)
@@ -373,7 +374,7 @@ def test_concurrent_compose_with_cache_evictions(shim, tmp_path, mode):
         env["MJ_GPU_DECODE_MIN_BYTES"] = "0"
     if mode == "device-resident":
         env["MJ_DEVICE_RESIDENT"] = "1"
-    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "stress", image, os.path.join(IMAGES, "dropon.png"), "16", "40"], capture_output=True, text=True,
+    res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "stress", image, os.path.join(IMAGES, "dropon.png"), "16", "40"], capture_output=True, text=True,
                          env=env)
     assert res.returncode == 0 and res.stdout.strip() == "ok", (res.stdout, res.stderr[-500:])
 
@@ -383,7 +384,7 @@ def _make_input(path, size, sampling, **knobs):
     env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DUMP_INPUT=str(path), MJ_GPU_DECODE="0", MJ_GPU_ENCODE="0")
     for k, v in knobs.items():
         env["BENCH_" + k.upper()] = str(v)
-    subprocess.check_output([os.path.join(HOST, "bench_dropin"), os.path.join(HOST, "libmodjpeg.so.1"), *size, "16", "16", "1"], env=env)
+    subprocess.check_output([os.path.join(TOOLS, "bench_dropin"), os.path.join(HOST, "libmodjpeg.so.1"), *size, "16", "16", "1"], env=env)
     assert os.path.getsize(path) > 100
 
 
@@ -409,7 +410,7 @@ def test_gpu_entropy_decoder_matches_libjpeg(shim, tmp_path, sampling, case):
     size, knobs = DECODE_CASES[case]
     src = tmp_path / "in.jpg"
     _make_input(src, size, sampling, **knobs)
-    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "decodecmp", str(src)], capture_output=True, text=True,
+    res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "decodecmp", str(src)], capture_output=True, text=True,
                          env=dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0"))
     assert res.returncode == 0 and res.stdout.strip() == "same gpu", (res.stdout, res.stderr[-500:])
 
@@ -419,7 +420,7 @@ def test_gpu_entropy_decoder_declines_what_it_does_not_decode(shim, tmp_path):
     """progressive, arithmetic-coded and small files are read by libjpeg exactly as in the reference"""
     src = tmp_path / "in.jpg"
     _make_input(src, ("320", "240"), "420")
-    cli, probe = os.path.join(HOST, "modjpeg"), os.path.join(HOST, "mjhost_probe")
+    cli, probe = os.path.join(HOST, "modjpeg"), os.path.join(TOOLS, "mjhost_probe")
     for flag in ("-P", "-A"):
         out = tmp_path / ("out%s.jpg" % flag)
         subprocess.check_call([cli, flag, "-i", str(src), "-o", str(out)])
@@ -437,7 +438,7 @@ def test_gpu_entropy_decoder_on_damaged_files(shim, tmp_path, sampling, knobs):
     same arrays or the same error - the GPU decoder refuses anything that is not a clean stream"""
     src = tmp_path / "in.jpg"
     _make_input(src, ("400", "300"), sampling, **knobs)
-    res = subprocess.run([os.path.join(HOST, "mjhost_probe"), "decodefuzz", str(src), "150", "7"], capture_output=True, text=True,
+    res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "decodefuzz", str(src), "150", "7"], capture_output=True, text=True,
                          env=dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0"))
     assert res.returncode == 0 and res.stdout.strip().endswith(" 0 differ"), (res.stdout, res.stderr[-500:])
 
@@ -447,7 +448,7 @@ def test_read_compose_write_identical_with_both_entropy_paths_on_the_gpu(shim):
     """end to end with decoder and encoder on the GPU: same bytes as with libjpeg doing both, and
     as the reference library"""
     import json
-    exe = os.path.join(HOST, "bench_dropin")
+    exe = os.path.join(TOOLS, "bench_dropin")
     args = ["1920", "1080", "256", "256", "3", "7", "5", "-3"]
     env = dict(os.environ, BENCH_RESTART="120")
     gpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))
@@ -470,7 +471,7 @@ def test_files_from_another_encoder(shim, tmp_path):
     y, x = np.mgrid[0:413, 0:655]
     base = np.stack([(x * 255 // 655), (y * 255 // 413), ((x + y) // 8 * 8) % 256], -1).astype(np.int16)
     img = PIL.fromarray((base + rng.integers(-20, 20, base.shape)).clip(0, 255).astype(np.uint8))
-    probe, cli = os.path.join(HOST, "mjhost_probe"), os.path.join(HOST, "modjpeg")
+    probe, cli = os.path.join(TOOLS, "mjhost_probe"), os.path.join(HOST, "modjpeg")
     ref_cli = os.path.join(ROOT, "oracle", "_ref", "modjpeg_ref")
     env = dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0")
     k = 0
@@ -506,7 +507,7 @@ def test_mj_compose_takes_the_pattern_schedule_and_int16_tiles(shim):
     schedule that picks the blocks of an octet by pattern; MJ_TILES_I16=0 / MJ_TILE_SCHEDULE=0 switch
     each off.  (That the files stay byte-identical to the reference's is tests/test_cli.py and
     test_example_program_matches_reference, which run through this default.)"""
-    probe = os.path.join(HOST, "mjhost_probe")
+    probe = os.path.join(TOOLS, "mjhost_probe")
     args = [probe, "composepath", os.path.join(IMAGES, "image.jpg"), os.path.join(IMAGES, "dropon.png"), "3"]
     rects, i16, sched, gpu = [int(v) for v in subprocess.check_output(args, text=True).split()]
     assert rects == 9 and i16 == 9 and gpu >= 1, (rects, i16, sched, gpu)

@@ -9,6 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "libmodjpeg_amd", "host")
+TOOLS = os.path.join(ROOT, "tests", "tools")  # mjhost_probe, bench_dropin: test harnesses, built by tests/tools/Makefile
 IMAGES = os.path.join(ROOT, "tests", "golden", "images")
 
 pytestmark = pytest.mark.gpu
@@ -50,7 +51,7 @@ def test_batch_cli_on_two_devices_writes_what_one_device_writes(two_devices, tmp
 def test_tile_cache_and_buffer_pools_across_devices(two_devices):
     """the probe's concurrency stress with its threads sharded over the GPUs (every result must equal the
     single-thread result for the same placement), and the recycled image buffers stay on their device"""
-    probe = os.path.join(HOST, "mjhost_probe")
+    probe = os.path.join(TOOLS, "mjhost_probe")
     res = subprocess.run([probe, "stress", os.path.join(IMAGES, "image.jpg"), os.path.join(IMAGES, "dropon.png"), "12", "30"],
                          env=dict(os.environ, MJ_STRESS_DEVICES=str(two_devices)), capture_output=True, text=True)
     assert res.returncode == 0 and res.stdout.strip() == "ok", (res.stdout[-300:], res.stderr[-800:])

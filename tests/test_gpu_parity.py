@@ -320,7 +320,12 @@ for seed in (2, 3, 4):                                            # the arena is
     assert rc == MJX_OK and np.array_equal(plane, want), (seed, rc)
 print("ok")
 """
-    env = dict(os.environ, MJX_INJECT_FAILURE=where, MJX_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MJX_ARENAS="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    faulty = os.path.join(root, "libmodjpeg_amd", "libmjx_hip_faultinj.so")  # the product library carries no injector (-DMJX_FAULT_INJECTION, __graft_entry__.build_hip)
+    if not os.path.exists(faulty):
+        import __graft_entry__ as g
+        g.build_hip()
+    env = dict(os.environ, MJX_INJECT_FAILURE=where, MJX_ROOT=root, MJX_ARENAS="1", MJX_HIP_LIB=faulty)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert res.returncode == 0 and res.stdout.strip().endswith("ok"), (res.stdout[-300:], res.stderr[-800:])
     assert "failure injected" in res.stderr

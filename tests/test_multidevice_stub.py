@@ -35,7 +35,7 @@ def stubbed(tmp_path_factory):
     run(["gcc", *san, "-fPIC", "-std=gnu99", "-Wall", *inc, *png, "-shared", "-Wl,-soname,libmodjpeg.so.1", "-o", os.path.join(d, "libmodjpeg.so.1"),
          *HOST_SRCS, *libs, "-Wl,-rpath," + os.path.join(JPEG, "lib"), "-L" + d, "-Wl,-rpath," + d, "-lmjx_hip", "-lm", "-lpthread"], cwd=HOST)
     os.symlink("libmodjpeg.so.1", os.path.join(d, "libmodjpeg.so"))
-    for prog, src in (("modjpeg", "modjpeg.c"), ("probe", "probe.c")):
+    for prog, src in (("modjpeg", "modjpeg.c"), ("probe", os.path.join(ROOT, "tests", "tools", "probe.c"))):
         run(["gcc", *san, "-std=gnu99", *inc, "-o", os.path.join(d, prog), src, "-L" + d, "-Wl,-rpath," + d, "-Wl,--allow-shlib-undefined", "-lmodjpeg", "-lpthread", "-ldl", "-lm",
              *libs, "-Wl,-rpath," + os.path.join(JPEG, "lib")], cwd=HOST)
     env = dict(os.environ, MJ_GPU_DECODE="0", MJ_GPU_ENCODE="0", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
