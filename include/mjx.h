@@ -199,14 +199,15 @@ int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, in
  * tiles per component for image and alpha, identical to the ones the linked libjpeg (IJG 9d) would
  * have produced.  Supported: 3 components; target YCbCr from an RGB or YCbCr overlay, target RGB
  * from an RGB overlay; every component at full resolution or subsampled 2:1 in either direction
- * (4:4:4, 4:2:2, 4:4:0, 4:2:0).  Anything else returns
+ * (4:4:4, 4:2:2, 4:4:0, 4:2:0); 1 component, target grayscale from an RGB or YCbCr overlay.  Anything else returns
  * MJX_ERR_BAD_ARG before touching the device, and the caller prepares the tiles with libjpeg.
  * Block counts: canvas = crop + offset rounded up to whole MCUs; component c has
  * canvas_w / (8 * hmax / h_samp[c]) columns and canvas_h / (8 * vmax / v_samp[c]) rows. */
 #define MJX_PREP_SOURCE_RGB 1
 #define MJX_PREP_SOURCE_YCC 5 /* = MJ_COLORSPACE_RGB / MJ_COLORSPACE_YCC of libmodjpeg.h */
+#define MJX_PREP_TARGET_GRAY 1 /* one component: libjpeg's Y of an RGB overlay, the first component of a YCbCr one */
 #define MJX_PREP_TARGET_RGB 2
-#define MJX_PREP_TARGET_YCC 3 /* = JCS_RGB / JCS_YCbCr of jpeglib.h */
+#define MJX_PREP_TARGET_YCC 3 /* = JCS_GRAYSCALE / JCS_RGB / JCS_YCbCr of jpeglib.h */
 typedef struct mjx_tileprep {
     const unsigned char *image;      /* HOST: width x height pixels, 3 bytes each */
     const unsigned char *alpha;      /* HOST: the same geometry, alpha replicated into 3 bytes */
@@ -214,7 +215,7 @@ typedef struct mjx_tileprep {
     int32_t              crop_x, crop_y, crop_w, crop_h; /* visible window of the overlay */
     int32_t              off_x, off_y;                   /* its offset inside the first MCU */
     int32_t              source, target;                 /* MJX_PREP_SOURCE_*, MJX_PREP_TARGET_* */
-    int32_t              ncomp;                          /* 3 */
+    int32_t              ncomp;                          /* 3, or 1 for MJX_PREP_TARGET_GRAY */
     int32_t              h_samp[4], v_samp[4];           /* the target image's sampling factors */
     float               *tile[4];                        /* DEVICE out, rows*cols*64 floats each */
     float               *alpha_tile[4];
@@ -224,6 +225,12 @@ typedef struct mjx_tileprep {
 /* write the tiles as int16 coefficients (the form MJX_JOB_TILES_I16 consumes): tile[] / alpha_tile[]
  * then point at int16_t[rows*cols][64] */
 #define MJX_PREP_TILES_I16 1
+/* `image` points at the visible window already packed (crop_w * 3 bytes per row, crop_h rows), immediately
+ * followed by the packed window of alpha (alpha == image + crop_w * 3 * crop_h), in PINNED host memory
+ * (mjx_malloc_host): it is uploaded as it lies, without a staging copy.  width == crop_w, height == crop_h,
+ * crop_x == crop_y == 0.  (The drop-in's tile cache keeps such a copy of the window anyway, to compare
+ * later callers' pixels with.) */
+#define MJX_PREP_WINDOW_PACKED 2
 int mjx_tiles_prepare(const mjx_tileprep_t *p);
 
 /* ---- one (k,l) term: mj_convolve (reference convolve.c:29), test seam ------------------- */

@@ -81,7 +81,8 @@ float rq_of(unsigned q) {
     return f;
 }
 
-static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static bool   aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 } // namespace mjx
 
@@ -584,13 +585,29 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern) {
         }
     }
     pattern.resize((size_t)t.blocks);
+    const size_t run_bytes = round256(tmp.size() * sizeof(Run)), pat_bytes = (size_t)t.blocks * sizeof(uint64_t);
+    if(run_bytes + pat_bytes <= ((size_t)8 << 20)) {
+        // the usual case (the tiles of one overlay): through a pooled staging arena, no hipMalloc / hipFree
+        // (each of which synchronises the device: four of them were half of the 0.8 ms a 4K schedule took)
+        ArenaLease arena;
+        int        err = arena->prepare(run_bytes + pat_bytes, run_bytes + pat_bytes);
+        if(err != MJX_OK) return err;
+        hipStream_t s = arena->stream;
+        memcpy(arena->pin, tmp.data(), tmp.size() * sizeof(Run));
+        err = check_hip(hipMemcpyAsync(arena->dev, arena->pin, tmp.size() * sizeof(Run), hipMemcpyHostToDevice, s), "hipMemcpyAsync(scan runs)", MJX_ERR_LAUNCH);
+        if(err == MJX_OK) err = launch_alpha_pattern(reinterpret_cast<const Run *>(arena->dev), (int)tmp.size(), reinterpret_cast<uint64_t *>(arena->dev + run_bytes), t.tiles_i16, s);
+        if(err == MJX_OK) err = check_hip(hipMemcpyAsync(arena->pin + run_bytes, arena->dev + run_bytes, pat_bytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(patterns)", MJX_ERR_LAUNCH);
+        const int serr = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
+        if(err == MJX_OK && serr == MJX_OK) memcpy(pattern.data(), arena->pin + run_bytes, pat_bytes);
+        return err != MJX_OK ? err : serr;
+    }
     Run      *d_tmp = nullptr;
     uint64_t *d_pat = nullptr;
     int       err = check_hip(hipMalloc((void **)&d_tmp, tmp.size() * sizeof(Run)), "hipMalloc(scan runs)", MJX_ERR_MEMORY);
-    if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_pat, (size_t)t.blocks * sizeof(uint64_t)), "hipMalloc(patterns)", MJX_ERR_MEMORY);
+    if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_pat, pat_bytes), "hipMalloc(patterns)", MJX_ERR_MEMORY);
     if(err == MJX_OK) err = check_hip(hipMemcpy(d_tmp, tmp.data(), tmp.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(scan runs)", MJX_ERR_LAUNCH);
     if(err == MJX_OK) err = launch_alpha_pattern(d_tmp, (int)tmp.size(), d_pat, t.tiles_i16, nullptr);
-    if(err == MJX_OK) err = check_hip(hipMemcpy(pattern.data(), d_pat, (size_t)t.blocks * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(patterns)", MJX_ERR_LAUNCH);
+    if(err == MJX_OK) err = check_hip(hipMemcpy(pattern.data(), d_pat, pat_bytes, hipMemcpyDeviceToHost), "hipMemcpy(patterns)", MJX_ERR_LAUNCH);
     if(d_tmp) (void)hipFree(d_tmp);
     if(d_pat) (void)hipFree(d_pat);
     return err;
@@ -778,7 +795,6 @@ int mjx_tile_schedule_stats(const mjx_tile_schedule_t *sched, mjx_plan_stats_t *
 // host-buffer path (per-image callers): per-thread staging arena, no allocation in steady state
 // ------------------------------------------------------------------------------------------
 namespace {
-size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // scoped device buffer for the one-shot effect calls
 struct DevBuf {

@@ -21,8 +21,10 @@
 //
 // Supported: three components, target YCbCr (overlay RGB: converted; overlay YCbCr: as is) or RGB
 // (overlay RGB), every component at full resolution or subsampled 2:1 in either direction (4:4:4,
-// 4:2:2, 4:4:0, 4:2:0).  Everything else returns MJX_ERR_BAD_ARG and the caller prepares the tiles
-// with libjpeg as before.
+// 4:2:2, 4:4:0, 4:2:0); one component, target grayscale (overlay RGB: libjpeg's Y; overlay YCbCr: its
+// first component).  Everything else (4:1:1 and other ratios above 2: libjpeg folds only ONE halving
+// into the transform and box-filters the rest, CMYK ...) returns MJX_ERR_BAD_ARG and the caller
+// prepares the tiles with libjpeg as before.
 //
 // One wavefront per output block: the C x R samples go to LDS (colour conversion on the way),
 // pass 1 along the rows (R x 8 outputs), pass 2 down the columns (8 x 8), quantisation, float.
@@ -152,15 +154,24 @@ using namespace mjx;
 extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
     if(p == nullptr) return MJX_ERR_NULL_DATA;
     if(p->image == nullptr || p->alpha == nullptr) return MJX_ERR_NULL_DATA;
-    if((p->flags & ~MJX_PREP_TILES_I16) != 0) return MJX_ERR_BAD_ARG;
-    if(p->ncomp != 3 || p->crop_w <= 0 || p->crop_h <= 0 || p->off_x < 0 || p->off_y < 0 || p->crop_x < 0 || p->crop_y < 0) return MJX_ERR_BAD_ARG;
+    if((p->flags & ~(MJX_PREP_TILES_I16 | MJX_PREP_WINDOW_PACKED)) != 0) return MJX_ERR_BAD_ARG;
+    const bool packed = (p->flags & MJX_PREP_WINDOW_PACKED) != 0;
+    if(packed && (p->crop_x != 0 || p->crop_y != 0 || p->width != p->crop_w || p->height != p->crop_h || p->alpha != p->image + (size_t)p->crop_w * 3 * (size_t)p->crop_h))
+        return MJX_ERR_BAD_ARG;
+    if((p->ncomp != 3 && p->ncomp != 1) || p->crop_w <= 0 || p->crop_h <= 0 || p->off_x < 0 || p->off_y < 0 || p->crop_x < 0 || p->crop_y < 0) return MJX_ERR_BAD_ARG;
+    if((p->ncomp == 1) != (p->target == MJX_PREP_TARGET_GRAY)) return MJX_ERR_BAD_ARG;
+    const int ncomp = p->ncomp;
     if(p->crop_x + (int64_t)p->crop_w > p->width || p->crop_y + (int64_t)p->crop_h > p->height) return MJX_ERR_BAD_ARG;
     int convert;
-    if(p->target == MJX_PREP_TARGET_YCC && p->source == MJX_PREP_SOURCE_RGB) convert = 1;
+    // a grayscale target takes libjpeg's Y of an RGB overlay (jccolor.c rgb_gray_convert: the Y row of the same
+    // tables) or the first component of a YCbCr one (grayscale_convert); its alpha canvas is handed over as
+    // YCbCr (reference dropon.c:409-413), i.e. its first component as it stands
+    if((p->target == MJX_PREP_TARGET_YCC || p->target == MJX_PREP_TARGET_GRAY) && p->source == MJX_PREP_SOURCE_RGB) convert = 1;
+    else if(p->target == MJX_PREP_TARGET_GRAY && p->source == MJX_PREP_SOURCE_YCC) convert = 0;
     else if((p->target == MJX_PREP_TARGET_YCC && p->source == MJX_PREP_SOURCE_YCC) || (p->target == MJX_PREP_TARGET_RGB && p->source == MJX_PREP_SOURCE_RGB)) convert = 0;
     else return MJX_ERR_BAD_ARG;
     int hmax = 1, vmax = 1;
-    for(int c = 0; c < 3; ++c) {
+    for(int c = 0; c < ncomp; ++c) {
         if(p->h_samp[c] < 1 || p->v_samp[c] < 1) return MJX_ERR_BAD_ARG;
         hmax = p->h_samp[c] > hmax ? p->h_samp[c] : hmax;
         vmax = p->v_samp[c] > vmax ? p->v_samp[c] : vmax;
@@ -171,7 +182,7 @@ extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
     PrepJob job;
     memset(&job, 0, sizeof(job));
     int64_t total = 0;
-    for(int c = 0; c < 3; ++c) {
+    for(int c = 0; c < ncomp; ++c) {
         if(hmax % p->h_samp[c] != 0 || vmax % p->v_samp[c] != 0) return MJX_ERR_BAD_ARG;
         const int fx = hmax / p->h_samp[c], fy = vmax / p->v_samp[c];
         if((fx != 1 && fx != 2) || (fy != 1 && fy != 2)) return MJX_ERR_BAD_ARG; // 8x8, 16x16, 16x8, 8x16 transforms only
@@ -186,6 +197,7 @@ extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
         total += (int64_t)job.comp[c].rows * job.comp[c].cols;
     }
     if(total * 2 > 0x7FFFFFFFll) return MJX_ERR_BAD_ARG;
+    for(int c = ncomp; c < 3; ++c) job.comp[c].first = 0x7FFFFFFF; // no block belongs to a component the target does not have
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
 
     // MJX_TILEPREP_DEBUG=1: where the time goes (stderr)
@@ -196,19 +208,23 @@ extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
         return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
     };
     const double t0 = dbg ? now() : 0;
-    // the crop window of image and alpha, packed, through the leased arena
-    const size_t row = (size_t)p->crop_w * 3, win = row * (size_t)p->crop_h, win_al = (win + 255) & ~(size_t)255;
+    // the crop window of image and alpha, packed: straight out of the caller's pinned copy, or through the leased arena's
+    const size_t row = (size_t)p->crop_w * 3, win = row * (size_t)p->crop_h, win_al = packed ? win : ((win + 255) & ~(size_t)255);
     ArenaLease   arena;
-    int          err = arena->prepare(2 * win_al, 2 * win_al);
+    int          err = arena->prepare(win_al + win, packed ? 256 : win_al + win);
     if(err != MJX_OK) return err;
-    for(int y = 0; y < p->crop_h; ++y) {
-        const size_t src = ((size_t)(y + p->crop_y) * (size_t)p->width + (size_t)p->crop_x) * 3;
-        memcpy(arena->pin + (size_t)y * row, p->image + src, row);
-        memcpy(arena->pin + win_al + (size_t)y * row, p->alpha + src, row);
+    const unsigned char *src = p->image;
+    if(!packed) {
+        for(int y = 0; y < p->crop_h; ++y) {
+            const size_t at = ((size_t)(y + p->crop_y) * (size_t)p->width + (size_t)p->crop_x) * 3;
+            memcpy(arena->pin + (size_t)y * row, p->image + at, row);
+            memcpy(arena->pin + win_al + (size_t)y * row, p->alpha + at, row);
+        }
+        src = reinterpret_cast<const unsigned char *>(arena->pin);
     }
     const double t1 = dbg ? now() : 0;
     hipStream_t  s = arena->stream;
-    MJX_HIP(hipMemcpyAsync(arena->dev, arena->pin, win_al + win, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    MJX_HIP(hipMemcpyAsync(arena->dev, src, win_al + win, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
     if(dbg) (void)hipStreamSynchronize(s);
     const double t2 = dbg ? now() : 0;
     job.image = reinterpret_cast<const unsigned char *>(arena->dev);

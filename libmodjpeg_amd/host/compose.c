@@ -9,7 +9,9 @@
 #include "mjhost.h"
 
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 /* one component's share of a compose call */
 typedef struct {
@@ -50,6 +52,7 @@ int mj_compose(mj_jpeg_t *m, mj_dropon_t *d, unsigned int align, int offset_x, i
     struct mjh_tiles   *cached = NULL;
     axis_t              ax, ay;
     int                 inblock_x, inblock_y, mcu_x, mcu_y, rv;
+    double              t_start = 0, t_tiles = 0; /* MJ_DEBUG_TILES */
 
     if(m == NULL || d == NULL) return MJ_ERR_NULL_DATA;
     if(d->blend == MJ_BLEND_NONE) return MJ_OK; /* fully transparent: nothing to do (compose.c:38) */
@@ -74,6 +77,13 @@ int mj_compose(mj_jpeg_t *m, mj_dropon_t *d, unsigned int align, int offset_x, i
 
     /* tiles: from the device-resident cache when this (overlay window, offset, target format) has
      * been prepared before, else prepared now exactly as the reference does on every call */
+    {
+        struct timespec ts;
+        if(getenv("MJ_DEBUG_TILES") != NULL) {
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            t_start = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+        }
+    }
     rv = mjh_tiles_acquire(&cached, d, m->cinfo.jpeg_color_space, &m->sampling, inblock_x, inblock_y, ax.crop_at, ay.crop_at, ax.crop_len, ay.crop_len);
     if(rv != MJ_OK) return rv;
     if(cached != NULL) {
@@ -84,8 +94,18 @@ int mj_compose(mj_jpeg_t *m, mj_dropon_t *d, unsigned int align, int offset_x, i
             mjh_tiles_component(cached, c, &ct[c].rows, &ct[c].cols, &ct[c].tile, &ct[c].alpha);
             ct[c].schedule = mjh_tiles_schedule(cached, c);
         }
+        if(t_start > 0) {
+            struct timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            t_tiles = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+        }
         rv = blend_components(m, n, ct, MJX_RECT_TILES_ON_DEVICE | (mjh_tiles_i16(cached) ? MJX_RECT_TILES_I16 : 0), mcu_x, mcu_y);
         mjh_tiles_release(cached);
+        if(t_start > 0) {
+            struct timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            fprintf(stderr, "mj_compose: tiles %.3f ms, blend (planes up, kernel, planes down) %.3f ms\n", t_tiles - t_start, ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - t_tiles);
+        }
         return rv;
     }
 

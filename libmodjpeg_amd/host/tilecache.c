@@ -51,11 +51,14 @@ struct mjh_tiles {
     float   *dev_tile[4], *dev_alpha[4]; /* float[n][64], or int16_t[n][64] when i16 */
     int      i16;
     mjx_tile_schedule_t *sched[4];
+    int      sched_state; /* 0 none yet, 1 being made by the caller that saw the entry's first hit, 2 ready */
     /* what the key stands for, compared on every hit: a hash decides where to look, never what is equal */
     int            device;     /* HIP ordinal the tiles live on */
     int            params[16]; /* colour spaces, in-MCU offset, crop size, sampling */
     size_t         win_bytes;
     unsigned char *window;     /* the visible overlay pixels, image rows then alpha rows */
+    size_t         win_cap;    /* > 0: the window lives in pinned memory of that size (large windows: it is also what the device preparation uploads from) */
+    size_t         dev_cap[2][4]; /* capacity of dev_tile[c] / dev_alpha[c] (recycled buffers may be larger than needed) */
 };
 
 static struct mjh_tiles g_slots[CACHE_SLOTS];
@@ -175,15 +178,89 @@ static struct mjh_tiles *lookup(const uint64_t key[2], const int params[16], int
     return NULL;
 }
 
+/* ---- spare buffers ---------------------------------------------------------------------------------
+ * A miss on a large overlay used to spend most of its time on memory, not on tiles (full-frame 4K,
+ * profiles/r03: 9 ms to malloc and fill a fresh 50 MB window copy, 5.6 ms to free the evicted entry's,
+ * against 0.2 ms of kernel): what an evicted entry owned - its pinned window, its device tile buffers -
+ * is kept here for the next miss of similar size instead of going back to the system. */
+enum { SPARE_SLOTS = 16, SPARE_PINNED = 1, SPARE_DEVICE = 2 };
+#define SPARE_MIN_BYTES ((size_t)1 << 20)
+#define SPARE_BUDGET    ((size_t)768 << 20)
+static struct {
+    void  *ptr;
+    size_t cap;
+    int    kind, device;
+} g_spare[SPARE_SLOTS];
+static pthread_mutex_t g_spare_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void *spare_take(int kind, int device, size_t bytes, size_t *cap) {
+    void *p = NULL;
+    int   i, best = -1;
+    if(bytes < SPARE_MIN_BYTES) return NULL;
+    pthread_mutex_lock(&g_spare_lock);
+    for(i = 0; i < SPARE_SLOTS; i++) {
+        if(g_spare[i].ptr == NULL || g_spare[i].kind != kind || g_spare[i].device != device) continue;
+        if(g_spare[i].cap < bytes || g_spare[i].cap > bytes + bytes / 2) continue;
+        if(best < 0 || g_spare[i].cap < g_spare[best].cap) best = i;
+    }
+    if(best >= 0) {
+        p = g_spare[best].ptr;
+        *cap = g_spare[best].cap;
+        g_spare[best].ptr = NULL;
+    }
+    pthread_mutex_unlock(&g_spare_lock);
+    return p;
+}
+
+static void spare_release(int kind, void *p) {
+    if(kind == SPARE_PINNED) (void)mjx_free_host(p);
+    else (void)mjx_free(p);
+}
+
+static void spare_give(int kind, int device, void *p, size_t cap) {
+    size_t total = 0;
+    int    i, slot = -1;
+    if(p == NULL) return;
+    if(cap >= SPARE_MIN_BYTES) {
+        pthread_mutex_lock(&g_spare_lock);
+        for(i = 0; i < SPARE_SLOTS; i++) {
+            if(g_spare[i].ptr != NULL) total += g_spare[i].cap;
+            else if(slot < 0) slot = i;
+        }
+        if(slot >= 0 && total + cap <= SPARE_BUDGET) {
+            g_spare[slot].ptr = p;
+            g_spare[slot].cap = cap;
+            g_spare[slot].kind = kind;
+            g_spare[slot].device = device;
+            p = NULL;
+        }
+        pthread_mutex_unlock(&g_spare_lock);
+    }
+    if(p != NULL) spare_release(kind, p);
+}
+
+/* a device buffer of at least `bytes` on the calling thread's device: a spare one, else a new one */
+static int dev_buffer(float **out, size_t *cap, int device, size_t bytes) {
+    void *p = spare_take(SPARE_DEVICE, device, bytes, cap);
+    if(p == NULL) {
+        int e = mjx_malloc(&p, bytes);
+        if(e != MJX_OK) return e;
+        *cap = bytes;
+    }
+    *out = (float *)p;
+    return MJX_OK;
+}
+
 /* device buffers and window copy of an entry that has left the table (called WITHOUT the lock) */
 static void contents_free(struct mjh_tiles *t) {
     int c;
     for(c = 0; c < 4; c++) {
-        if(t->dev_tile[c]) (void)mjx_free(t->dev_tile[c]);
-        if(t->dev_alpha[c]) (void)mjx_free(t->dev_alpha[c]);
+        spare_give(SPARE_DEVICE, t->device, t->dev_tile[c], t->dev_cap[0][c]);
+        spare_give(SPARE_DEVICE, t->device, t->dev_alpha[c], t->dev_cap[1][c]);
         if(t->sched[c]) mjx_tile_schedule_destroy(t->sched[c]);
     }
-    free(t->window);
+    if(t->win_cap > 0) spare_give(SPARE_PINNED, 0, t->window, t->win_cap);
+    else free(t->window);
     memset(t, 0, sizeof(*t));
 }
 
@@ -205,7 +282,11 @@ static int env_on(const char *name) { /* switches that default to on */
     return !(e != NULL && e[0] == '0');
 }
 
-/* the schedules of a filled slot (which blocks share a wavefront: read once from the alpha tiles, kept with them) */
+/* The schedules of a slot (which blocks share a wavefront: read once from the alpha tiles, kept with them).
+ * They are made when an entry is hit for the FIRST time, not when it is filled: tiles that are used once
+ * (an overlay per image) would pay the scan - 0.2 ms for a 256x256 overlay, 2 ms for a full-frame 4K one -
+ * for nothing, tiles that are used again pay it once.  One caller makes them (sched_state 0 -> 1 under
+ * the lock, it holds the entry pinned), the others compose without until sched_state is 2. */
 static int contents_schedule(struct mjh_tiles *t) {
     int c, e;
     if(!env_on("MJ_TILE_SCHEDULE")) return MJX_OK;
@@ -217,11 +298,21 @@ static int contents_schedule(struct mjh_tiles *t) {
     return MJX_OK;
 }
 
+/* the entry's own copy of the visible pixels (image rows, then alpha rows).  A large window goes into pinned
+ * memory (recycled): the device preparation then uploads straight from this copy instead of making a
+ * second one for the DMA. */
 static int window_copy(struct mjh_tiles *t, const mj_dropon_t *d, int cx, int cy, int cw, int ch) {
     const size_t row = (size_t)cw * 3;
     int          y;
     t->win_bytes = 2 * row * (size_t)ch;
-    t->window = (unsigned char *)malloc(t->win_bytes ? t->win_bytes : 1);
+    t->win_cap = 0;
+    if(t->win_bytes >= SPARE_MIN_BYTES) {
+        void *p = spare_take(SPARE_PINNED, 0, t->win_bytes, &t->win_cap);
+        if(p == NULL && mjx_malloc_host(&p, t->win_bytes) == MJX_OK) t->win_cap = t->win_bytes;
+        t->window = (unsigned char *)p; /* NULL: pinned memory refused, ordinary memory below */
+        if(p == NULL) t->win_cap = 0;
+    }
+    if(t->window == NULL) t->window = (unsigned char *)malloc(t->win_bytes ? t->win_bytes : 1);
     if(t->window == NULL) return MJX_ERR_MEMORY;
     for(y = 0; y < ch; y++) {
         const size_t off = ((size_t)(y + cy) * (size_t)d->width + (size_t)cx) * 3;
@@ -244,13 +335,12 @@ static int contents_fill(struct mjh_tiles *t, const mj_compileddropon_t *cd, con
         t->rows[c] = cd->image[c].height_in_blocks;
         t->cols[c] = cd->image[c].width_in_blocks;
         if(cd->image[c].nblocks == 0) continue;
-        if((e = mjx_malloc((void **)&t->dev_tile[c], bytes)) != MJX_OK) return e;
-        if((e = mjx_malloc((void **)&t->dev_alpha[c], bytes)) != MJX_OK) return e;
+        if((e = dev_buffer(&t->dev_tile[c], &t->dev_cap[0][c], t->device, bytes)) != MJX_OK) return e;
+        if((e = dev_buffer(&t->dev_alpha[c], &t->dev_cap[1][c], t->device, bytes)) != MJX_OK) return e;
         if((e = mjx_memcpy_h2d(t->dev_tile[c], cd->image[c].blocks[0], bytes, NULL)) != MJX_OK) return e;
         if((e = mjx_memcpy_h2d(t->dev_alpha[c], cd->alpha[c].blocks[0], bytes, NULL)) != MJX_OK) return e;
         t->bytes += 2 * bytes;
     }
-    if((e = contents_schedule(t)) != MJX_OK) return e;
     return window_copy(t, d, cx, cy, cw, ch);
 }
 
@@ -270,27 +360,48 @@ static int device_prep_enabled(void) {
 static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_sampling_t *s, int bx, int by, int cx, int cy, int cw,
                                 int ch, int want_i16) {
     mjx_tileprep_t p;
+    const int      ncomp = cs == JCS_GRAYSCALE ? 1 : 3;
     int            c, e, w, h;
-    if(cs != JCS_YCbCr && cs != JCS_RGB) return MJX_ERR_BAD_ARG;
+    double         t0 = debug_tiles() ? now_ms() : 0, t1, t2, t3;
+    if(cs != JCS_YCbCr && cs != JCS_RGB && cs != JCS_GRAYSCALE) return MJX_ERR_BAD_ARG;
     if(d->colorspace != MJ_COLORSPACE_RGB && d->colorspace != MJ_COLORSPACE_YCC) return MJX_ERR_BAD_ARG;
     if(s->h_factor <= 0 || s->v_factor <= 0) return MJX_ERR_BAD_ARG;
+    for(c = 0; c < ncomp; c++) { /* formats the device does not reproduce are declined before anything is allocated or copied */
+        const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
+        if(hs < 1 || vs < 1 || s->max_h_samp_factor % hs != 0 || s->max_v_samp_factor % vs != 0) return MJX_ERR_BAD_ARG;
+        if(s->max_h_samp_factor / hs > 2 || s->max_v_samp_factor / vs > 2) return MJX_ERR_BAD_ARG;
+    }
+    /* the entry's copy of the window first: when it is pinned it is also the upload source */
+    if((e = window_copy(t, d, cx, cy, cw, ch)) != MJX_OK) return e;
+    t3 = debug_tiles() ? now_ms() : 0;
     memset(&p, 0, sizeof(p));
-    p.image = d->image;
-    p.alpha = d->alpha;
-    p.width = d->width;
-    p.height = d->height;
-    p.crop_x = cx; p.crop_y = cy; p.crop_w = cw; p.crop_h = ch;
+    if(t->win_cap > 0) {
+        p.image = t->window;
+        p.alpha = t->window + t->win_bytes / 2;
+        p.width = cw;
+        p.height = ch;
+        p.crop_x = 0; p.crop_y = 0;
+        p.flags = MJX_PREP_WINDOW_PACKED;
+    }
+    else {
+        p.image = d->image;
+        p.alpha = d->alpha;
+        p.width = d->width;
+        p.height = d->height;
+        p.crop_x = cx; p.crop_y = cy;
+    }
+    p.crop_w = cw; p.crop_h = ch;
     p.off_x = bx; p.off_y = by;
     p.source = d->colorspace == MJ_COLORSPACE_RGB ? MJX_PREP_SOURCE_RGB : MJX_PREP_SOURCE_YCC;
-    p.target = cs == JCS_RGB ? MJX_PREP_TARGET_RGB : MJX_PREP_TARGET_YCC;
-    p.ncomp = 3;
-    p.flags = want_i16 ? MJX_PREP_TILES_I16 : 0;
+    p.target = cs == JCS_RGB ? MJX_PREP_TARGET_RGB : (cs == JCS_GRAYSCALE ? MJX_PREP_TARGET_GRAY : MJX_PREP_TARGET_YCC);
+    p.ncomp = ncomp;
+    p.flags |= want_i16 ? MJX_PREP_TILES_I16 : 0;
     w = (cw + bx + s->h_factor - 1) / s->h_factor * s->h_factor; /* whole MCUs (dropon.c:340-350) */
     h = (ch + by + s->v_factor - 1) / s->v_factor * s->v_factor;
-    t->ncomp = 3;
+    t->ncomp = ncomp;
     t->bytes = 0;
     t->i16 = want_i16 != 0;
-    for(c = 0; c < 3; c++) {
+    for(c = 0; c < ncomp; c++) {
         const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
         size_t    bytes;
         if(hs < 1 || vs < 1 || s->max_h_samp_factor % hs != 0 || s->max_v_samp_factor % vs != 0) return MJX_ERR_BAD_ARG;
@@ -300,15 +411,34 @@ static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COL
         t->cols[c] = w / (8 * (s->max_h_samp_factor / hs));
         t->rows[c] = h / (8 * (s->max_v_samp_factor / vs));
         bytes = (size_t)t->rows[c] * (size_t)t->cols[c] * 64 * (want_i16 ? sizeof(int16_t) : sizeof(float));
-        if((e = mjx_malloc((void **)&t->dev_tile[c], bytes)) != MJX_OK) return e;
-        if((e = mjx_malloc((void **)&t->dev_alpha[c], bytes)) != MJX_OK) return e;
+        if((e = dev_buffer(&t->dev_tile[c], &t->dev_cap[0][c], t->device, bytes)) != MJX_OK) return e;
+        if((e = dev_buffer(&t->dev_alpha[c], &t->dev_cap[1][c], t->device, bytes)) != MJX_OK) return e;
         p.tile[c] = t->dev_tile[c];
         p.alpha_tile[c] = t->dev_alpha[c];
         t->bytes += 2 * bytes;
     }
+    t1 = debug_tiles() ? now_ms() : 0;
     if((e = mjx_tiles_prepare(&p)) != MJX_OK) return e;
-    if((e = contents_schedule(t)) != MJX_OK) return e;
-    return window_copy(t, d, cx, cy, cw, ch);
+    t2 = debug_tiles() ? now_ms() : 0;
+    if(debug_tiles())
+        fprintf(stderr, "tilecache: window copy (%s) %.3f ms, device buffers %.3f ms, mjx_tiles_prepare %.3f ms\n", t->win_cap ? "pinned" : "malloc", t3 - t0, t1 - t3, t2 - t1);
+    return MJX_OK;
+}
+
+/* the combinations mjx_tiles_prepare reproduces (the others are libjpeg's: CMYK, gray overlays, 4:1:1 ...) */
+static int device_prep_covers(const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_sampling_t *s) {
+    const int ncomp = cs == JCS_GRAYSCALE ? 1 : 3;
+    int       c;
+    if(cs != JCS_YCbCr && cs != JCS_RGB && cs != JCS_GRAYSCALE) return 0;
+    if(d->colorspace != MJ_COLORSPACE_RGB && d->colorspace != MJ_COLORSPACE_YCC) return 0;
+    if(cs == JCS_RGB && d->colorspace != MJ_COLORSPACE_RGB) return 0;
+    if(s->h_factor <= 0 || s->v_factor <= 0) return 0;
+    for(c = 0; c < ncomp; c++) {
+        const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
+        if(hs < 1 || vs < 1 || s->max_h_samp_factor % hs != 0 || s->max_v_samp_factor % vs != 0) return 0;
+        if(s->max_h_samp_factor / hs > 2 || s->max_v_samp_factor / vs > 2) return 0;
+    }
+    return 1;
 }
 
 /* ---- is the device preparation THIS libjpeg's arithmetic? ----------------------------------------
@@ -359,9 +489,11 @@ static int device_prep_verified(const mj_dropon_t *like, J_COLOR_SPACE cs, mj_sa
         }
     }
     memset(&dev, 0, sizeof(dev));
+    (void)mjx_get_device(&dev.device);
     if(mj_compile_dropon(&cd, &probe, cs, s, 3, 5, 0, 0, W, H) != MJ_OK) return 0;
     if(contents_fill_device(&dev, &probe, cs, s, 3, 5, 0, 0, W, H, 0) != MJX_OK) equal = 0;
-    for(c = 0; equal && c < 3; c++) {
+    if(equal && cd.image_ncomponents != dev.ncomp) equal = 0;
+    for(c = 0; equal && c < dev.ncomp; c++) {
         const size_t n = (size_t)cd.image[c].nblocks * 64;
         float       *got;
         if(cd.image[c].nblocks != dev.rows[c] * dev.cols[c] || cd.alpha[c].nblocks != cd.image[c].nblocks) {
@@ -416,7 +548,21 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
     if(debug_tiles()) t1 = now_ms();
 
     if((t = lookup(key, params, device, d, cx, cy, cw, ch)) != NULL) {
+        int mine = 0;
         if(debug_tiles()) fprintf(stderr, "tilecache: hit   key %.3f ms, look-up + window compare %.3f ms (%dx%d)\n", t1 - t0, now_ms() - t1, cw, ch);
+        pthread_mutex_lock(&g_lock);
+        if(t->sched_state == 0) {
+            t->sched_state = 1;
+            mine = 1;
+        }
+        pthread_mutex_unlock(&g_lock);
+        if(mine) { /* the entry is used again: now its schedules pay */
+            const double ts = debug_tiles() ? now_ms() : 0;
+            rv = contents_schedule(t);
+            __sync_synchronize();
+            t->sched_state = rv == MJX_OK ? 2 : 3; /* 3: failed, composes go on without (the compose call reports a sick device) */
+            if(debug_tiles()) fprintf(stderr, "tilecache: schedules for the entry's second use %.3f ms\n", now_ms() - ts);
+        }
         *out = t;
         return MJ_OK;
     }
@@ -426,8 +572,9 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
      * reproduces (the usual colour cases) and the linked libjpeg is the one it reproduces; else by
      * libjpeg on the host, uploaded afterwards */
     memset(&fresh, 0, sizeof(fresh));
+    fresh.device = device; /* recycled device buffers are looked up by device */
     rv = MJX_ERR_BAD_ARG;
-    if(device_prep_enabled() && (cs == JCS_YCbCr || cs == JCS_RGB) && device_prep_verified(d, cs, s))
+    if(device_prep_enabled() && device_prep_covers(d, cs, s) && device_prep_verified(d, cs, s))
         rv = contents_fill_device(&fresh, d, cs, s, bx, by, cx, cy, cw, ch, env_on("MJ_TILES_I16"));
     if(rv == MJX_OK) {
         __sync_fetch_and_add(&mjh_tiles_gpu_prepared, 1);
@@ -436,6 +583,7 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
     else {
         const int declined = rv == MJX_ERR_BAD_ARG;
         contents_free(&fresh);
+        fresh.device = device;
         if(!declined) return mjh_from_mjx(rv);
         rv = mj_compile_dropon(&cd, d, cs, s, bx, by, cx, cy, cw, ch);
         if(rv != MJ_OK) return rv;
@@ -498,8 +646,10 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
         t->stamp = ++g_clock;
     }
     pthread_mutex_unlock(&g_lock);
+    if(debug_tiles()) t3 = now_ms();
     for(i = 0; i < nevicted; i++) contents_free(&evicted[i]);
     contents_free(&fresh); /* every slot busy: nothing is kept */
+    if(debug_tiles()) fprintf(stderr, "tilecache: freeing %d evicted entries %.3f ms\n", nevicted, now_ms() - t3);
     *out = t;              /* NULL: the caller takes the uncached path */
     return MJ_OK;
 }
@@ -519,4 +669,8 @@ void mjh_tiles_component(const struct mjh_tiles *t, int c, int *rows, int *cols,
     *dev_alpha = t->dev_alpha[c];
 }
 int mjh_tiles_i16(const struct mjh_tiles *t) { return t->i16; }
-const mjx_tile_schedule_t *mjh_tiles_schedule(const struct mjh_tiles *t, int c) { return t->sched[c]; }
+const mjx_tile_schedule_t *mjh_tiles_schedule(const struct mjh_tiles *t, int c) {
+    if(t->sched_state != 2) return NULL;
+    __sync_synchronize();
+    return t->sched[c];
+}

@@ -100,8 +100,6 @@ def test_batch_pipeline_keeps_images_on_the_device_and_matches_the_reference(cli
     """batch mode decodes on the GPU and leaves the planes there (shadow.c): compose, effects and the
     encoder work on the device copy, libjpeg's host arrays are only filled when libjpeg itself has
     to write.  Every output must equal what the reference CLI writes for the same file and script."""
-    if sampling == "gray" and "-d" in script:
-        pytest.skip("the reference cannot prepare a colour dropon for a gray image")
     src = tmp_path / "in"
     src.mkdir()
     names = []

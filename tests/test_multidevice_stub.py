@@ -86,9 +86,11 @@ def test_batch_cli_shards_its_workers_over_two_devices(stubbed, tmp_path):
     per_dev = collections.Counter(next(iter(v)) for v in devs_of_thread.values())
     assert set(per_dev) == {"0", "1"} and max(per_dev.values()) <= 4, per_dev  # 8 workers: t mod 2
     composes = [kv for what, kv in rows if what == "compose"]
-    assert len(composes) == 32 * 3 and all(kv["schedule"] == "1" for kv in composes)
-    # one overlay, one target format, two devices: its tiles are prepared (and scheduled) once per device,
-    # or once more when two workers of a device miss at the same moment
+    assert len(composes) == 32 * 3
+    # one overlay, one target format, two devices: its tiles are prepared once per device (or once more when
+    # two workers of a device miss at the same moment) and scheduled when they are used the second time
+    with_sched = sum(kv["schedule"] == "1" for kv in composes)
+    assert with_sched >= 32 * 3 - 2 * 4 * 3 and with_sched < 32 * 3, with_sched
     scheds = collections.Counter(kv["device"] for what, kv in rows if what == "schedule")
     assert set(scheds) == {"0", "1"} and all(3 <= n <= 12 for n in scheds.values()), scheds
     # the same command on ONE device must write the same files (nothing depends on the sharding)
