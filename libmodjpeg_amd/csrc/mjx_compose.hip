@@ -330,6 +330,27 @@ MJX_DEV int16_t *dma_octet_coef_only(const DevJob &job, int o, int lane, const i
     return cptr;
 }
 
+// DC-only run: the JCOEF piece, the tile piece(s) and ONE piece that brings the first 16 bytes of every alpha
+// block (all 8 lanes of a block ask for the same 16 bytes: weight (0,0) is its first element)
+template <bool I16>
+MJX_DEV int16_t *dma_octet_dc_only(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned dC, unsigned dT, unsigned dW) {
+    const int bq = lane >> 4;
+    const int n = G[o * kWaveBlocks + (lane >> 3)];
+    int16_t  *cptr = job.coef + (size_t)plane_block_of(job, n) * 64 + (lane & 7) * 8;
+    dma16(cptr, dC);
+    if constexpr(I16) {
+        dma16_so(job.tile, (unsigned)n * 128u + (unsigned)(lane & 7) * 16u, dT);
+        dma16_so(job.alpha, (unsigned)n * 128u, dW);
+    }
+    else {
+        const int t_lo = G[o * kWaveBlocks + bq], t_hi = G[o * kWaveBlocks + 4 + bq];
+        dma16_so(job.tile, (unsigned)t_lo * 256u + t_in, dT);
+        dma16_so(job.tile, (unsigned)t_hi * 256u + t_in, dT + 1024);
+        dma16_so(job.alpha, (unsigned)n * 256u, dW);
+    }
+    return cptr;
+}
+
 template <bool I16>
 MJX_DEV int16_t *dma_octet_gather(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned a_in, unsigned dC, unsigned dT, unsigned dA) {
     const int bq = lane >> 4;
@@ -515,6 +536,24 @@ MJX_DEV void octet_zero_alpha(int16_t *cptr, const float *qrow, const uint4 c4) 
     octet_tail(cptr, qrow, cd, y);
 }
 
+// a block whose only weight is w = alpha[0][0]: the single term (k, l) = (0, 0) of compose.c:300-312 is
+// V_0(H_0(X)) * w with H_0 and V_0 both "twice the element" (convolve.c:36-45, :567-580), i.e. elementwise:
+// z = (float)(2.0 * x) = x + x, y = (float)(0.0 + (2.0 * z) * w) = fmaf(z, 2w, +0) (vstage_first) - the very
+// operations the general path performs, minus the two transpositions around them
+MJX_DEV void octet_dc_only(int16_t *cptr, const float *qrow, const uint4 c4, const float (&t)[8], float w) {
+    const uint4    q4 = *reinterpret_cast<const uint4 *>(qrow);
+    const unsigned cd[4] = {pk_mul_lo_u16(c4.x, q4.x), pk_mul_lo_u16(c4.y, q4.y), pk_mul_lo_u16(c4.z, q4.z), pk_mul_lo_u16(c4.w, q4.w)};
+    float          x[8], z[8], y[8];
+    static_for<4>([&](auto P) { // X = tile - (float)coef (compose.c:289-298)
+        x[2 * P] = t[2 * P] - s16_lo_to_f32(cd[P]);
+        x[2 * P + 1] = t[2 * P + 1] - s16_hi_to_f32(cd[P]);
+    });
+    static_for<8>([&](auto U) { z[U] = x[U] + x[U]; });
+    static_for<8>([&](auto U) { y[U] = 0.0f; });
+    vstage_first(y, z, w);
+    octet_tail(cptr, qrow, cd, y);
+}
+
 // one octet whose operands have landed in (pC, pT, pA): registers, blend, store to cptr
 MJX_DEV void octet_compute(int16_t *cptr, int lane, int b, int r, const float *qrow, const uint4 c4, const float4 t_lo, const float4 t_hi, const float4 a_lo,
                            const float4 a_hi, const float *pA, float *imgZ) {
@@ -607,6 +646,41 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
             int16_t *cn = cp;
             if(i + 1 < noct) cn = dma_octet_coef_only(job, i + 1, lane, rc.G, lds_addr(L.C[0]));
             octet_zero_alpha(cp, qrow, c4);
+            cp = cn;
+        }
+        return;
+    }
+
+    if(kind == kRunDcOnly) { // wave-uniform
+        // per octet: JCOEF piece, tile piece(s), one piece with the heads of the 8 alpha blocks; VMEM order as in
+        // the zero-alpha run (at the top of step i only the store of step i-1 is younger than octet i's pieces)
+        const int    ph = (b >> 1) & 1;
+        const double kdc = 0.3535534 * 0.3535534 / 1020.0; // dropon.c:548, for int16 tiles
+        int16_t     *cp = dma_octet_dc_only<I16>(job, 0, lane, rc.G, rc.t_in, lds_addr(L.C[0]), lds_addr(L.T[0]), lds_addr(L.A[0]));
+#pragma unroll 1
+        for(int i = 0; i < noct; ++i) {
+            wait_vmcnt_n(i < 1 ? i : 1);
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(L.C[0] + lane * 4);
+            float       t[8], w;
+            if constexpr(I16) {
+                const uint4    ti4 = *reinterpret_cast<const uint4 *>(L.T[0] + lane * 4);
+                const unsigned a0 = *reinterpret_cast<const unsigned *>(L.A[0] + lane * 4);
+                const unsigned tw[4] = {ti4.x, ti4.y, ti4.z, ti4.w};
+                static_for<4>([&](auto P) {
+                    t[2 * P] = s16_lo_to_f32(tw[P]);
+                    t[2 * P + 1] = s16_hi_to_f32(tw[P]);
+                });
+                w = (float)((double)s16_lo_to_f32(a0) * kdc);
+            }
+            else {
+                const float4 t_lo = *reinterpret_cast<const float4 *>(L.T[0] + lane * 8 + 4 * ph), t_hi = *reinterpret_cast<const float4 *>(L.T[0] + lane * 8 + 4 - 4 * ph);
+                t[0] = t_lo.x; t[1] = t_lo.y; t[2] = t_lo.z; t[3] = t_lo.w; t[4] = t_hi.x; t[5] = t_hi.y; t[6] = t_hi.z; t[7] = t_hi.w;
+                w = L.A[0][lane * 4];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int16_t *cn = cp;
+            if(i + 1 < noct) cn = dma_octet_dc_only<I16>(job, i + 1, lane, rc.G, rc.t_in, lds_addr(L.C[0]), lds_addr(L.T[0]), lds_addr(L.A[0]));
+            octet_dc_only(cp, qrow, c4, t, w);
             cp = cn;
         }
         return;

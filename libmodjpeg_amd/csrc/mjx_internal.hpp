@@ -27,8 +27,11 @@ static_assert(sizeof(DevJob) == 56, "DevJob layout");
 enum RunKind : int32_t {
     kRunConsecutive = 0, // the octets are consecutive tile blocks, `first` = first tile block
     kRunGather = 1,      // they are listed in the plan's gather table, `first` = first octet there
-    kRunZeroAlpha = 2    // gather octets of blocks whose 64 weights are all zero: the reference skips every
+    kRunZeroAlpha = 2,   // gather octets of blocks whose 64 weights are all zero: the reference skips every
                          // term of such a block (convolve.c:32), Y stays +0, only the JCOEF block travels
+    kRunDcOnly = 3       // gather octets of blocks whose ONLY weight is (0,0) - every block an opaque or evenly
+                         // translucent part of an overlay covers: of the alpha block only its first 16 bytes
+                         // travel, and the one term left, V_0(H_0(X)) * w = 2X * 2w, needs no transposition
 };
 struct Run {
     DevJob         job;

@@ -101,9 +101,9 @@ struct Segment {
 };
 
 struct SchedStats {
-    int64_t blocks = 0, octets = 0, gather_octets = 0, zero_octets = 0, block_terms = 0, union_terms = 0;
+    int64_t blocks = 0, octets = 0, gather_octets = 0, zero_octets = 0, dc_octets = 0, block_terms = 0, union_terms = 0;
     void add(const SchedStats &o) {
-        blocks += o.blocks; octets += o.octets; gather_octets += o.gather_octets; zero_octets += o.zero_octets;
+        blocks += o.blocks; octets += o.octets; gather_octets += o.gather_octets; zero_octets += o.zero_octets; dc_octets += o.dc_octets;
         block_terms += o.block_terms; union_terms += o.union_terms;
     }
 };
@@ -241,7 +241,7 @@ struct Tables {
 // 505 / 2215 at 1 / 10 / 64 terms in 1 / 4 / 8 columns): 121 fixed + 20.6 per column of weights in use
 // (one H stage and its transposition) + 30.1 per term; an octet cannot be faster than its 5 KiB take
 // to stream, which is what an A2 octet (505) needs as well: below that the memory system is the bound.
-constexpr float kCostFixed = 121.0f, kCostColumn = 20.6f, kCostTerm = 30.1f, kCostMemory = 480.0f, kCostZeroAlpha = 170.0f;
+constexpr float kCostFixed = 121.0f, kCostColumn = 20.6f, kCostTerm = 30.1f, kCostMemory = 480.0f, kCostZeroAlpha = 170.0f, kCostDcOnly = 340.0f;
 
 inline unsigned pattern_columns(uint64_t p) { // bit l: some weight (k, l) is used
     p |= p >> 32;
@@ -274,7 +274,7 @@ void schedule_tiles(const uint64_t *pattern, int nblocks, bool skip_zero, std::v
     }
     // what the blocks cost as they lie
     bool     all_same = true;
-    int      nzero = 0;
+    int      nzero = 0, ndc = 0;
     float    cost_cons = 0.0f;
     int64_t  terms = 0, union_cons = 0;
     for(int o = 0; o < noct_all; ++o) {
@@ -284,19 +284,22 @@ void schedule_tiles(const uint64_t *pattern, int nblocks, bool skip_zero, std::v
             u |= p;
             all_same = all_same && p == pattern[0];
             nzero += p == 0;
+            ndc += p == 1;
             terms += __builtin_popcountll(p);
         }
         cost_cons += octet_cost(u);
         union_cons += __builtin_popcountll(u);
     }
     st.block_terms += terms;
-    const bool split_zero = skip_zero && nzero >= kWaveBlocks;
+    // with the caller's promise that alpha is final: blocks without weights travel without tiles, blocks whose
+    // only weight is (0,0) with the head of their alpha block only
+    const bool split_zero = skip_zero && nzero >= kWaveBlocks, split_dc = skip_zero && ndc >= kWaveBlocks;
     auto consecutive = [&]() {
         segs.push_back(Segment{kRunConsecutive, cost_class(cost_cons / (float)noct_all), 0, noct_all});
         st.octets += noct_all;
         st.union_terms += union_cons;
     };
-    if(all_same && !(split_zero && pattern[0] == 0)) return consecutive();
+    if(all_same && !(split_zero && pattern[0] == 0) && !(split_dc && pattern[0] == 1)) return consecutive();
 
     // sorted order: densest first; among blocks of similar density those that use the same rows and
     // columns of weights lie together, then equal patterns.  Real masks have few DISTINCT patterns (an
@@ -340,16 +343,17 @@ void schedule_tiles(const uint64_t *pattern, int nblocks, bool skip_zero, std::v
         return a.p < b.p;
     });
     std::vector<Key> keys;
-    std::vector<int> zeros;
+    std::vector<int> zeros, dconly;
     keys.reserve((size_t)nblocks);
     for(const Group &g : groups) {
         for(int n = g.head; n >= 0; n = next[(size_t)n]) {
             if(split_zero && g.p == 0) zeros.push_back(n);
+            else if(split_dc && g.p == 1) dconly.push_back(n);
             else keys.push_back(Key{g.p, n});
         }
     }
     const int noct_sorted = (int)((keys.size() + kWaveBlocks - 1) / kWaveBlocks);
-    float     cost_sorted = kCostZeroAlpha * (float)((zeros.size() + kWaveBlocks - 1) / kWaveBlocks);
+    float     cost_sorted = kCostZeroAlpha * (float)((zeros.size() + kWaveBlocks - 1) / kWaveBlocks) + kCostDcOnly * (float)((dconly.size() + kWaveBlocks - 1) / kWaveBlocks);
     std::vector<uint64_t> unions((size_t)noct_sorted);
     for(int o = 0; o < noct_sorted; ++o) {
         uint64_t u = 0;
@@ -377,6 +381,16 @@ void schedule_tiles(const uint64_t *pattern, int nblocks, bool skip_zero, std::v
     }
     st.octets += noct_sorted;
     st.gather_octets += noct_sorted;
+    if(!dconly.empty()) {
+        base = (int)(gather.size() / kWaveBlocks);
+        const int nd = (int)((dconly.size() + kWaveBlocks - 1) / kWaveBlocks);
+        segs.push_back(Segment{kRunDcOnly, 0, base, nd});
+        for(int i = 0; i < nd * kWaveBlocks; ++i) gather.push_back(dconly[(size_t)i < dconly.size() ? (size_t)i : dconly.size() - 1]);
+        st.octets += nd;
+        st.gather_octets += nd;
+        st.dc_octets += nd;
+        st.union_terms += nd;
+    }
     if(!zeros.empty()) {
         base = (int)(gather.size() / kWaveBlocks);
         const int nz = (int)((zeros.size() + kWaveBlocks - 1) / kWaveBlocks);
@@ -619,6 +633,7 @@ void fill_stats(mjx_plan_stats_t *out, const SchedStats &st, int64_t runs, int s
     out->octets = st.octets;
     out->gather_octets = st.gather_octets;
     out->zero_alpha_octets = st.zero_octets;
+    out->dc_only_octets = st.dc_octets;
     out->runs = runs;
     out->block_terms = st.block_terms;
     out->union_terms = st.union_terms;

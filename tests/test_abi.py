@@ -44,7 +44,7 @@ def test_ctypes_mirrors_have_the_c_layout(hiplib, tmp_path):
     mirrors = {
         "mjx_rect_job_t": (hiplib.RectJob, ["coef", "blocks_per_row", "qtable", "flags"]),
         "mjx_host_rect_t": (hiplib.HostRect, ["rows_ptr", "q", "blocks_per_row", "flags", "schedule"]),
-        "mjx_plan_stats_t": (hiplib.PlanStats, ["blocks", "runs", "union_terms", "resident_waves", "run_octets_min"]),
+        "mjx_plan_stats_t": (hiplib.PlanStats, ["blocks", "runs", "union_terms", "dc_only_octets", "resident_waves", "run_octets_min"]),
         "mjx_dc_job_t": (hiplib.DcJob, ["coef", "value", "q0"]),
         "mjx_tileprep_t": (hiplib.TilePrep, ["image", "crop_w", "off_y", "source", "ncomp", "h_samp", "v_samp", "tile", "alpha_tile", "flags"]),
         "mjx_huff_table_t": (E.HuffTable, ["code", "size"]),

@@ -356,6 +356,11 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
         alpha[rng.random((n, 64)) < 0.002] = np.float32(1e-41)
         if seed % 2 == 0:
             alpha[rng.random((n, 64)) < 0.001] = np.float32("nan")
+        # blocks whose only weight is (0,0) (what an opaque or evenly translucent part of an overlay gives):
+        # exactly 0.25 (opaque), ordinary, denormal, negative, infinite and NaN weights
+        dc = rng.random(n) < 0.2
+        alpha[dc] = 0
+        alpha[dc, 0] = rng.choice(np.array([0.25, 0.1, 1e-41, -0.3, np.inf, np.nan, 3e38], np.float32), int(dc.sum()))
         alpha = np.ascontiguousarray(alpha, np.float32)
         host.append((coef, tile, alpha))
     results = []
@@ -375,6 +380,7 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
             assert st.block_terms == terms, "zero patterns of the alpha blocks"
             assert st.union_terms >= (st.block_terms + 7) // 8
             assert (st.zero_alpha_octets > 0) == bool(flags & MJX_PLAN_ALPHA_IS_FINAL)
+            assert (st.dc_only_octets > 0) == bool(flags & MJX_PLAN_ALPHA_IS_FINAL)
         check(lib().mjx_compose_run(plan, None), "run")
         torch.cuda.synchronize()
         lib().mjx_compose_plan_destroy(plan)
@@ -407,6 +413,9 @@ def test_int16_tile_plans_vs_oracle_on_full_range_values(mj, seed):
         tile = rng.integers(-32768, 32768, (n, 64)).astype(np.int16)
         alpha = rng.integers(-32768, 32768, (n, 64)).astype(np.int16)
         alpha = np.where(rng.random((n, 64)) < rng.choice([0.0, 0.05, 0.3, 1.0], n)[:, None], alpha, np.int16(0)).astype(np.int16)
+        dc = rng.random(n) < 0.25  # blocks whose only weight is (0,0): the whole int16 range, 2040 (opaque) among them
+        alpha[dc] = 0
+        alpha[dc, 0] = rng.choice(np.array([2040, 1, -1, 32767, -32768, 777], np.int16), int(dc.sum()))
         host.append((coef, np.ascontiguousarray(tile), np.ascontiguousarray(alpha)))
     for flags in (0, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL):
         dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
