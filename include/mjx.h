@@ -378,6 +378,14 @@ typedef struct mjx_huff_dscan {
  * outside the tables.  The caller then uses its ordinary decoder, which owns those semantics. */
 int mjx_huff_decode_host(const mjx_huff_dscan_t *scan);
 
+/* The decoder's first step on its own (pure host code, no device; a test seam): scan data as it stands in
+ * the file -> the bytes without 0xFF00 stuffing and RSTn markers, and the offset (in `out`) at which every
+ * restart segment starts (segment_offsets[0] = 0).  `out` needs nbytes + 32 bytes.  form 0: what the
+ * decoder uses on this host (AVX2 when the CPU has it), 1: the portable form, 2: the AVX2 form
+ * (MJX_ERR_NO_DEVICE without AVX2).  MJX_ERR_BAD_ARG: not a plain run of [segment RSTn]* segment EOI. */
+int mjx_huff_unstuff(const uint8_t *data, size_t nbytes, uint8_t *out, size_t *outlen, uint64_t *segment_offsets, int64_t max_segments, int64_t *nsegments,
+                     int form);
+
 /* ---- synthetic workload generators (bench / test support; definition: mjx_synth.h) ------
  * The *_batch forms fill one array of a whole batch with ONE launch: image i of the batch (global
  * index image0 + i) starts image_stride_blocks * 64 elements after image i-1.  regime: MJX_ALPHA_*

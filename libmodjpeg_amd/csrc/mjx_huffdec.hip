@@ -32,6 +32,7 @@
 
 #include <math.h>
 #include <new>
+#include <immintrin.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -439,9 +440,27 @@ bool derive(const mjx_huff_spec_t *spec, TableBuilder &B, bool is_dc) {
 // scan data as it stands in the file -> bytes without stuffing, the restart segments' offsets.
 // false when the data is not a plain run of [segment RSTn]* segment EOI (fill bytes, markers out of
 // sequence, no EOI inside the buffer, ...: libjpeg knows what to do with those)
-bool unstuff(const unsigned char *src, size_t n, unsigned char *dst, size_t *outlen, unsigned long long *segs, long long max_segs, long long *nsegs) {
-    // ~3 GB/s on the host (0.16 ms for a 1080p quality-85 scan): bound by the unpredictable branch per
-    // 0xFF, not by the copy — a 16-byte SIMD scan measured the same
+// what follows a 0xFF at src[i] (i + 1 < n): 0 = a stuffed zero was skipped, go on; 1 = EOI, done; -1 = not ours
+static inline int after_ff(const unsigned char *src, size_t &i, unsigned char *dst, size_t &o, unsigned long long *segs, long long max_segs, long long &ns, int &expect) {
+    const unsigned char marker = src[i + 1];
+    if(marker == 0x00) {
+        dst[o++] = 0xFF;
+        i += 2;
+        return 0;
+    }
+    if(marker >= 0xD0 && marker <= 0xD7) {
+        if(marker != 0xD0 + expect || ns >= max_segs) return -1;
+        expect = (expect + 1) & 7;
+        segs[ns++] = o;
+        i += 2;
+        return 0;
+    }
+    return marker == 0xD9 ? 1 : -1;
+}
+
+// portable form: memchr to the next 0xFF, memcpy of the run in front of it.  ~3.7 GB/s (0.136 ms for a 1080p
+// quality-85 scan): a 0xFF comes every ~250 bytes, so the time goes into two library calls per short run
+static bool unstuff_scalar(const unsigned char *src, size_t n, unsigned char *dst, size_t *outlen, unsigned long long *segs, long long max_segs, long long *nsegs) {
     size_t    i = 0, o = 0;
     long long ns = 1;
     int       expect = 0;
@@ -454,28 +473,79 @@ bool unstuff(const unsigned char *src, size_t n, unsigned char *dst, size_t *out
         o += run;
         i += run;
         if(i + 1 >= n) return false;
-        const unsigned char marker = src[i + 1];
-        if(marker == 0x00) {
-            dst[o++] = 0xFF;
-        }
-        else if(marker >= 0xD0 && marker <= 0xD7) {
-            if(marker != 0xD0 + expect || ns >= max_segs) return false;
-            expect = (expect + 1) & 7;
-            segs[ns++] = o;
-        }
-        else if(marker == 0xD9) {
+        const int r = after_ff(src, i, dst, o, segs, max_segs, ns, expect);
+        if(r < 0) return false;
+        if(r > 0) {
             *outlen = o;
             *nsegs = ns;
             return true;
         }
-        else {
-            return false;
-        }
-        i += 2;
     }
 }
 
+// AVX2 form: 32 bytes are copied unconditionally and tested for 0xFF in the same pass; on a hit the copy is
+// kept up to the 0xFF and the byte behind it is dealt with.  No library call per run, one well-predicted
+// branch per 32 bytes.  dst must have 32 bytes of slack behind the unstuffed length (the caller's buffer is
+// padded by more than that for the decoder's overshoot anyway).
+__attribute__((target("avx2"))) static bool unstuff_avx2(const unsigned char *src, size_t n, unsigned char *dst, size_t *outlen, unsigned long long *segs,
+                                                       long long max_segs, long long *nsegs) {
+    size_t        i = 0, o = 0;
+    long long     ns = 1;
+    int           expect = 0;
+    const __m256i ff = _mm256_set1_epi8((char)0xFF);
+    segs[0] = 0;
+    for(;;) {
+        if(i + 33 <= n) {
+            const __m256i  v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+            const unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, ff));
+            _mm256_storeu_si256(reinterpret_cast<__m256i *>(dst + o), v);
+            if(m == 0) {
+                i += 32;
+                o += 32;
+                continue;
+            }
+            const unsigned p = (unsigned)__builtin_ctz(m); // the bytes in front of the first 0xFF stay; src[i + p + 1] exists
+            i += p;
+            o += p;
+        }
+        else { // the last bytes of the buffer
+            while(i < n && src[i] != 0xFF) dst[o++] = src[i++];
+            if(i + 1 >= n) return false;
+        }
+        const int r = after_ff(src, i, dst, o, segs, max_segs, ns, expect);
+        if(r < 0) return false;
+        if(r > 0) {
+            *outlen = o;
+            *nsegs = ns;
+            return true;
+        }
+    }
+}
+
+bool unstuff(const unsigned char *src, size_t n, unsigned char *dst, size_t *outlen, unsigned long long *segs, long long max_segs, long long *nsegs) {
+    static const bool avx2 = __builtin_cpu_supports("avx2") && getenv("MJX_UNSTUFF_SCALAR") == nullptr;
+    return avx2 ? unstuff_avx2(src, n, dst, outlen, segs, max_segs, nsegs) : unstuff_scalar(src, n, dst, outlen, segs, max_segs, nsegs);
+}
+
 } // namespace
+
+// test seam (pure host code): the decoder's first step on its own
+extern "C" int mjx_huff_unstuff(const uint8_t *data, size_t nbytes, uint8_t *out, size_t *outlen, uint64_t *segment_offsets, int64_t max_segments, int64_t *nsegments,
+                                int form) {
+    if(data == nullptr || out == nullptr || outlen == nullptr || segment_offsets == nullptr || nsegments == nullptr) return MJX_ERR_NULL_DATA;
+    if(max_segments < 1 || form < 0 || form > 2) return MJX_ERR_BAD_ARG;
+    unsigned long long *segs = reinterpret_cast<unsigned long long *>(segment_offsets);
+    long long           ns = 0;
+    bool                ok;
+    if(form == 1) ok = unstuff_scalar(data, nbytes, out, outlen, segs, max_segments, &ns);
+    else if(form == 2) {
+        if(!__builtin_cpu_supports("avx2")) return MJX_ERR_NO_DEVICE;
+        ok = unstuff_avx2(data, nbytes, out, outlen, segs, max_segments, &ns);
+    }
+    else ok = unstuff(data, nbytes, out, outlen, segs, max_segments, &ns);
+    *nsegments = ns;
+    return ok ? MJX_OK : MJX_ERR_BAD_ARG;
+}
 
 // ---- combining concurrent callers into one batch ------------------------------------------
 namespace {

@@ -264,6 +264,10 @@ int mjx_tiles_prepare(const mjx_tileprep_t *p) { (void)p; NEED_DEVICE(); return 
 int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char **out, size_t *outlen) { (void)scan; (void)out; (void)outlen; NEED_DEVICE(); return MJX_ERR_BAD_ARG; }
 int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) { (void)scan; NEED_DEVICE(); return MJX_ERR_BAD_ARG; }
 int mjx_huff_optimal_table(const uint32_t freq[256], mjx_huff_spec_t *table) { (void)freq; (void)table; return MJX_ERR_BAD_ARG; }
+int mjx_huff_unstuff(const uint8_t *data, size_t nbytes, uint8_t *out, size_t *outlen, uint64_t *segment_offsets, int64_t max_segments, int64_t *nsegments, int form) {
+    (void)data; (void)nbytes; (void)out; (void)outlen; (void)segment_offsets; (void)max_segments; (void)nsegments; (void)form;
+    return MJX_ERR_BAD_ARG;
+}
 
 /* everything below belongs to the plan / test-seam / generator API the drop-in's host code never calls */
 #define UNUSED_INT(name, args) int name args { return MJX_ERR_NO_DEVICE; }
