@@ -132,6 +132,7 @@ typedef struct mjx_plan_stats {
     int64_t blocks, octets, gather_octets, zero_alpha_octets, runs;
     int64_t block_terms, union_terms;
     int64_t dc_only_octets; /* octets of blocks whose only weight is (0,0): only the head of their alpha blocks travels */
+    int64_t union_terms_consecutive; /* what union_terms would be with every octet 8 consecutive blocks (over all of them) */
     int32_t resident_waves; /* wavefronts of the compose kernel the device holds at once: what runs are cut for */
     int32_t run_octets_max, run_octets_min;
     int32_t reserved;

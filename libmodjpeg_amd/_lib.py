@@ -49,7 +49,7 @@ class HostRect(ctypes.Structure):
 class PlanStats(ctypes.Structure):
     """struct mjx_plan_stats (include/mjx.h)"""
     _fields_ = [("blocks", ctypes.c_int64), ("octets", ctypes.c_int64), ("gather_octets", ctypes.c_int64), ("zero_alpha_octets", ctypes.c_int64),
-                ("runs", ctypes.c_int64), ("block_terms", ctypes.c_int64), ("union_terms", ctypes.c_int64), ("dc_only_octets", ctypes.c_int64),
+                ("runs", ctypes.c_int64), ("block_terms", ctypes.c_int64), ("union_terms", ctypes.c_int64), ("dc_only_octets", ctypes.c_int64), ("union_terms_consecutive", ctypes.c_int64),
                 ("resident_waves", ctypes.c_int32), ("run_octets_max", ctypes.c_int32), ("run_octets_min", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
     def as_dict(self):
@@ -57,6 +57,7 @@ class PlanStats(ctypes.Structure):
         real = d["octets"] - d["zero_alpha_octets"]  # (DC-only octets count with a union of one term)
         d["mean_union_terms_per_octet"] = d["union_terms"] / real if real and d["union_terms"] else None
         d["mean_terms_per_block"] = d["block_terms"] / d["blocks"] if d["blocks"] and d["block_terms"] else None
+        d["mean_union_terms_per_octet_consecutive"] = d["union_terms_consecutive"] / ((d["blocks"] + 7) // 8) if d["union_terms_consecutive"] else None
         return d
 
 

@@ -101,8 +101,9 @@ struct Segment {
 };
 
 struct SchedStats {
-    int64_t blocks = 0, octets = 0, gather_octets = 0, zero_octets = 0, dc_octets = 0, block_terms = 0, union_terms = 0;
+    int64_t blocks = 0, octets = 0, gather_octets = 0, zero_octets = 0, dc_octets = 0, block_terms = 0, union_terms = 0, union_consecutive = 0;
     void add(const SchedStats &o) {
+        union_consecutive += o.union_consecutive;
         blocks += o.blocks; octets += o.octets; gather_octets += o.gather_octets; zero_octets += o.zero_octets; dc_octets += o.dc_octets;
         block_terms += o.block_terms; union_terms += o.union_terms;
     }
@@ -291,6 +292,7 @@ void schedule_tiles(const uint64_t *pattern, int nblocks, bool skip_zero, std::v
         union_cons += __builtin_popcountll(u);
     }
     st.block_terms += terms;
+    st.union_consecutive += union_cons;
     // with the caller's promise that alpha is final: blocks without weights travel without tiles, blocks whose
     // only weight is (0,0) with the head of their alpha block only
     const bool split_zero = skip_zero && nzero >= kWaveBlocks, split_dc = skip_zero && ndc >= kWaveBlocks;
@@ -634,6 +636,7 @@ void fill_stats(mjx_plan_stats_t *out, const SchedStats &st, int64_t runs, int s
     out->gather_octets = st.gather_octets;
     out->zero_alpha_octets = st.zero_octets;
     out->dc_only_octets = st.dc_octets;
+    out->union_terms_consecutive = st.union_consecutive;
     out->runs = runs;
     out->block_terms = st.block_terms;
     out->union_terms = st.union_terms;
