@@ -22,9 +22,10 @@
 // Supported: three components, target YCbCr (overlay RGB: converted; overlay YCbCr: as is) or RGB
 // (overlay RGB), every component at full resolution or subsampled 2:1 in either direction (4:4:4,
 // 4:2:2, 4:4:0, 4:2:0); one component, target grayscale (overlay RGB: libjpeg's Y; overlay YCbCr: its
-// first component).  Everything else (4:1:1 and other ratios above 2: libjpeg folds only ONE halving
-// into the transform and box-filters the rest, CMYK ...) returns MJX_ERR_BAD_ARG and the caller
-// prepares the tiles with libjpeg as before.
+// first component); a component subsampled 4:1 horizontally (4:1:1, 4:1:0): libjpeg folds only ONE halving
+// into the transform and makes the other with its h2v1 box filter, reproduced in prep_block.  Everything
+// else (vertical ratios above 2, CMYK ...) returns MJX_ERR_BAD_ARG and the caller prepares the tiles with
+// libjpeg as before.
 //
 // One wavefront per output block: the C x R samples go to LDS (colour conversion on the way),
 // pass 1 along the rows (R x 8 outputs), pass 2 down the columns (8 x 8), quantisation, float.
@@ -42,6 +43,7 @@ struct PrepComp {
     int32_t rows, cols;     // blocks
     int32_t nx, ny;         // samples per block: 8 or 16 in each direction
     int32_t first;          // index of this component's first block in the launch
+    int32_t pre;            // 2: the samples are first averaged in horizontal pairs (a 4:1 ratio: see prep_block), else 1
 };
 
 struct PrepJob {
@@ -83,21 +85,33 @@ MJX_FDCT(16, 16);
 MJX_FDCT(16, 8);
 MJX_FDCT(8, 16);
 
-template <int C, int R> __device__ __forceinline__ void prep_block(const PrepJob &job, int c, int kind, int brow, int bcol, float *out, int lane, int (*s)[16], int (*d1)[8]) {
+template <int C, int R> __device__ __forceinline__ void prep_block(const PrepJob &job, int c, int kind, int brow, int bcol, float *out, int lane, int (*s)[16], int (*d1)[8], int pre) {
     using T = Fdct<C, R>;
     const int *M1 = T::M1(), *M2 = T::M2(), *B1 = T::B1(), *S1 = T::S1(), *B2 = T::B2(), *S2 = T::S2();
     const unsigned char *pix = kind == 0 ? job.image : job.alpha;
     // samples: canvas pixel (x, y) is overlay window pixel (x - off_x, y - off_y), zero outside it
-    for(int i = lane; i < C * R; i += 64) {
-        const int sy = i / C, sx = i - sy * C;
-        const int wx = bcol * C + sx - job.off_x, wy = brow * R + sy - job.off_y;
-        int r = 0, g = 0, b = 0;
+    auto sample = [&](int cx, int cy) { // canvas pixel (cx, cy) of this component, colour-converted
+        const int wx = cx - job.off_x, wy = cy - job.off_y;
+        int       r = 0, g = 0, b = 0;
         if(wx >= 0 && wx < job.crop_w && wy >= 0 && wy < job.crop_h) {
             const unsigned char *p = pix + ((size_t)wy * job.crop_w + wx) * 3;
             r = p[0]; g = p[1]; b = p[2];
         }
         // the alpha canvas is never converted (reference dropon.c:389-402 hands it over in the target's own space)
-        s[sy][sx] = (kind == 0 && job.convert) ? ycc_of_rgb(c, r, g, b) : (c == 0 ? r : (c == 1 ? g : b));
+        return (kind == 0 && job.convert) ? ycc_of_rgb(c, r, g, b) : (c == 0 ? r : (c == 1 ? g : b));
+    };
+    for(int i = lane; i < C * R; i += 64) {
+        const int sy = i / C, sx = i - sy * C;
+        if(pre == 2) {
+            // a component subsampled 4:1 horizontally (4:1:1, 4:1:0): IJG 9 folds ONE halving into the transform
+            // (16 samples per row) and makes the other with jcsample.c h2v1_downsample on the colour-converted
+            // samples: (a + b + bias) >> 1, bias alternating 0, 1 along the output row from 0
+            const int ox = bcol * C + sx;
+            s[sy][sx] = (sample(2 * ox, brow * R + sy) + sample(2 * ox + 1, brow * R + sy) + (ox & 1)) >> 1;
+        }
+        else {
+            s[sy][sx] = sample(bcol * C + sx, brow * R + sy);
+        }
     }
     __syncthreads();
     for(int i = lane; i < R * 8; i += 64) { // pass 1: row r, output l
@@ -141,10 +155,10 @@ __global__ __launch_bounds__(64) void tileprep_kernel(PrepJob job) {
     const PrepComp pc = job.comp[c];
     const int      blk = id - pc.first, brow = blk / pc.cols, bcol = blk - brow * pc.cols;
     float         *out = (kind == 0 ? pc.tile : pc.alpha) + (size_t)blk * (job.i16 ? 32 : 64); // an int16 block is 32 floats long
-    if(pc.nx == 8 && pc.ny == 8) prep_block<8, 8>(job, c, kind, brow, bcol, out, lane, s, d1);
-    else if(pc.nx == 16 && pc.ny == 16) prep_block<16, 16>(job, c, kind, brow, bcol, out, lane, s, d1);
-    else if(pc.nx == 16) prep_block<16, 8>(job, c, kind, brow, bcol, out, lane, s, d1);
-    else prep_block<8, 16>(job, c, kind, brow, bcol, out, lane, s, d1);
+    if(pc.nx == 8 && pc.ny == 8) prep_block<8, 8>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre);
+    else if(pc.nx == 16 && pc.ny == 16) prep_block<16, 16>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre);
+    else if(pc.nx == 16) prep_block<16, 8>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre);
+    else prep_block<8, 16>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre);
 }
 
 } // namespace mjx
@@ -185,12 +199,14 @@ extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
     for(int c = 0; c < ncomp; ++c) {
         if(hmax % p->h_samp[c] != 0 || vmax % p->v_samp[c] != 0) return MJX_ERR_BAD_ARG;
         const int fx = hmax / p->h_samp[c], fy = vmax / p->v_samp[c];
-        if((fx != 1 && fx != 2) || (fy != 1 && fy != 2)) return MJX_ERR_BAD_ARG; // 8x8, 16x16, 16x8, 8x16 transforms only
+        // 8x8, 16x16, 16x8, 8x16 transforms; a horizontal ratio of 4 = h2v1 box filter + a 16-wide transform
+        if((fx != 1 && fx != 2 && fx != 4) || (fy != 1 && fy != 2)) return MJX_ERR_BAD_ARG;
         if(p->tile[c] == nullptr || p->alpha_tile[c] == nullptr) return MJX_ERR_NULL_DATA;
         job.comp[c].tile = p->tile[c];
         job.comp[c].alpha = p->alpha_tile[c];
-        job.comp[c].nx = 8 * fx;
+        job.comp[c].nx = fx == 1 ? 8 : 16;
         job.comp[c].ny = 8 * fy;
+        job.comp[c].pre = fx == 4 ? 2 : 1;
         job.comp[c].cols = (int32_t)(W / (8 * fx));
         job.comp[c].rows = (int32_t)(H / (8 * fy));
         job.comp[c].first = (int32_t)total;

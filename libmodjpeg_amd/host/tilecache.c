@@ -369,7 +369,7 @@ static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COL
     for(c = 0; c < ncomp; c++) { /* formats the device does not reproduce are declined before anything is allocated or copied */
         const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
         if(hs < 1 || vs < 1 || s->max_h_samp_factor % hs != 0 || s->max_v_samp_factor % vs != 0) return MJX_ERR_BAD_ARG;
-        if(s->max_h_samp_factor / hs > 2 || s->max_v_samp_factor / vs > 2) return MJX_ERR_BAD_ARG;
+        if((s->max_h_samp_factor / hs > 2 && s->max_h_samp_factor / hs != 4) || s->max_v_samp_factor / vs > 2) return MJX_ERR_BAD_ARG;
     }
     /* the entry's copy of the window first: when it is pinned it is also the upload source */
     if((e = window_copy(t, d, cx, cy, cw, ch)) != MJX_OK) return e;
@@ -404,8 +404,6 @@ static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COL
     for(c = 0; c < ncomp; c++) {
         const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
         size_t    bytes;
-        if(hs < 1 || vs < 1 || s->max_h_samp_factor % hs != 0 || s->max_v_samp_factor % vs != 0) return MJX_ERR_BAD_ARG;
-        if(s->max_h_samp_factor / hs > 2 || s->max_v_samp_factor / vs > 2) return MJX_ERR_BAD_ARG;
         p.h_samp[c] = hs;
         p.v_samp[c] = vs;
         t->cols[c] = w / (8 * (s->max_h_samp_factor / hs));
@@ -436,7 +434,7 @@ static int device_prep_covers(const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_s
     for(c = 0; c < ncomp; c++) {
         const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
         if(hs < 1 || vs < 1 || s->max_h_samp_factor % hs != 0 || s->max_v_samp_factor % vs != 0) return 0;
-        if(s->max_h_samp_factor / hs > 2 || s->max_v_samp_factor / vs > 2) return 0;
+        if((s->max_h_samp_factor / hs > 2 && s->max_h_samp_factor / hs != 4) || s->max_v_samp_factor / vs > 2) return 0;
     }
     return 1;
 }

@@ -94,7 +94,7 @@ BATCH_SCRIPTS = [
 ]
 
 
-@pytest.mark.parametrize("sampling", ["420", "444", "gray"])
+@pytest.mark.parametrize("sampling", ["420", "444", "gray", "411"])
 @pytest.mark.parametrize("script", BATCH_SCRIPTS, ids=[str(i) for i in range(len(BATCH_SCRIPTS))])
 def test_batch_pipeline_keeps_images_on_the_device_and_matches_the_reference(cli, tmp_path, script, sampling):
     """batch mode decodes on the GPU and leaves the planes there (shadow.c): compose, effects and the

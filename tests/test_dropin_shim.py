@@ -169,12 +169,13 @@ def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sampling,expect", [("420", "gpu"), ("444", "gpu"), ("422", "gpu"), ("440", "gpu"), ("rgb", "gpu"), ("gray", "gpu")])
+@pytest.mark.parametrize("sampling,expect", [("420", "gpu"), ("444", "gpu"), ("422", "gpu"), ("440", "gpu"), ("rgb", "gpu"), ("gray", "gpu"), ("411", "gpu"), ("410", "gpu")])
 def test_gpu_tile_preparation_equals_libjpeg_on_random_overlays(shim, tmp_path, sampling, expect):
     """device-prepared tiles == libjpeg-prepared tiles (the drop-in's host path, itself pinned to the
     reference) on random overlays: RGB / RGBA / YCC / YCCA pixels, odd sizes, every kind of in-MCU
     offset and crop, noise / smooth / saturated contents, translucent blends; 4:2:0, 4:4:4, 4:2:2 and
-    4:4:0 targets (libjpeg's 8x8, 16x16, 16x8 and 8x16 transforms) are all prepared on the device"""
+    4:4:0 targets (libjpeg's 8x8, 16x16, 16x8 and 8x16 transforms), grayscale targets and 4:1:1 / 4:1:0 targets
+    (its h2v1 box filter in front of a 16-wide transform) are all prepared on the device"""
     rng = np.random.default_rng(int(sampling) if sampling.isdigit() else (7 if sampling == "rgb" else 9))
     target = str(tmp_path / "target.jpg")
     _make_input(target, ("200", "120"), sampling)

@@ -48,13 +48,15 @@ static unsigned char *make_jpeg(int w, int h, uint32_t seed, unsigned long *len)
     c.in_color_space = JCS_RGB;
     jpeg_set_defaults(&c);
     jpeg_set_quality(&c, 85, TRUE);
-    { /* BENCH_SAMPLING = 420 (default) | 422 | 444 | 440 | gray | rgb (an RGB-colourspace JPEG, 1x1 sampling) */
+    { /* BENCH_SAMPLING = 420 (default) | 422 | 444 | 440 | 411 | 410 | gray | rgb (an RGB-colourspace JPEG, 1x1 sampling) */
         const char *sm = getenv("BENCH_SAMPLING");
         if(sm != NULL && strcmp(sm, "gray") == 0) jpeg_set_colorspace(&c, JCS_GRAYSCALE);
         else if(sm != NULL && strcmp(sm, "rgb") == 0) jpeg_set_colorspace(&c, JCS_RGB);
         else if(sm != NULL && strcmp(sm, "444") == 0) c.comp_info[0].h_samp_factor = c.comp_info[0].v_samp_factor = 1;
         else if(sm != NULL && strcmp(sm, "422") == 0) c.comp_info[0].v_samp_factor = 1;
         else if(sm != NULL && strcmp(sm, "440") == 0) c.comp_info[0].h_samp_factor = 1;
+        else if(sm != NULL && strcmp(sm, "411") == 0) { c.comp_info[0].h_samp_factor = 4; c.comp_info[0].v_samp_factor = 1; }
+        else if(sm != NULL && strcmp(sm, "410") == 0) { c.comp_info[0].h_samp_factor = 4; c.comp_info[0].v_samp_factor = 2; }
     }
     { /* BENCH_QUALITY, BENCH_RESTART (MCUs per restart segment), BENCH_OPTIMIZE (per-image Huffman tables) */
         const char *q = getenv("BENCH_QUALITY"), *r = getenv("BENCH_RESTART"), *o = getenv("BENCH_OPTIMIZE");
