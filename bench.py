@@ -481,9 +481,18 @@ def bench_compose(args, rank, world):
     per_rank = gather_objects(mine, world)
 
     if rank == 0:
-        achieved = blocks_per_step * bytes_per_block / (mean_kern_ms * 1e-3) / 1e9
+        # Algorithmic bytes of THIS launch.  SURVEY 8d prices a composed block at 768 B (512 with int16 tiles); a plan made
+        # with the promise that alpha is final moves less for two kinds of block: no weight at all -> the
+        # JCOEF block in and out + its table entry (260 B); the single weight (0,0) -> JCOEF in and out, the tile block and
+        # a table entry with the weight (520 B, 392 with int16 tiles).  The headline regime A2 has neither kind.
+        special_dc, special_zero = 8 * plan_stats["dc_only_octets"], 8 * plan_stats["zero_alpha_octets"]
+        dc_bytes = 128 + (128 if args.tiles == "i16" else 256) + 8 + 128
+        launch_bytes = (blocks_per_step - special_dc - special_zero) * bytes_per_block + special_dc * dc_bytes + special_zero * 260
+        launch_bytes = max(min(launch_bytes, blocks_per_step * bytes_per_block), 0)
+        achieved = launch_bytes / (mean_kern_ms * 1e-3) / 1e9
+        achieved_nominal = blocks_per_step * bytes_per_block / (mean_kern_ms * 1e-3) / 1e9
         # every rank's own launch against the peak of its own GPU: the figures above describe rank 0's shard
-        rank_gbs = [r["blocks_per_step"] * bytes_per_block / (r["kernel_ms_mean"] * 1e-3) / 1e9 for r in per_rank]
+        rank_gbs = [r["blocks_per_step"] * (launch_bytes / blocks_per_step) / (r["kernel_ms_mean"] * 1e-3) / 1e9 for r in per_rank]
         key = f"{args.workload}:{args.regime}:"
         traffic, traffic_src = traffic_from_profiles(args.traffic_json, f"{args.workload}:{args.regime}:{images}" + (":i16" if args.tiles == "i16" else ""))
         if traffic is None and args.tiles == "f32":
@@ -509,7 +518,9 @@ def bench_compose(args, rank, world):
                          "kernel_ms_mean_is": "distance of two HIP events around the K timed launches on the launch stream / K",
                          "kernel_ms_pristine": pristine_ms, "kernel_ms_pristine_min": min(ms) if ms else None,
                          "kernel_ms_pristine_median": sorted(ms)[len(ms) // 2] if ms else None,
-                         "algorithmic_bytes_per_launch": blocks_per_step * bytes_per_block, "bytes_per_block": bytes_per_block,
+                         "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_block": bytes_per_block,
+                         "bytes_per_block_of_this_plan": launch_bytes / blocks_per_step,
+                         "achieved_at_nominal_bytes_per_block": achieved_nominal, "frac_at_nominal_bytes_per_block": achieved_nominal / HBM_PEAK_GBS,
                          "scope": "rank 0" if world > 1 else "the one rank", "rank": 0,
                          "achieved_min_over_ranks": min(rank_gbs), "achieved_max_over_ranks": max(rank_gbs),
                          "frac_min_over_ranks": min(rank_gbs) / HBM_PEAK_GBS, "frac_max_over_ranks": max(rank_gbs) / HBM_PEAK_GBS},

@@ -322,35 +322,6 @@ MJX_DEV unsigned plane_block_of(const DevJob &job, int n) {
     return __umul24((unsigned)(job.row0 + trow), (unsigned)job.bpr) + (unsigned)(job.col0 + tcol);
 }
 
-// zero-alpha run: only the JCOEF piece of gather octet o
-MJX_DEV int16_t *dma_octet_coef_only(const DevJob &job, int o, int lane, const int *G, unsigned dC) {
-    const int n = G[o * kWaveBlocks + (lane >> 3)];
-    int16_t  *cptr = job.coef + (size_t)plane_block_of(job, n) * 64 + (lane & 7) * 8;
-    dma16(cptr, dC);
-    return cptr;
-}
-
-// DC-only run: the JCOEF piece, the tile piece(s) and ONE piece that brings the first 16 bytes of every alpha
-// block (all 8 lanes of a block ask for the same 16 bytes: weight (0,0) is its first element)
-template <bool I16>
-MJX_DEV int16_t *dma_octet_dc_only(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned dC, unsigned dT, unsigned dW) {
-    const int bq = lane >> 4;
-    const int n = G[o * kWaveBlocks + (lane >> 3)];
-    int16_t  *cptr = job.coef + (size_t)plane_block_of(job, n) * 64 + (lane & 7) * 8;
-    dma16(cptr, dC);
-    if constexpr(I16) {
-        dma16_so(job.tile, (unsigned)n * 128u + (unsigned)(lane & 7) * 16u, dT);
-        dma16_so(job.alpha, (unsigned)n * 128u, dW);
-    }
-    else {
-        const int t_lo = G[o * kWaveBlocks + bq], t_hi = G[o * kWaveBlocks + 4 + bq];
-        dma16_so(job.tile, (unsigned)t_lo * 256u + t_in, dT);
-        dma16_so(job.tile, (unsigned)t_hi * 256u + t_in, dT + 1024);
-        dma16_so(job.alpha, (unsigned)n * 256u, dW);
-    }
-    return cptr;
-}
-
 template <bool I16>
 MJX_DEV int16_t *dma_octet_gather(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned a_in, unsigned dC, unsigned dT, unsigned dA) {
     const int bq = lane >> 4;
@@ -500,8 +471,9 @@ struct WaveLds {
     int   G[256];                // gather runs: tile block index of every block of the run (8 per octet; the piece lands as 1 KiB)
 };
 
-// steps A and Q of compose.c:315-336 and the store, given the dequantised coefficients (packed pairs) and Y in row layout
-MJX_DEV void octet_tail(int16_t *cptr, const float *qrow, const unsigned (&cd)[4], const float (&y)[8]) {
+// steps A and Q of compose.c:315-336 and the store, given the dequantised coefficients (packed pairs), Y in row
+// layout and the row's eight reciprocal quantisers
+MJX_DEV void octet_tail_rq(int16_t *cptr, const float (&rq)[8], const unsigned (&cd)[4], const float (&y)[8]) {
     // A: coef = (short)(coef + (int)Y) (compose.c:315-324).  v_cvt_i32_f32 differs from the x86
     // conversion of the reference only for Y >= 2^31 (0x7fffffff instead of 0x80000000; NaN and
     // Y <= -2^31 agree in the low 16 bits), which the wave tests once with a max-reduction.
@@ -513,9 +485,7 @@ MJX_DEV void octet_tail(int16_t *cptr, const float *qrow, const unsigned (&cd)[4
     else {
         static_for<8>([&](auto U) { ti[U] = cvt_i32_sat(y[U]); });
     }
-    const float4 rq_lo = *reinterpret_cast<const float4 *>(qrow + 4), rq_hi = *reinterpret_cast<const float4 *>(qrow + 8);
-    const float  rq[8] = {rq_lo.x, rq_lo.y, rq_lo.z, rq_lo.w, rq_hi.x, rq_hi.y, rq_hi.z, rq_hi.w};
-    unsigned     o[4];
+    unsigned o[4];
     static_for<4>([&](auto P) {
         const unsigned s = pk_add_u16(cd[P], pack16(ti[2 * P], ti[2 * P + 1]));
         // Q: (short)(coef / q) by the exact reciprocal product (compose.c:327-336)
@@ -525,23 +495,27 @@ MJX_DEV void octet_tail(int16_t *cptr, const float *qrow, const unsigned (&cd)[4
     });
     global_store16(cptr, make_uint4(o[0], o[1], o[2], o[3]));
 }
+// the same with the quantisation row staged in LDS (8 x u16, then the 8 reciprocals)
+MJX_DEV void octet_tail(int16_t *cptr, const float *qrow, const unsigned (&cd)[4], const float (&y)[8]) {
+    const float4 rq_lo = *reinterpret_cast<const float4 *>(qrow + 4), rq_hi = *reinterpret_cast<const float4 *>(qrow + 8);
+    const float  rq[8] = {rq_lo.x, rq_lo.y, rq_lo.z, rq_lo.w, rq_hi.x, rq_hi.y, rq_hi.z, rq_hi.w};
+    octet_tail_rq(cptr, rq, cd, y);
+}
 
 // a block whose 64 weights are all zero: every mj_convolve call returns at convolve.c:32, Y stays +0.0f,
 // (int)Y == 0, and what is left of compose.c:277-336 is coef = (short)((short)(coef * q) / q) - the
 // identity unless coef * q leaves int16, which is why the block is still rewritten
-MJX_DEV void octet_zero_alpha(int16_t *cptr, const float *qrow, const uint4 c4) {
-    const uint4    q4 = *reinterpret_cast<const uint4 *>(qrow);
+MJX_DEV void octet_zero_alpha_rq(int16_t *cptr, const uint4 q4, const float (&rq)[8], const uint4 c4) {
     const unsigned cd[4] = {pk_mul_lo_u16(c4.x, q4.x), pk_mul_lo_u16(c4.y, q4.y), pk_mul_lo_u16(c4.z, q4.z), pk_mul_lo_u16(c4.w, q4.w)};
     const float    y[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    octet_tail(cptr, qrow, cd, y);
+    octet_tail_rq(cptr, rq, cd, y);
 }
 
 // a block whose only weight is w = alpha[0][0]: the single term (k, l) = (0, 0) of compose.c:300-312 is
 // V_0(H_0(X)) * w with H_0 and V_0 both "twice the element" (convolve.c:36-45, :567-580), i.e. elementwise:
 // z = (float)(2.0 * x) = x + x, y = (float)(0.0 + (2.0 * z) * w) = fmaf(z, 2w, +0) (vstage_first) - the very
 // operations the general path performs, minus the two transpositions around them
-MJX_DEV void octet_dc_only(int16_t *cptr, const float *qrow, const uint4 c4, const float (&t)[8], float w) {
-    const uint4    q4 = *reinterpret_cast<const uint4 *>(qrow);
+MJX_DEV void octet_dc_only_rq(int16_t *cptr, const uint4 q4, const float (&rq)[8], const uint4 c4, const float (&t)[8], float w) {
     const unsigned cd[4] = {pk_mul_lo_u16(c4.x, q4.x), pk_mul_lo_u16(c4.y, q4.y), pk_mul_lo_u16(c4.z, q4.z), pk_mul_lo_u16(c4.w, q4.w)};
     float          x[8], z[8], y[8];
     static_for<4>([&](auto P) { // X = tile - (float)coef (compose.c:289-298)
@@ -551,7 +525,7 @@ MJX_DEV void octet_dc_only(int16_t *cptr, const float *qrow, const uint4 c4, con
     static_for<8>([&](auto U) { z[U] = x[U] + x[U]; });
     static_for<8>([&](auto U) { y[U] = 0.0f; });
     vstage_first(y, z, w);
-    octet_tail(cptr, qrow, cd, y);
+    octet_tail_rq(cptr, rq, cd, y);
 }
 
 // one octet whose operands have landed in (pC, pT, pA): registers, blend, store to cptr
@@ -634,58 +608,6 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
-    if(kind == kRunZeroAlpha) { // wave-uniform
-        // one JCOEF piece per octet; VMEM order P(0) | P(1) S(0) | P(2) S(1) ...: at the top of step i
-        // only S(i-1) is younger than P(i)
-        int16_t *cp = dma_octet_coef_only(job, 0, lane, rc.G, lds_addr(L.C[0]));
-#pragma unroll 1
-        for(int i = 0; i < noct; ++i) {
-            wait_vmcnt_n(i < 1 ? i : 1);
-            const uint4 c4 = *reinterpret_cast<const uint4 *>(L.C[0] + lane * 4);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            int16_t *cn = cp;
-            if(i + 1 < noct) cn = dma_octet_coef_only(job, i + 1, lane, rc.G, lds_addr(L.C[0]));
-            octet_zero_alpha(cp, qrow, c4);
-            cp = cn;
-        }
-        return;
-    }
-
-    if(kind == kRunDcOnly) { // wave-uniform
-        // per octet: JCOEF piece, tile piece(s), one piece with the heads of the 8 alpha blocks; VMEM order as in
-        // the zero-alpha run (at the top of step i only the store of step i-1 is younger than octet i's pieces)
-        const int    ph = (b >> 1) & 1;
-        const double kdc = 0.3535534 * 0.3535534 / 1020.0; // dropon.c:548, for int16 tiles
-        int16_t     *cp = dma_octet_dc_only<I16>(job, 0, lane, rc.G, rc.t_in, lds_addr(L.C[0]), lds_addr(L.T[0]), lds_addr(L.A[0]));
-#pragma unroll 1
-        for(int i = 0; i < noct; ++i) {
-            wait_vmcnt_n(i < 1 ? i : 1);
-            const uint4 c4 = *reinterpret_cast<const uint4 *>(L.C[0] + lane * 4);
-            float       t[8], w;
-            if constexpr(I16) {
-                const uint4    ti4 = *reinterpret_cast<const uint4 *>(L.T[0] + lane * 4);
-                const unsigned a0 = *reinterpret_cast<const unsigned *>(L.A[0] + lane * 4);
-                const unsigned tw[4] = {ti4.x, ti4.y, ti4.z, ti4.w};
-                static_for<4>([&](auto P) {
-                    t[2 * P] = s16_lo_to_f32(tw[P]);
-                    t[2 * P + 1] = s16_hi_to_f32(tw[P]);
-                });
-                w = (float)((double)s16_lo_to_f32(a0) * kdc);
-            }
-            else {
-                const float4 t_lo = *reinterpret_cast<const float4 *>(L.T[0] + lane * 8 + 4 * ph), t_hi = *reinterpret_cast<const float4 *>(L.T[0] + lane * 8 + 4 - 4 * ph);
-                t[0] = t_lo.x; t[1] = t_lo.y; t[2] = t_lo.z; t[3] = t_lo.w; t[4] = t_hi.x; t[5] = t_hi.y; t[6] = t_hi.z; t[7] = t_hi.w;
-                w = L.A[0][lane * 4];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            int16_t *cn = cp;
-            if(i + 1 < noct) cn = dma_octet_dc_only<I16>(job, i + 1, lane, rc.G, rc.t_in, lds_addr(L.C[0]), lds_addr(L.T[0]), lds_addr(L.A[0]));
-            octet_dc_only(cp, qrow, c4, t, w);
-            cp = cn;
-        }
-        return;
-    }
-
     // prologue: the first DEPTH octets of the run
     OctetAddr addr;
     int16_t  *cp[MJX_DEPTH + 1]; // cp[d] = store address of octet i + d
@@ -758,6 +680,104 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The blocks that need no blend (mjx_internal.hpp RunKind: zero-alpha and DC-only runs) have a kernel of
+// their own.  They are pure streams - 256 resp. ~530 bytes per block, a handful of VALU instructions - and
+// the measurements of scripts/ubench/copy_roof.hip say what a stream wants on this device: short-lived
+// waves and many of them (0.76 of 8 TB/s with runs of <= 4 octets against 0.69 with 16, the per-CU request
+// path being the limiter; profiles/r03/copy_roof_run_length_counters.txt).  Inside compose_kernel they ran
+// with its 164 VGPRs, i.e. 12 waves per CU, and its 16-octet runs.  Here: ~40 VGPRs, no LDS, plain
+// non-temporal loads to registers, runs of a few octets; the arithmetic is the same device functions.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
+MJX_DEV uint4 global_load16_nt(const void *p) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <bool I16>
+__global__ __launch_bounds__(256) void compose_light_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
+    const int lane = threadIdx.x & 63;
+    const int b = lane >> 3, r = lane & 7;
+    const int ridx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if(ridx >= nruns) return;
+    const Run    run = runs[ridx];
+    const int    noct = __builtin_amdgcn_readfirstlane(run.noctets);
+    const bool   dc = __builtin_amdgcn_readfirstlane(run.kind) == kRunDcOnly;
+    const DevJob job = run.job;
+    // this lane's quantisation row: 8 x u16, 8 reciprocals (48 bytes of the 384-byte table)
+    const char  *qbase = reinterpret_cast<const char *>(qrq) + (size_t)(unsigned)job.qidx * kQuantTableBytes + r * (kQuantRowDwords * 4);
+    const uint4  q4 = *reinterpret_cast<const uint4 *>(qbase);
+    const float4 rq_lo = *reinterpret_cast<const float4 *>(qbase + 16), rq_hi = *reinterpret_cast<const float4 *>(qbase + 32);
+    const float  rq[8] = {rq_lo.x, rq_lo.y, rq_lo.z, rq_lo.w, rq_hi.x, rq_hi.y, rq_hi.z, rq_hi.w};
+    // the run's table: zero-alpha octets are 8 tile indices; DC-only octets 8 tile indices followed by the
+    // blocks' 8 weights (0,0) as float bits (read by the schedule from the alpha tiles, which are final)
+    const int    gstride = dc ? 2 * kWaveBlocks : kWaveBlocks;
+    const int   *G = run.gather + (size_t)run.first * kWaveBlocks + b;
+
+    // this lane's operands of one octet: the JCOEF row, and for DC-only runs the tile row and the block's weight
+    struct Octet {
+        int16_t *cptr;
+        uint4    c4, t0, t1; // t0 (,t1): the tile row, 8 x int16 or 8 x float
+        unsigned w;          // alpha[0][0]: float bits, or the int16 coefficient in the low half
+    };
+    auto fetch = [&](const int *g) {
+        const int n = g[0];
+        Octet     o;
+        o.cptr = job.coef + (size_t)plane_block_of(job, n) * 64 + r * 8;
+        o.c4 = global_load16_nt(o.cptr);
+        o.t0 = o.t1 = make_uint4(0, 0, 0, 0);
+        o.w = 0;
+        if(dc) {
+            o.w = (unsigned)g[kWaveBlocks];
+            if constexpr(I16) {
+                o.t0 = global_load16_nt(reinterpret_cast<const int16_t *>(job.tile) + (size_t)n * 64 + r * 8);
+            }
+            else {
+                o.t0 = global_load16_nt(job.tile + (size_t)n * 64 + r * 8);
+                o.t1 = global_load16_nt(job.tile + (size_t)n * 64 + r * 8 + 4);
+            }
+        }
+        return o;
+    };
+    auto finish = [&](const Octet &o) {
+        if(!dc) {
+            octet_zero_alpha_rq(o.cptr, q4, rq, o.c4);
+            return;
+        }
+        float t[8];
+        if constexpr(I16) {
+            const unsigned tw[4] = {o.t0.x, o.t0.y, o.t0.z, o.t0.w};
+            static_for<4>([&](auto P) {
+                t[2 * P] = s16_lo_to_f32(tw[P]);
+                t[2 * P + 1] = s16_hi_to_f32(tw[P]);
+            });
+        }
+        else {
+            t[0] = __uint_as_float(o.t0.x); t[1] = __uint_as_float(o.t0.y); t[2] = __uint_as_float(o.t0.z); t[3] = __uint_as_float(o.t0.w);
+            t[4] = __uint_as_float(o.t1.x); t[5] = __uint_as_float(o.t1.y); t[6] = __uint_as_float(o.t1.z); t[7] = __uint_as_float(o.t1.w);
+        }
+        octet_dc_only_rq(o.cptr, q4, rq, o.c4, t, __uint_as_float(o.w));
+    };
+    // two octets in flight: the next octet's loads are issued before this one is finished and stored
+    Octet cur = fetch(G);
+#pragma unroll 1
+    for(int i = 0; i < noct; ++i) {
+        Octet nxt = cur;
+        if(i + 1 < noct) nxt = fetch(G + (i + 1) * gstride);
+        finish(cur);
+        cur = nxt;
+    }
+}
+
+int launch_compose_light(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s) {
+    if(nruns <= 0) return MJX_OK;
+    const int groups = (nruns + 3) / 4;
+    if(tiles_i16) hipLaunchKernelGGL(compose_light_kernel<true>, dim3((unsigned)groups), dim3(256), 0, s, runs, nruns, qrq);
+    else hipLaunchKernelGGL(compose_light_kernel<false>, dim3((unsigned)groups), dim3(256), 0, s, runs, nruns, qrq);
+    return check_hip(hipGetLastError(), "compose_light_kernel launch", MJX_ERR_LAUNCH);
+}
+
 int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
     const int groups = (nruns + MJX_GROUP_WAVES - 1) / MJX_GROUP_WAVES;
@@ -795,8 +815,10 @@ int compose_resident_waves(bool tiles_i16) {
 // need.  Walks the consecutive runs of a plan: lane (b, r) looks at row r of its block, the 8 lanes
 // of a block combine their bytes, lane r == 0 writes the word.
 // ------------------------------------------------------------------------------------------
+// w00[block] = the block's weight (0,0) as the compose kernels see it (float bits): DC-only runs carry it
+// in their table instead of fetching the head of every alpha block (a 64-byte request for 4 bytes)
 template <bool I16>
-__global__ __launch_bounds__(256) void alpha_pattern_kernel(const Run *__restrict__ runs, int nruns, uint64_t *__restrict__ pattern) {
+__global__ __launch_bounds__(256) void alpha_pattern_kernel(const Run *__restrict__ runs, int nruns, uint64_t *__restrict__ pattern, uint32_t *__restrict__ w00) {
     const int lane = threadIdx.x & 63, b = lane >> 3, r = lane & 7;
     const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if(ridx >= nruns) return;
@@ -822,14 +844,25 @@ __global__ __launch_bounds__(256) void alpha_pattern_kernel(const Run *__restric
             lo32 |= (unsigned)__shfl_xor((int)lo32, d);
             hi32 |= (unsigned)__shfl_xor((int)hi32, d);
         }
-        if(r == 0 && n < job.nblocks) pattern[(size_t)(unsigned)job.nnz_off + n] = ((uint64_t)hi32 << 32) | lo32;
+        if(r == 0 && n < job.nblocks) {
+            pattern[(size_t)(unsigned)job.nnz_off + n] = ((uint64_t)hi32 << 32) | lo32;
+            float w;
+            if constexpr(I16) { // dropon.c:548: (float)((float)coef * (0.3535534 * 0.3535534 / 1020.0))
+                const double kdc = 0.3535534 * 0.3535534 / 1020.0;
+                w = (float)((double)(float)(int)*(reinterpret_cast<const int16_t *>(job.alpha) + (size_t)nc * 64) * kdc);
+            }
+            else {
+                w = job.alpha[(size_t)nc * 64];
+            }
+            w00[(size_t)(unsigned)job.nnz_off + n] = __float_as_uint(w);
+        }
     }
 }
 
-int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, bool tiles_i16, hipStream_t s) {
+int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, uint32_t *w00, bool tiles_i16, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
-    if(tiles_i16) hipLaunchKernelGGL(alpha_pattern_kernel<true>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, runs, nruns, pattern);
-    else hipLaunchKernelGGL(alpha_pattern_kernel<false>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, runs, nruns, pattern);
+    if(tiles_i16) hipLaunchKernelGGL(alpha_pattern_kernel<true>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, runs, nruns, pattern, w00);
+    else hipLaunchKernelGGL(alpha_pattern_kernel<false>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, runs, nruns, pattern, w00);
     return check_hip(hipGetLastError(), "alpha_pattern_kernel launch", MJX_ERR_LAUNCH);
 }
 

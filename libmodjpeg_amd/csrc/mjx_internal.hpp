@@ -27,11 +27,12 @@ static_assert(sizeof(DevJob) == 56, "DevJob layout");
 enum RunKind : int32_t {
     kRunConsecutive = 0, // the octets are consecutive tile blocks, `first` = first tile block
     kRunGather = 1,      // they are listed in the plan's gather table, `first` = first octet there
+    // the two kinds below are run by compose_light_kernel, not by compose_kernel:
     kRunZeroAlpha = 2,   // gather octets of blocks whose 64 weights are all zero: the reference skips every
                          // term of such a block (convolve.c:32), Y stays +0, only the JCOEF block travels
     kRunDcOnly = 3       // gather octets of blocks whose ONLY weight is (0,0) - every block an opaque or evenly
-                         // translucent part of an overlay covers: of the alpha block only its first 16 bytes
-                         // travel, and the one term left, V_0(H_0(X)) * w = 2X * 2w, needs no transposition
+                         // translucent part of an overlay covers: of the alpha block only its first weight
+                         // travels, and the one term left, V_0(H_0(X)) * w = 2X * 2w, needs no transposition
 };
 struct Run {
     DevJob         job;
@@ -51,7 +52,8 @@ constexpr int kQuantTableBytes = 8 * kQuantRowDwords * 4;
 // A gather table names the 8 blocks of every octet by their index inside the job's tile / alpha arrays
 // (tile row * cols + tile column); the kernel derives the plane block from it, so a table depends only
 // on the tiles and can be kept with them (the tile cache of the drop-in does) whatever image they are
-// composed into.
+// composed into.  An octet of a DC-only run takes two slots of 8: the tile indices, then the blocks'
+// weights (0,0) as float bits.
 constexpr int kWaveBlocks = 8;     // one wavefront = 8 blocks x 8 lanes
 constexpr int kWavesPerGroup = 4;  // 256 threads
 
@@ -102,8 +104,11 @@ struct ArenaLease {
 // launchers implemented in the kernel translation units
 // qrq: kQuantTableBytes per quantisation table (see above)
 int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s);
+// runs of kind kRunZeroAlpha / kRunDcOnly only: the blocks that need no blend stream through a lean kernel of their own
+int launch_compose_light(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s);
 // pattern[first block of the job in the plan + n] = bit (8k + l) set when weight (k, l) of tile block n is not zero
-int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, bool tiles_i16, hipStream_t s);
+// ... and w00[same index] = its weight (0,0) as float bits
+int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, uint32_t *w00, bool tiles_i16, hipStream_t s);
 int run_octets();
 // wavefronts of compose_kernel the current device holds at once (CUs x resident waves per CU)
 int compose_resident_waves(bool tiles_i16);

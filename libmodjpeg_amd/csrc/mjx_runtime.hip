@@ -120,8 +120,8 @@ struct mjx_tile_schedule {
 };
 
 struct mjx_compose_plan {
-    Run        *d_runs = nullptr;
-    int         nruns = 0;
+    Run        *d_runs = nullptr;    // compose_kernel's runs, then compose_light_kernel's (zero-alpha, DC-only)
+    int         nruns = 0, nlight = 0;
     void       *d_qrq = nullptr;     // kQuantTableBytes per quantisation table
     int32_t    *d_gather = nullptr;  // plans grouped by pattern: the blocks of every gather octet
     int         njobs = 0;
@@ -226,7 +226,8 @@ struct RunRef {
 
 struct Tables {
     std::vector<DevJob>  jobs;
-    std::vector<RunRef>  runs;
+    std::vector<RunRef>  runs;   // compose_kernel's
+    std::vector<RunRef>  light;  // compose_light_kernel's: zero-alpha and DC-only runs
     std::vector<int32_t> gather; // the plan's own table: 8 tile block indices per gather octet
     std::vector<uint8_t> qrq;    // kQuantTableBytes per table
     int64_t              blocks = 0;
@@ -265,7 +266,8 @@ inline int cost_class(float c) { return c <= kCostMemory ? 0 : (c <= 2.0f * kCos
 // block; gather octets are appended to `gather` (segment.first counts octets from its start).
 // pattern == nullptr: one consecutive segment.  skip_zero: blocks without any weight form zero-alpha
 // segments (MJX_PLAN_ALPHA_IS_FINAL).
-void schedule_tiles(const uint64_t *pattern, int nblocks, bool skip_zero, std::vector<int32_t> &gather, std::vector<Segment> &segs, SchedStats &st) {
+// w00 (with pattern): every block's weight (0,0) as float bits, for the tables of DC-only runs.
+void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, bool skip_zero, std::vector<int32_t> &gather, std::vector<Segment> &segs, SchedStats &st) {
     const int noct_all = (nblocks + kWaveBlocks - 1) / kWaveBlocks;
     st.blocks += nblocks;
     if(pattern == nullptr) {
@@ -387,7 +389,15 @@ void schedule_tiles(const uint64_t *pattern, int nblocks, bool skip_zero, std::v
         base = (int)(gather.size() / kWaveBlocks);
         const int nd = (int)((dconly.size() + kWaveBlocks - 1) / kWaveBlocks);
         segs.push_back(Segment{kRunDcOnly, 0, base, nd});
-        for(int i = 0; i < nd * kWaveBlocks; ++i) gather.push_back(dconly[(size_t)i < dconly.size() ? (size_t)i : dconly.size() - 1]);
+        for(int o = 0; o < nd; ++o) { // two slots of 8 per octet: the tile indices, then the blocks' weights (0,0)
+            int at[kWaveBlocks];
+            for(int k = 0; k < kWaveBlocks; ++k) {
+                const size_t i = (size_t)o * kWaveBlocks + k;
+                at[k] = dconly[i < dconly.size() ? i : dconly.size() - 1];
+                gather.push_back(at[k]);
+            }
+            for(int k = 0; k < kWaveBlocks; ++k) gather.push_back((int32_t)w00[at[k]]);
+        }
         st.octets += nd;
         st.gather_octets += nd;
         st.dc_octets += nd;
@@ -427,6 +437,12 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
         int32_t cls;
     };
     std::vector<Labelled> runs;
+    static const int light_len = [] {
+        const char *e = getenv("MJX_LIGHT_RUN"); // experiments
+        const int   v = e ? atoi(e) : 4; // measured (scripts/r03_check6.sh): 2..8 octets within 2 %, 16 is 3-5 % slower
+        return v < 1 ? 1 : (v > kMaxRunOctets ? kMaxRunOctets : v);
+    }();
+    t.light.clear();
     for(size_t i = 0; i < all.size();) {
         // the stretch [i, e): same job, same kind, same table, each segment starting where the one before ends
         size_t e = i + 1;
@@ -436,6 +452,14 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
         int total = 0;
         for(size_t k = i; k < e; ++k) total += all[k].seg.noctets;
         const int kind = all[i].seg.kind, base = all[i].seg.first;
+        if(kind == kRunZeroAlpha || kind == kRunDcOnly) {
+            // streams for the lean kernel: many short-lived waves (a few octets each), in table order
+            const int slots_per_octet = kind == kRunDcOnly ? 2 : 1; // a DC-only octet: 8 tile indices + 8 weights
+            for(int f = 0; f < total; f += light_len)
+                t.light.push_back(RunRef{all[i].job, base + f * slots_per_octet, total - f < light_len ? total - f : light_len, kind, all[i].sched});
+            i = e;
+            continue;
+        }
         size_t    seg = i;       // segment that holds octet f
         int       seg_end = all[i].seg.noctets;
         for(int f = 0; f < total;) {
@@ -565,16 +589,16 @@ void plain_runs(Tables &t) {
     all.reserve(t.jobs.size());
     for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
         std::vector<Segment> one;
-        schedule_tiles(nullptr, t.jobs[(size_t)jid].nblocks, false, t.gather, one, t.stats);
+        schedule_tiles(nullptr, nullptr, t.jobs[(size_t)jid].nblocks, false, t.gather, one, t.stats);
         all.push_back(JobSegment{jid, -1, one[0]});
     }
     cut_runs(t, all);
 }
 
 // write the runs out as device descriptors; gather tables: the plan's own (sched < 0) or that of schedule `sched`
-void expand_runs(const Tables &t, Run *out, const int32_t *own, const mjx_tile_schedule_t *const *scheds) {
-    for(size_t i = 0; i < t.runs.size(); ++i) {
-        const RunRef &r = t.runs[i];
+void expand_runs(const Tables &t, const std::vector<RunRef> &refs, Run *out, const int32_t *own, const mjx_tile_schedule_t *const *scheds) {
+    for(size_t i = 0; i < refs.size(); ++i) {
+        const RunRef &r = refs[i];
         Run          &d = out[i];
         d.job = t.jobs[(size_t)r.job];
         d.first = r.first;
@@ -586,7 +610,7 @@ void expand_runs(const Tables &t, Run *out, const int32_t *own, const mjx_tile_s
 }
 
 // zero patterns of the alpha tiles of every job in t (one launch over temporary consecutive runs)
-int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern) {
+int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<uint32_t> &w00) {
     std::vector<Run> tmp;
     for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
         const DevJob &d = t.jobs[(size_t)jid];
@@ -601,31 +625,41 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern) {
         }
     }
     pattern.resize((size_t)t.blocks);
-    const size_t run_bytes = round256(tmp.size() * sizeof(Run)), pat_bytes = (size_t)t.blocks * sizeof(uint64_t);
-    if(run_bytes + pat_bytes <= ((size_t)8 << 20)) {
+    w00.resize((size_t)t.blocks);
+    const size_t run_bytes = round256(tmp.size() * sizeof(Run)), pat_bytes = round256((size_t)t.blocks * sizeof(uint64_t)), w_bytes = (size_t)t.blocks * sizeof(uint32_t);
+    if(run_bytes + pat_bytes + w_bytes <= ((size_t)12 << 20)) {
         // the usual case (the tiles of one overlay): through a pooled staging arena, no hipMalloc / hipFree
         // (each of which synchronises the device: four of them were half of the 0.8 ms a 4K schedule took)
         ArenaLease arena;
-        int        err = arena->prepare(run_bytes + pat_bytes, run_bytes + pat_bytes);
+        int        err = arena->prepare(run_bytes + pat_bytes + w_bytes, run_bytes + pat_bytes + w_bytes);
         if(err != MJX_OK) return err;
         hipStream_t s = arena->stream;
         memcpy(arena->pin, tmp.data(), tmp.size() * sizeof(Run));
         err = check_hip(hipMemcpyAsync(arena->dev, arena->pin, tmp.size() * sizeof(Run), hipMemcpyHostToDevice, s), "hipMemcpyAsync(scan runs)", MJX_ERR_LAUNCH);
-        if(err == MJX_OK) err = launch_alpha_pattern(reinterpret_cast<const Run *>(arena->dev), (int)tmp.size(), reinterpret_cast<uint64_t *>(arena->dev + run_bytes), t.tiles_i16, s);
-        if(err == MJX_OK) err = check_hip(hipMemcpyAsync(arena->pin + run_bytes, arena->dev + run_bytes, pat_bytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(patterns)", MJX_ERR_LAUNCH);
+        if(err == MJX_OK)
+            err = launch_alpha_pattern(reinterpret_cast<const Run *>(arena->dev), (int)tmp.size(), reinterpret_cast<uint64_t *>(arena->dev + run_bytes),
+                                       reinterpret_cast<uint32_t *>(arena->dev + run_bytes + pat_bytes), t.tiles_i16, s);
+        if(err == MJX_OK) err = check_hip(hipMemcpyAsync(arena->pin + run_bytes, arena->dev + run_bytes, pat_bytes + w_bytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(patterns)", MJX_ERR_LAUNCH);
         const int serr = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
-        if(err == MJX_OK && serr == MJX_OK) memcpy(pattern.data(), arena->pin + run_bytes, pat_bytes);
+        if(err == MJX_OK && serr == MJX_OK) {
+            memcpy(pattern.data(), arena->pin + run_bytes, (size_t)t.blocks * sizeof(uint64_t));
+            memcpy(w00.data(), arena->pin + run_bytes + pat_bytes, w_bytes);
+        }
         return err != MJX_OK ? err : serr;
     }
     Run      *d_tmp = nullptr;
     uint64_t *d_pat = nullptr;
+    uint32_t *d_w = nullptr;
     int       err = check_hip(hipMalloc((void **)&d_tmp, tmp.size() * sizeof(Run)), "hipMalloc(scan runs)", MJX_ERR_MEMORY);
     if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_pat, pat_bytes), "hipMalloc(patterns)", MJX_ERR_MEMORY);
+    if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_w, w_bytes), "hipMalloc(weights)", MJX_ERR_MEMORY);
     if(err == MJX_OK) err = check_hip(hipMemcpy(d_tmp, tmp.data(), tmp.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(scan runs)", MJX_ERR_LAUNCH);
-    if(err == MJX_OK) err = launch_alpha_pattern(d_tmp, (int)tmp.size(), d_pat, t.tiles_i16, nullptr);
-    if(err == MJX_OK) err = check_hip(hipMemcpy(pattern.data(), d_pat, pat_bytes, hipMemcpyDeviceToHost), "hipMemcpy(patterns)", MJX_ERR_LAUNCH);
+    if(err == MJX_OK) err = launch_alpha_pattern(d_tmp, (int)tmp.size(), d_pat, d_w, t.tiles_i16, nullptr);
+    if(err == MJX_OK) err = check_hip(hipMemcpy(pattern.data(), d_pat, (size_t)t.blocks * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(patterns)", MJX_ERR_LAUNCH);
+    if(err == MJX_OK) err = check_hip(hipMemcpy(w00.data(), d_w, w_bytes, hipMemcpyDeviceToHost), "hipMemcpy(weights)", MJX_ERR_LAUNCH);
     if(d_tmp) (void)hipFree(d_tmp);
     if(d_pat) (void)hipFree(d_pat);
+    if(d_w) (void)hipFree(d_w);
     return err;
 }
 
@@ -685,13 +719,14 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
             // a wavefront (results do not depend on it) - except that with MJX_PLAN_ALPHA_IS_FINAL blocks
             // without weights leave their tiles behind, which is why that needs the caller's promise
             std::vector<uint64_t> pattern;
-            if((err = scan_patterns(t, pattern)) != MJX_OK) break;
+            std::vector<uint32_t> w00;
+            if((err = scan_patterns(t, pattern, w00)) != MJX_OK) break;
             std::vector<JobSegment> all;
             std::vector<Segment>    one;
             for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
                 const DevJob &d = t.jobs[(size_t)jid];
                 one.clear();
-                schedule_tiles(pattern.data() + (size_t)(unsigned)d.nnz_off, d.nblocks, (flags & MJX_PLAN_ALPHA_IS_FINAL) != 0, t.gather, one, t.stats);
+                schedule_tiles(pattern.data() + (size_t)(unsigned)d.nnz_off, w00.data() + (size_t)(unsigned)d.nnz_off, d.nblocks, (flags & MJX_PLAN_ALPHA_IS_FINAL) != 0, t.gather, one, t.stats);
                 for(const Segment &sg : one) all.push_back(JobSegment{jid, -1, sg});
             }
             cut_runs(t, all);
@@ -700,6 +735,7 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
             plain_runs(t);
         }
         p->nruns = (int)t.runs.size();
+        p->nlight = (int)t.light.size();
         p->stats = t.stats;
         p->slots = t.slots;
         p->run_max = t.run_max;
@@ -710,8 +746,9 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
             if((err = check_hip(hipMalloc((void **)&p->d_gather, t.gather.size() * sizeof(int32_t)), "hipMalloc(gather)", MJX_ERR_MEMORY))) break;
             if((err = check_hip(hipMemcpy(p->d_gather, t.gather.data(), t.gather.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(gather)", MJX_ERR_LAUNCH))) break;
         }
-        std::vector<Run> runs(t.runs.size());
-        expand_runs(t, runs.data(), p->d_gather, nullptr);
+        std::vector<Run> runs(t.runs.size() + t.light.size());
+        expand_runs(t, t.runs, runs.data(), p->d_gather, nullptr);
+        expand_runs(t, t.light, runs.data() + t.runs.size(), p->d_gather, nullptr);
         if((err = check_hip(hipMalloc((void **)&p->d_runs, runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMemcpy(p->d_runs, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
     } while(0);
@@ -744,14 +781,17 @@ int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan) { return plan ? 
 
 int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out) {
     if(plan == nullptr || out == nullptr) return MJX_ERR_NULL_DATA;
-    fill_stats(out, plan->stats, plan->nruns, plan->slots, plan->run_max, plan->run_min);
+    fill_stats(out, plan->stats, (int64_t)plan->nruns + plan->nlight, plan->slots, plan->run_max, plan->run_min);
     return MJX_OK;
 }
 
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
-    if(plan->nruns == 0) return MJX_OK;
-    return launch_compose(plan->d_runs, plan->nruns, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
+    // the blend first (the long-running waves), then the streams of the blocks that need none; the two kernels
+    // touch disjoint blocks
+    int err = launch_compose(plan->d_runs, plan->nruns, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
+    if(err == MJX_OK) err = launch_compose_light(plan->d_runs + plan->nruns, plan->nlight, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
+    return err;
 }
 
 // ---- schedules kept with resident tiles ------------------------------------------------------------
@@ -779,7 +819,8 @@ int mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha, int
     t.jobs.push_back(d);
     t.blocks = d.nblocks;
     std::vector<uint64_t> pattern;
-    int                   err = scan_patterns(t, pattern);
+    std::vector<uint32_t> w00;
+    int                   err = scan_patterns(t, pattern, w00);
     if(err != MJX_OK) return err;
     mjx_tile_schedule *s = new(std::nothrow) mjx_tile_schedule;
     if(s == nullptr) return MJX_ERR_MEMORY;
@@ -788,7 +829,7 @@ int mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha, int
     s->tiles_i16 = t.tiles_i16;
     (void)hipGetDevice(&s->device);
     std::vector<int32_t> gather;
-    schedule_tiles(pattern.data(), d.nblocks, true, gather, s->segs, s->stats);
+    schedule_tiles(pattern.data(), w00.data(), d.nblocks, true, gather, s->segs, s->stats);
     if(!gather.empty()) {
         err = check_hip(hipMalloc((void **)&s->d_gather, gather.size() * sizeof(int32_t)), "hipMalloc(schedule)", MJX_ERR_MEMORY);
         if(err == MJX_OK) err = check_hip(hipMemcpy(s->d_gather, gather.data(), gather.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(schedule)", MJX_ERR_LAUNCH);
@@ -1030,8 +1071,8 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     // runs hold at least two octets of 8 blocks each (one when a segment of a schedule is that short),
     // plus a ragged one per (possibly split) job
     size_t max_runs = 16;
-    for(size_t k = 0; k < jobs.size(); ++k)
-        max_runs += (size_t)jobs[k].rows * (size_t)jobs[k].cols / (kWaveBlocks * 2) + 4 + (scheds[k] ? 2 * scheds[k]->segs.size() : 0);
+    for(size_t k = 0; k < jobs.size(); ++k) // (a schedule's streams for the lean kernel may be cut into single octets)
+        max_runs += (size_t)jobs[k].rows * (size_t)jobs[k].cols / (kWaveBlocks * (scheds[k] ? 1 : 2)) + 4 + (scheds[k] ? 2 * scheds[k]->segs.size() : 0);
     const size_t packet_cap = round256((size_t)nq * kQuantTableBytes) + round256(max_runs * sizeof(Run));
     ArenaLease arena;
     int        err = arena->prepare(packet_cap + data_bytes, packet_cap + stage_bytes);
@@ -1099,7 +1140,7 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
             }
             else {
                 one.clear();
-                schedule_tiles(nullptr, t.jobs[(size_t)jid].nblocks, false, t.gather, one, t.stats);
+                schedule_tiles(nullptr, nullptr, t.jobs[(size_t)jid].nblocks, false, t.gather, one, t.stats);
                 all.push_back(JobSegment{jid, -1, one[0]});
             }
         }
@@ -1107,13 +1148,15 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     }
 
     // descriptor packet in pinned memory: [Run[] | quantisation tables], one copy
-    const size_t o_runs = 0, o_q = round256(t.runs.size() * sizeof(Run)), packet = o_q + round256(t.qrq.size());
+    const size_t o_runs = 0, o_q = round256((t.runs.size() + t.light.size()) * sizeof(Run)), packet = o_q + round256(t.qrq.size());
     if(packet > packet_cap) return MJX_ERR_BAD_ARG; // cannot happen for rectangles below 2^24 blocks
-    expand_runs(t, reinterpret_cast<Run *>(arena->pin + o_runs), nullptr, scheds.data());
+    expand_runs(t, t.runs, reinterpret_cast<Run *>(arena->pin + o_runs), nullptr, scheds.data());
+    expand_runs(t, t.light, reinterpret_cast<Run *>(arena->pin + o_runs) + t.runs.size(), nullptr, scheds.data());
     memcpy(arena->pin + o_q, t.qrq.data(), t.qrq.size());
     MJX_HIP(hipMemcpyAsync(base, arena->pin, packet, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
 
     err = launch_compose(reinterpret_cast<const Run *>(base + o_runs), (int)t.runs.size(), base + o_q, tiles_i16, s);
+    if(err == MJX_OK) err = launch_compose_light(reinterpret_cast<const Run *>(base + o_runs) + t.runs.size(), (int)t.light.size(), base + o_q, tiles_i16, s);
     if(err == MJX_OK) {
         k = 0;
         for(int i = 0; i < n && err == MJX_OK; ++i) {
