@@ -115,8 +115,9 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
  * then travel without their tile and alpha blocks: the reference skips every term of such a block
  * (Y stays 0), only the de-/re-quantisation of compose.c:277-286 / :327-336 is left, and that still runs.
  * Blocks whose ONLY weight is (0,0) - every block an opaque or evenly translucent part of an overlay
- * covers - travel with the first 16 bytes of their alpha block instead of all 256, and their one term
- * runs without the two transpositions the general product needs.
+ * covers - travel without their alpha block (the schedule reads the weight once and keeps it in the run table),
+ * and their one term runs without the two transpositions the general product needs.  Both kinds are streamed
+ * by a lean kernel of their own (8 waves per SIMD, short runs) next to the blend kernel.
  * MJX_PLAN_TILES_I16: every job's tiles are int16 coefficients (the same as MJX_JOB_TILES_I16 on every job). */
 #define MJX_PLAN_GROUP_BY_DENSITY 1
 #define MJX_PLAN_ALPHA_IS_FINAL   2
@@ -131,7 +132,7 @@ int64_t mjx_compose_plan_gather_octets(const mjx_compose_plan_t *plan);
 typedef struct mjx_plan_stats {
     int64_t blocks, octets, gather_octets, zero_alpha_octets, runs;
     int64_t block_terms, union_terms;
-    int64_t dc_only_octets; /* octets of blocks whose only weight is (0,0): only the head of their alpha blocks travels */
+    int64_t dc_only_octets; /* octets of blocks whose only weight is (0,0): their alpha blocks do not travel */
     int64_t union_terms_consecutive; /* what union_terms would be with every octet 8 consecutive blocks (over all of them) */
     int32_t resident_waves; /* wavefronts of the compose kernel the device holds at once: what runs are cut for */
     int32_t run_octets_max, run_octets_min;
