@@ -509,3 +509,69 @@ def test_tile_schedules_travel_with_resident_tiles_through_the_host_buffer_call(
     assert lib().mjx_compose_host(bad, 1) == mj._lib.MJX_ERR_BAD_ARG
     for sc in scheds:
         lib().mjx_tile_schedule_destroy(sc)
+
+
+@pytest.mark.parametrize("i16", [False, True])
+def test_rectangles_made_of_blocks_that_need_no_blend(mj, i16):
+    """compose_light_kernel on its own: rectangles whose alpha blocks are ALL without weights, ALL with the single
+    weight (0,0), or an exact mixture at the 8-block threshold, ragged block counts (35, 33, 1 x 19), a rectangle
+    one block wide, quantisers that make coef * q wrap; float and int16 tiles; plan with the promise that alpha is
+    final == oracle == plan without it"""
+    import torch
+    from libmodjpeg_amd._lib import (MJX_JOB_TILES_I16, MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, PlanStats, RectJob, check, lib)
+    rng = np.random.default_rng(31 + i16)
+    c0, c1 = 0.3535534, 0.5
+    kk = np.array([(c0 if j // 8 == 0 else c1) * (c0 if j % 8 == 0 else c1) / 1020.0 for j in range(64)], np.float64)
+    # prow, bpr, row0, col0, rows, cols, kind of alpha
+    shapes = [(12, 20, 2, 3, 5, 7, "zero"), (9, 16, 1, 2, 3, 11, "dc"), (30, 4, 5, 2, 19, 1, "dc"), (8, 30, 0, 0, 4, 6, "mix"), (6, 6, 1, 1, 1, 1, "zero"), (10, 12, 0, 1, 2, 9, "zero")]
+    quants = np.stack([rng.integers(1, 256, 64), rng.integers(200, 65536, 64)]).astype(np.uint16)
+    host = []
+    for prow, bpr, row0, col0, rows, cols, kind in shapes:
+        n = rows * cols
+        coef = rng.integers(-1024, 1024, (prow, bpr, 64)).astype(np.int16)
+        if i16:
+            tile = rng.integers(-3000, 3000, (n, 64)).astype(np.int16)
+            alpha = np.zeros((n, 64), np.int16)
+            dcv = rng.choice(np.array([2040, 1020, 1, -7, 32767], np.int16), n)
+            dense = rng.integers(1, 2040, (n, 64)).astype(np.int16)
+        else:
+            tile = np.round(rng.standard_normal((n, 64)) * 300).astype(np.float32)
+            alpha = np.zeros((n, 64), np.float32)
+            dcv = rng.choice(np.array([0.25, 0.125, 1e-41, -0.4, 7.0], np.float32), n)
+            dense = (rng.random((n, 64)) * 0.1 + 0.01).astype(np.float32)
+        if kind == "dc":
+            alpha[:, 0] = dcv
+        elif kind == "mix":  # 8 without weights, 8 with the single weight, 8 dense
+            alpha[8:16, 0] = dcv[8:16]
+            alpha[16:24] = dense[16:24]
+        host.append((coef, np.ascontiguousarray(tile), np.ascontiguousarray(alpha)))
+    jobs = (RectJob * len(shapes))()
+    results = []
+    for flags in (MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL, 0):
+        dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
+        for j, (prow, bpr, row0, col0, rows, cols, kind) in enumerate(shapes):
+            jobs[j] = RectJob(dev[j][0].data_ptr(), dev[j][1].data_ptr(), dev[j][2].data_ptr(), bpr, prow, row0, col0, rows, cols, j % 2, MJX_JOB_TILES_I16 if i16 else 0)
+        plan = ctypes.c_void_p()
+        check(lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 2, flags), "plan")
+        if flags:
+            st = PlanStats()
+            check(lib().mjx_compose_plan_stats(plan, ctypes.byref(st)), "stats")
+            # the 35- and 18-block all-zero rectangles: 5 + 3 octets; the mix: 1; the 33- and 19-block DC-only ones: 5 + 3; the mix: 1;
+            # the single all-zero block stays below the 8-block threshold and goes the general way
+            assert st.zero_alpha_octets == 5 + 3 + 1 and st.dc_only_octets == 5 + 3 + 1, (st.zero_alpha_octets, st.dc_only_octets)
+        check(lib().mjx_compose_run(plan, None), "run")
+        check(lib().mjx_compose_run(plan, None), "run")  # twice: the second pass starts from composed planes
+        torch.cuda.synchronize()
+        lib().mjx_compose_plan_destroy(plan)
+        results.append([d[0].cpu().numpy() for d in dev])
+    for j, (prow, bpr, row0, col0, rows, cols, kind) in enumerate(shapes):
+        want = host[j][0].reshape(-1).copy()
+        if i16:
+            tf = host[j][1].astype(np.float32).reshape(-1)
+            af = (host[j][2].astype(np.float32).astype(np.float64) * kk).astype(np.float32).reshape(-1)
+        else:
+            tf, af = host[j][1].reshape(-1), host[j][2].reshape(-1)
+        for _ in range(2):
+            O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 2]), tf, af)
+        assert np.array_equal(results[1][j].reshape(-1), want), ("plain plan", j)
+        assert np.array_equal(results[0][j].reshape(-1), want), ("lean kernel", j, kind)
