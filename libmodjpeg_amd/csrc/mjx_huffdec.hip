@@ -62,6 +62,10 @@ struct DecScan {
     int                ntab, nsub;
     long long          nslots;
     unsigned long long dcpack, acpack; // 4 bits per slot: index of the slot's DC / AC table among the staged ones
+    // the wave-per-chunk walk (huffdec_sync_wave_kernel): where each staged table's field sits in a lane's two packed registers
+    // (bit 7: staged, bit 6: an AC table, low bits: shift), 3 bits per slot (DC field index | AC field index << 2), and whether
+    // the tables fit at all (at most four DC and two AC tables)
+    unsigned wave_place[4], wave_sel, wave_ok;
     DecComp            c[4];
     int                slot_comp[kDecMaxSlots], slot_x[kDecMaxSlots], slot_y[kDecMaxSlots];
 };
@@ -72,6 +76,7 @@ struct DecChunk {
     int                flags;      // 1: first chunk of its segment, 2: last
 };
 
+constexpr int kSubChunks = 4, kSubBitsPerLane = kChunkBits / kSubChunks; // store pass after wave-per-chunk rounds: four lanes share a chunk
 constexpr int kMaxRounds = 192, kMoreRounds = 12;
 constexpr int kFlagInts = kMaxRounds + 2; // per image: [0] error, [1 + r] round r changed something
 constexpr int kMaxBatch = 32;
@@ -83,6 +88,9 @@ struct DecJob {
     const unsigned     *words;
     const DecChunk     *chunks;
     unsigned long long *exits, *seen;
+    unsigned long long *substate; // [nchunks][kSubChunks - 1]: the state at every kSubBitsPerLane-bit mark inside the chunk (wave-per-chunk rounds)
+    unsigned           *subnb;    //                            ... and the blocks completed before it
+    int                 subchunks; // lanes of the store pass per chunk: kSubChunks after wave-per-chunk rounds, else 1
     unsigned           *nblk, *cpre;
     unsigned long long *ctot;
     unsigned           *diff, *dpre;
@@ -228,6 +236,13 @@ __device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack,
     p = base_bit + (unsigned long long)(unsigned)rel;
 }
 
+// "this round changed something": thousands of chunks say so in the same round, and read-modify-writes of one address
+// are served one after another by its L2 channel (round 1 of a 4K stream: 29 000 of them, 0.3 ms) — so look first,
+// and write a plain 1 only while the flag still reads 0
+__device__ __forceinline__ void note_change(int *flag) {
+    if(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // one synchronisation round (in place: a lane may see its neighbour's old or new exit state; the
 // rounds end when a whole round changed nothing, and then every read was of a final value).
 // flags[1 + r] says whether round r changed anything; once a round did not, later rounds return at once.
@@ -265,23 +280,219 @@ __global__ __launch_bounds__(kDecThreads) void huffdec_sync_kernel(const DecJob 
     if(round == 0 || out != J.exits[i] || nb != J.nblk[i]) {
         J.nblk[i] = nb;
         __hip_atomic_store(&J.exits[i], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if(round != 0) atomicOr(&changed[round], 1);
+        if(round != 0) note_change(&changed[round]);
+    }
+}
+
+// ---- the same round with one WAVEFRONT per chunk (few images in flight: latency matters, the GPU is idle) ----
+// The lane-per-chunk walk above is a dependent chain of ~60 vector and scalar instructions and an LDS look-up
+// per symbol, ten cycles each.  Here the 64 lanes first look up, for every bit position of the chunk and every
+// staged table, what a symbol starting there would be — all look-ups independent and in flight together — and keep
+// the answers in two registers per window of 64 positions:
+//   AC register: table a's total length (code + value bits) at bits 8a..8a+4, its zigzag advance at bits 16+8a..21+8a
+//                (EOB: 63 — in AC context k >= 1, so k + 63 ends the block as k + 64 would)
+//   DC register: table d's total length at bits 8d..8d+4 (the advance is always 1)
+// The chain itself is then scalar, nine instructions per AC symbol: v_readlane at the current position, shift, mask
+// (a zero field: not a code, or past the end of the chunk), one add to a register that holds position | k << 16, two
+// bit tests.  It publishes exactly what walk<false> would.
+constexpr int kWaveWindows = (kChunkBits + 31 + 63) / 64 + 1; // positions [0, 1024 + 24) relative to the word the chunk starts in
+
+// a value every lane holds alike, moved to scalar registers (what is computed from it stays there)
+__device__ __forceinline__ unsigned           uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int                uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uni(unsigned long long v) { return ((unsigned long long)uni((unsigned)(v >> 32)) << 32) | (unsigned long long)uni((unsigned)v); }
+
+// The chain through one window.  st = position in the window | k << 16; returns 0 when the position left the window
+// (st's position >= 64), 1 when it met a zero field (st, nb, slot as they were before that symbol).
+__device__ __forceinline__ unsigned wave_chain(unsigned fa, unsigned fd, unsigned &st, unsigned &nb, unsigned &slot, unsigned &sd, unsigned &sa, unsigned wrap, unsigned sel) {
+    unsigned status, r, t;
+    asm volatile("s_mov_b32 %[status], 0\n\t"
+                 "s_cmp_lt_u32 %[st], 0x10000\n\t"
+                 "s_cbranch_scc1 2f\n"
+                 "1:\n\t" // AC symbols of the current block
+                 "v_readlane_b32 %[r], %[fa], %[st]\n\t"
+                 "s_lshr_b32 %[r], %[r], %[sa]\n\t"
+                 "s_and_b32 %[r], %[r], 0x003f001f\n\t"
+                 "s_cbranch_scc0 9f\n\t"
+                 "s_add_u32 %[st], %[st], %[r]\n\t"
+                 "s_bitcmp1_b32 %[st], 22\n\t"
+                 "s_cbranch_scc1 3f\n\t"
+                 "s_bitcmp0_b32 %[st], 6\n\t"
+                 "s_cbranch_scc1 1b\n\t"
+                 "s_branch 8f\n"
+                 "3:\n\t" // the block is complete: next slot, its tables
+                 "s_and_b32 %[st], %[st], 0xffff\n\t"
+                 "s_add_u32 %[nb], %[nb], 1\n\t"
+                 "s_add_u32 %[slot], %[slot], 1\n\t"
+                 "s_cmp_eq_u32 %[slot], %[wrap]\n\t"
+                 "s_cselect_b32 %[slot], 0, %[slot]\n\t"
+                 "s_mul_i32 %[t], %[slot], 3\n\t"
+                 "s_lshr_b32 %[t], %[sel], %[t]\n\t"
+                 "s_and_b32 %[sd], %[t], 3\n\t"
+                 "s_lshl_b32 %[sd], %[sd], 3\n\t"
+                 "s_and_b32 %[sa], %[t], 4\n\t"
+                 "s_lshl_b32 %[sa], %[sa], 1\n\t"
+                 "s_bitcmp0_b32 %[st], 6\n\t"
+                 "s_cbranch_scc0 8f\n"
+                 "2:\n\t" // the DC symbol
+                 "v_readlane_b32 %[r], %[fd], %[st]\n\t"
+                 "s_lshr_b32 %[r], %[r], %[sd]\n\t"
+                 "s_and_b32 %[r], %[r], 31\n\t"
+                 "s_cbranch_scc0 9f\n\t"
+                 "s_add_u32 %[st], %[st], %[r]\n\t"
+                 "s_add_u32 %[st], %[st], 0x10000\n\t"
+                 "s_bitcmp0_b32 %[st], 6\n\t"
+                 "s_cbranch_scc1 1b\n\t"
+                 "s_branch 8f\n"
+                 "9:\n\t"
+                 "s_mov_b32 %[status], 1\n"
+                 "8:\n\t"
+                 : [status] "=&s"(status), [r] "=&s"(r), [t] "=&s"(t), [st] "+s"(st), [nb] "+s"(nb), [slot] "+s"(slot), [sd] "+s"(sd), [sa] "+s"(sa)
+                 : [fa] "v"(fa), [fd] "v"(fd), [wrap] "s"(wrap), [sel] "s"(sel)
+                 : "scc");
+    return status;
+}
+
+__global__ __launch_bounds__(64) void huffdec_sync_wave_kernel(const DecJob *__restrict__ jobs, int round) {
+    const DecJob &J = jobs[blockIdx.y];
+    const int     i = (int)blockIdx.x;
+    if(i >= J.nchunks) return;
+    int *changed = J.flags + 1;
+    if(round >= 2 && __hip_atomic_load(&changed[round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    const unsigned long long ck_start = uni(J.chunks[i].start), ck_end = uni(J.chunks[i].end);
+    const int                ck_flags = uni(J.chunks[i].flags);
+    const unsigned long long entry = uni(((ck_flags & 1) || round == 0) ? pack_state(ck_start, 0, 0) : __hip_atomic_load(&J.exits[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if(round != 0 && entry == uni(J.seen[i])) return;
+
+    const int                lane = (int)threadIdx.x;
+    const unsigned long long base_bit = (ck_start >> 5) << 5;
+    unsigned long long       p;
+    int                      slot_in, k_in;
+    unpack_state(entry, p, slot_in, k_in);
+    const unsigned wrap = uni((unsigned)J.S.period);
+    unsigned       slot = (unsigned)slot_in >= wrap ? 0u : (unsigned)slot_in, k = (unsigned)k_in, nb = 0;
+    if(p < ck_start) p = ck_start;
+    unsigned long long sub_state[kSubChunks - 1];
+    unsigned           sub_nb[kSubChunks - 1];
+    int                sub_set = 0; // marks reached; the lanes of the others find the final state and nothing to do
+    if(p < ck_end) {
+        unsigned       rel = (unsigned)(p - base_bit);
+        const unsigned rel_end = (unsigned)(ck_end - base_bit);
+        // this lane's word of the chunk (the buffer is padded), handed round with v_readlane
+        const unsigned wv = lane < kChunkWords ? __builtin_bswap32(J.words[(ck_start >> 5) + (unsigned)lane]) : 0u;
+        const unsigned *__restrict__ lut = J.tables;
+        const unsigned *__restrict__ sub = J.tables + ((size_t)J.S.ntab << kLutBits);
+        unsigned place[4];
+#pragma unroll
+        for(int t = 0; t < 4; ++t) place[t] = uni(J.S.wave_place[t]);
+        unsigned E[kWaveWindows][4], E2[kWaveWindows][4], sub_at[kWaveWindows];
+        // first level for every position and table, all in flight together (a table that is not staged reads table 0 and is dropped) ...
+#pragma unroll
+        for(int w = 0; w < kWaveWindows; ++w) {
+            const unsigned w0 = __builtin_amdgcn_readlane(wv, 2 * w), w1 = __builtin_amdgcn_readlane(wv, 2 * w + 1), w2 = __builtin_amdgcn_readlane(wv, 2 * w + 2);
+            const unsigned hi = lane < 32 ? w0 : w1, lo = lane < 32 ? w1 : w2;
+            const unsigned peek = (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (32 - (lane & 31)));
+            sub_at[w] = (peek >> 16) & ((1u << kSubBits) - 1u);
+#pragma unroll
+            for(int t = 0; t < 4; ++t) E[w][t] = lut[(((place[t] & 128u) ? t : 0) << kLutBits) + (peek >> (32 - kLutBits))];
+        }
+        // ... then the second level where any lane met a long code (issued, not waited for)
+#pragma unroll
+        for(int w = 0; w < kWaveWindows; ++w) {
+#pragma unroll
+            for(int t = 0; t < 4; ++t) {
+                const bool link = (E[w][t] & kEntryLink) != 0;
+                E2[w][t] = 0;
+                if(__builtin_amdgcn_ballot_w64(link) != 0) E2[w][t] = sub[link ? (E[w][t] & 0xFFFFu) + sub_at[w] : 0u];
+            }
+        }
+        unsigned FA[kWaveWindows], FD[kWaveWindows];
+#pragma unroll
+        for(int w = 0; w < kWaveWindows; ++w) {
+            unsigned fa = 0, fd = 0;
+#pragma unroll
+            for(int t = 0; t < 4; ++t) {
+                const unsigned e = (E[w][t] & kEntryLink) ? E2[w][t] : E[w][t];
+                const unsigned total = (e >> 16) & 31u, kinc = (e >> 22) & 127u; // an entry of 0 (not a code) gives a field of 0
+                const unsigned ac = (total | ((kinc < 63u ? kinc : 63u) << 16)) << (place[t] & 31u), dc = total << (place[t] & 31u);
+                fa |= (place[t] & 192u) == 192u ? ac : 0u;
+                fd |= (place[t] & 192u) == 128u ? dc : 0u;
+            }
+            const bool inside = 64u * w + (unsigned)lane < rel_end; // positions from the end of the chunk on read as "stop"
+            FA[w] = inside ? fa : 0u;
+            FD[w] = inside ? fd : 0u;
+        }
+        const unsigned sel = uni(J.S.wave_sel);
+        unsigned       sd = ((sel >> (3 * slot)) & 3u) << 3, sa = ((sel >> (3 * slot)) & 4u) << 1;
+        unsigned       st = rel | (k << 16);
+        bool           finished = false;
+#pragma unroll
+        for(int w = 0; w < kWaveWindows; ++w) {
+            if(!finished) {
+                if((st & 0xFFFFu) < 64u) {
+                    if(wave_chain(FA[w], FD[w], st, nb, slot, sd, sa, wrap, sel)) {
+                        const unsigned at = 64u * w + (st & 0xFFFFu);
+                        rel = at >= rel_end ? at : rel_end; // the first symbol past the end / not a code: walk<false> gives up there too
+                        finished = true;
+                    }
+                    else st -= 64u;
+                }
+                else st -= 64u;
+                // the state at a mark: where the store pass's next lane of this chunk starts
+                if(!finished && (w + 1) % (kSubBitsPerLane / 64) == 0 && (w + 1) / (kSubBitsPerLane / 64) < kSubChunks) {
+                    const int j = (w + 1) / (kSubBitsPerLane / 64) - 1;
+                    sub_state[j] = pack_state(base_bit + 64u * (w + 1) + (st & 0xFFFFu), (int)slot, (int)(st >> 16));
+                    sub_nb[j] = nb;
+                    sub_set = j + 1;
+                }
+            }
+        }
+        if(!finished) rel = rel_end; // (cannot happen: the last window ends beyond the chunk)
+        k = st >> 16;
+        p = base_bit + (unsigned long long)rel;
+    }
+    if(lane == 0) {
+        J.seen[i] = entry;
+        const unsigned long long out = pack_state(p, (int)slot, (int)k);
+#pragma unroll
+        for(int j = 0; j < kSubChunks - 1; ++j) {
+            J.substate[(size_t)i * (kSubChunks - 1) + j] = j < sub_set ? sub_state[j] : out;
+            J.subnb[(size_t)i * (kSubChunks - 1) + j] = j < sub_set ? sub_nb[j] : nb;
+        }
+        if(round == 0 || out != J.exits[i] || nb != J.nblk[i]) {
+            J.nblk[i] = nb;
+            __hip_atomic_store(&J.exits[i], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(round != 0) note_change(&changed[round]);
+        }
     }
 }
 
 __global__ __launch_bounds__(kDecThreads) void huffdec_store_kernel(const DecJob *__restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     const DecJob &J = jobs[blockIdx.y];
-    if(blockIdx.x * kDecThreads >= (unsigned)J.nchunks) return;
-    const int  i = blockIdx.x * kDecThreads + threadIdx.x;
+    const int     per = J.subchunks; // lanes per chunk: after wave-per-chunk rounds the states at the marks inside a chunk are known too
+    if((long long)blockIdx.x * kDecThreads >= (long long)J.nchunks * per) return;
+    const int  lane_id = blockIdx.x * kDecThreads + threadIdx.x;
+    const int  i = lane_id / per, j = lane_id - i * per;
     const bool active = i < J.nchunks;
-    DecChunk   ck = {};
-    if(active) ck = J.chunks[i];
-    stage_shared(lds, J.S, J.tables, J.words, ck, active);
+    DecChunk   ck = {}, mine = {};
+    if(active) {
+        ck = J.chunks[i];
+        // this lane's part of the chunk: symbols that start in [mark j, mark j + 1) counted from the word the chunk starts in
+        const unsigned long long base = (ck.start >> 5) << 5;
+        mine = ck;
+        if(j > 0) mine.start = base + (unsigned long long)j * kSubBitsPerLane;
+        if(j + 1 < per && base + (unsigned long long)(j + 1) * kSubBitsPerLane < ck.end) mine.end = base + (unsigned long long)(j + 1) * kSubBitsPerLane;
+        if(mine.start > ck.end) mine.start = ck.end; // a short chunk: nothing there (and nothing staged from beyond the padding)
+    }
+    stage_shared(lds, J.S, J.tables, J.words, mine, active);
     if(!active) return;
+    // Nothing of the chunk starts at or after this lane's mark: its record is the rounds' final state, which at the end of a
+    // segment has walked on into the padding (the rounds do not know where the blocks end; the lane before this one does).
+    if(j > 0 && mine.start >= ck.end) return;
     const DecScan &S = J.S;
     if(J.totals[0] != (unsigned long long)S.nslots) { // the stream does not hold this image
-        if(i == 0) atomicOr(&J.flags[0], 2);
+        if(lane_id == 0) atomicOr(&J.flags[0], 2);
         return;
     }
     const DecLds    L = carve(lds, S.ntab, S.nsub);
@@ -294,13 +505,19 @@ __global__ __launch_bounds__(kDecThreads) void huffdec_store_kernel(const DecJob
     int                slot, k, err = 0;
     unsigned           nb = 0;
     long long          t = (long long)(J.ctot[i / kScanItems] + J.cpre[i]);
-    unpack_state((ck.flags & 1) ? pack_state(ck.start, 0, 0) : J.exits[i - 1], p, slot, k);
-    if((ck.flags & 1) && t != seg_t0) err = 1; // a restart segment with the wrong number of blocks
-    if(t < seg_t0 || t > t_stop || slot != (int)((t % S.bpm) % S.period) || p < ck.start) err = 1;
+    if(j == 0) {
+        unpack_state((ck.flags & 1) ? pack_state(ck.start, 0, 0) : J.exits[i - 1], p, slot, k);
+        if((ck.flags & 1) && t != seg_t0) err = 1; // a restart segment with the wrong number of blocks
+    }
+    else {
+        unpack_state(J.substate[(size_t)i * (kSubChunks - 1) + (j - 1)], p, slot, k);
+        t += J.subnb[(size_t)i * (kSubChunks - 1) + (j - 1)];
+    }
+    if(t < seg_t0 || t > t_stop || slot != (int)((t % S.bpm) % S.period) || p < mine.start) err = 1;
     slot = (int)(t % S.bpm);
     if(err == 0) {
-        if(p < ck.end) walk<true>(L, S.dcpack, S.acpack, (ck.start >> 5) << 5, p, ck.end, slot, S.bpm, k, nb, t, t_stop, err);
-        if(ck.flags & 2) {
+        if(p < mine.end) walk<true>(L, S.dcpack, S.acpack, (mine.start >> 5) << 5, p, mine.end, slot, S.bpm, k, nb, t, t_stop, err);
+        if((ck.flags & 2) && mine.end == ck.end) { // the lane that reaches the end of the segment
             if(t != t_stop || k != 0 || p > ck.end) err = 1; // segment ended inside a block / blocks missing
         }
     }
@@ -580,6 +797,18 @@ int max_leaders() {
     return n;
 }
 
+// Chunks of a batch up to which the synchronisation rounds run one wavefront per chunk (MJX_DECODE_WAVE_CHUNKS; 0: never).
+// Measured (profiles/r03/decode_wave_rounds.md): a 1080p quality-85 stream (4 000 chunks) 0.57 -> 0.33 ms of kernels, a 4K
+// quality-85 one (15 700) 0.67 -> 0.61; at 28 700 chunks (4K quality 95) the first rounds have seven wavefronts per SIMD
+// to get through and one lane per chunk is faster again, as it is for the batches of the multi-threaded tool.
+long long wave_chunk_limit() {
+    static const long long n = [] {
+        const char *e = getenv("MJX_DECODE_WAVE_CHUNKS");
+        return e ? atoll(e) : 16384ll;
+    }();
+    return n;
+}
+
 // the leader's part: one set of kernels over all images of the batch, on the leader's stream
 void run_batch(Request *lead, Request **batch, int n) {
     hipStream_t s = lead->arena->stream;
@@ -600,16 +829,31 @@ void run_batch(Request *lead, Request **batch, int n) {
     }
     if(hipMemsetAsync(d_flags, 0, sizeof(int) * (size_t)kFlagInts * (size_t)n, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
 
+    // One wavefront per chunk while the device has the wavefronts to spare (a lone caller, a small batch), one lane per
+    // chunk beyond.  Decided once: the store pass's lanes per chunk rely on what the LAST walk of every chunk left behind.
+    bool waves = true;
+    {
+        long long all_chunks = 0;
+        for(int i = 0; i < n; ++i) {
+            all_chunks += batch[i]->job.nchunks;
+            if(!batch[i]->job.S.wave_ok) waves = false;
+        }
+        if(all_chunks > wave_chunk_limit()) waves = false;
+    }
+    const int per = waves ? kSubChunks : 1;
+
     int pending[kMaxBatch], npending = n, round = 0;
     for(int i = 0; i < n; ++i) pending[i] = i;
     while(npending > 0) {
         const int first = round;
         int       nrounds = round == 0 ? 2 : kMoreRounds;
-        unsigned  cbx = 1, dbx = 1, gcx = 1, gdx = 1;
+        unsigned  cbx = 1, dbx = 1, gcx = 1, gdx = 1, most_chunks = 1;
         size_t    lds = 0;
         for(int k = 0; k < npending; ++k) {
             const Request *r = batch[pending[k]];
             h_jobs[k] = r->job;
+            h_jobs[k].subchunks = per;
+            if((unsigned)r->job.nchunks > most_chunks) most_chunks = (unsigned)r->job.nchunks;
             if(round == 0 && r->first_rounds > nrounds) nrounds = r->first_rounds;
             if(r->chunk_wgs > cbx) cbx = r->chunk_wgs;
             if(r->dc_wgs > dbx) dbx = r->dc_wgs;
@@ -622,11 +866,14 @@ void run_batch(Request *lead, Request **batch, int n) {
         // 1. synchronisation rounds.  Settled rounds cost a launch each, so a generous batch of them
         //    is queued together with everything that follows; the flags are looked at once, at the
         //    end, and only an image that had not settled by then goes round again.
-        for(int r = 0; r < nrounds; ++r, ++round) hipLaunchKernelGGL(huffdec_sync_kernel, dim3(cbx, m), dim3(kDecThreads), lds, s, d_jobs, round);
+        for(int r = 0; r < nrounds; ++r, ++round) {
+            if(waves) hipLaunchKernelGGL(huffdec_sync_wave_kernel, dim3(most_chunks, m), dim3(64), 0, s, d_jobs, round);
+            else hipLaunchKernelGGL(huffdec_sync_kernel, dim3(cbx, m), dim3(kDecThreads), lds, s, d_jobs, round);
+        }
         // 2.-4. block offsets, coefficients, DC values (wasted for an image whose rounds had not settled: rare)
         hipLaunchKernelGGL(huffdec_scan_groups_kernel, dim3(gcx, m), dim3(kScanThreads), 0, s, d_jobs, 0);
         hipLaunchKernelGGL(huffdec_scan_totals_kernel, dim3(1, m), dim3(kScanThreads), 0, s, d_jobs, 0);
-        hipLaunchKernelGGL(huffdec_store_kernel, dim3(cbx, m), dim3(kDecThreads), lds, s, d_jobs);
+        hipLaunchKernelGGL(huffdec_store_kernel, dim3((most_chunks * (unsigned)per + kDecThreads - 1) / kDecThreads, m), dim3(kDecThreads), lds, s, d_jobs);
         hipLaunchKernelGGL(huffdec_dc_gather_kernel, dim3(dbx, m), dim3(256), 0, s, d_jobs);
         hipLaunchKernelGGL(huffdec_scan_groups_kernel, dim3(gdx, m), dim3(kScanThreads), 0, s, d_jobs, 1);
         hipLaunchKernelGGL(huffdec_scan_totals_kernel, dim3(1, m), dim3(kScanThreads), 0, s, d_jobs, 1);
@@ -683,7 +930,8 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
         TableBuilder *b;
         ~Free() { delete b; }
     } free_builder{B};
-    int comp_dc[4] = {0, 0, 0, 0}, comp_ac[4] = {0, 0, 0, 0};
+    int  comp_dc[4] = {0, 0, 0, 0}, comp_ac[4] = {0, 0, 0, 0};
+    bool staged_is_dc[8] = {false, false, false, false, false, false, false, false};
     for(int c = 0; c < S.ncomp; ++c) {
         const mjx_huff_dcomponent_t &h = scan->comp[c];
         if(h.plane == nullptr) return MJX_ERR_NULL_DATA;
@@ -692,6 +940,7 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
             return MJX_ERR_BAD_ARG;
         if(dc_of[h.dc_tbl] < 0) {
             dc_of[h.dc_tbl] = B->ntab;
+            staged_is_dc[B->ntab] = true;
             if(!derive(scan->dc[h.dc_tbl], *B, true)) return MJX_ERR_BAD_ARG;
         }
         if(ac_of[h.ac_tbl] < 0) {
@@ -722,6 +971,15 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     }
     S.nslots = nmcu * S.bpm;
     S.ntab = B->ntab;
+    { // the wave-per-chunk walk keeps up to four DC and two AC fields per bit position
+        int field_of[8], nd = 0, na = 0;
+        for(int t = 0; t < B->ntab; ++t) field_of[t] = staged_is_dc[t] ? nd++ : na++;
+        S.wave_ok = B->ntab <= 4 && nd <= 4 && na <= 2;
+        if(S.wave_ok) {
+            for(int t = 0; t < B->ntab; ++t) S.wave_place[t] = 128u | (staged_is_dc[t] ? 0u : 64u) | (unsigned)(8 * field_of[t]);
+            for(int b = 0; b < S.bpm; ++b) S.wave_sel |= (unsigned)(field_of[comp_dc[S.slot_comp[b]]] | (field_of[comp_ac[S.slot_comp[b]]] << 2)) << (3 * b);
+        }
+    }
     S.nsub = B->nsub;
     if(S.nslots > 0x7FFFFFFFll) return MJX_ERR_BAD_ARG;
     for(S.period = 1; S.period < S.bpm; ++S.period) {
@@ -755,6 +1013,8 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     const size_t o_words = off;  off += up256(data_bytes);
     const size_t o_exit = off;   off += up256((size_t)max_chunks * 8);
     const size_t o_seen = off;   off += up256((size_t)max_chunks * 8);
+    const size_t o_subst = off;  off += up256((size_t)max_chunks * (kSubChunks - 1) * 8);
+    const size_t o_subnb = off;  off += up256((size_t)max_chunks * (kSubChunks - 1) * 4);
     const size_t o_nblk = off;   off += up256((size_t)max_chunks * 4);
     const size_t o_cpre = off;   off += up256((size_t)max_chunks * 4);
     const size_t o_ctot = off;   off += up256((size_t)gc * 8);
@@ -834,6 +1094,9 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     J.chunks = reinterpret_cast<const DecChunk *>(base + o_chunks);
     J.exits = reinterpret_cast<unsigned long long *>(base + o_exit);
     J.seen = reinterpret_cast<unsigned long long *>(base + o_seen);
+    J.substate = reinterpret_cast<unsigned long long *>(base + o_subst);
+    J.subnb = reinterpret_cast<unsigned *>(base + o_subnb);
+    J.subchunks = 1;
     J.nblk = reinterpret_cast<unsigned *>(base + o_nblk);
     J.cpre = reinterpret_cast<unsigned *>(base + o_cpre);
     J.ctot = reinterpret_cast<unsigned long long *>(base + o_ctot);
