@@ -62,10 +62,9 @@ struct DecScan {
     int                ntab, nsub;
     long long          nslots;
     unsigned long long dcpack, acpack; // 4 bits per slot: index of the slot's DC / AC table among the staged ones
-    // the wave-per-chunk walk (huffdec_sync_wave_kernel): where each staged table's field sits in a lane's two packed registers
-    // (bit 7: staged, bit 6: an AC table, low bits: shift), 3 bits per slot (DC field index | AC field index << 2), and whether
-    // the tables fit at all (at most four DC and two AC tables)
-    unsigned wave_place[4], wave_sel, wave_ok;
+    // the wave-per-chunk walk (huffdec_sync_wave_kernel): AC and DC tables in use (at most two and four: wave_ok), and
+    // 3 bits per slot: index of its DC field | index of its AC field << 2
+    unsigned wave_nac, wave_ndc, wave_sel, wave_ok;
     DecComp            c[4];
     int                slot_comp[kDecMaxSlots], slot_x[kDecMaxSlots], slot_y[kDecMaxSlots];
 };
@@ -76,6 +75,7 @@ struct DecChunk {
     int                flags;      // 1: first chunk of its segment, 2: last
 };
 
+constexpr int kWaveSlots = 6; // wave-per-chunk walk: tables 0, 1 are the AC tables, 2..5 the DC tables
 constexpr int kSubChunks = 4, kSubBitsPerLane = kChunkBits / kSubChunks; // store pass after wave-per-chunk rounds: four lanes share a chunk
 constexpr int kMaxRounds = 192, kMoreRounds = 12;
 constexpr int kFlagInts = kMaxRounds + 2; // per image: [0] error, [1 + r] round r changed something
@@ -85,6 +85,7 @@ constexpr int kMaxBatch = 32;
 struct DecJob {
     DecScan             S;
     const unsigned     *tables;
+    const unsigned     *wtables; // wave-per-chunk walk: kWaveSlots first-level tables of ready-made fields, then the second-level ones
     const unsigned     *words;
     const DecChunk     *chunks;
     unsigned long long *exits, *seen;
@@ -303,24 +304,30 @@ __device__ __forceinline__ int                uni(int v) { return __builtin_amdg
 __device__ __forceinline__ unsigned long long uni(unsigned long long v) { return ((unsigned long long)uni((unsigned)(v >> 32)) << 32) | (unsigned long long)uni((unsigned)v); }
 
 // The chain through one window.  st = position in the window | k << 16; returns 0 when the position left the window
-// (st's position >= 64), 1 when it met a zero field (st, nb, slot as they were before that symbol).
+// (st's position >= 64), 1 when it met "not a code" (st, nb, slot as they were before that symbol).  An AC field that is
+// not a code reads total 0, advance 63: the one test per symbol (block complete or window left) catches it as a block end,
+// where a total of 0 tells it apart.  Taken branches cost a wavefront most, so the AC loop is four symbols long.
 __device__ __forceinline__ unsigned wave_chain(unsigned fa, unsigned fd, unsigned &st, unsigned &nb, unsigned &slot, unsigned &sd, unsigned &sa, unsigned wrap, unsigned sel) {
     unsigned status, r, t;
     asm volatile("s_mov_b32 %[status], 0\n\t"
                  "s_cmp_lt_u32 %[st], 0x10000\n\t"
                  "s_cbranch_scc1 2f\n"
                  "1:\n\t" // AC symbols of the current block
+                 ".rept 4\n\t"
                  "v_readlane_b32 %[r], %[fa], %[st]\n\t"
                  "s_lshr_b32 %[r], %[r], %[sa]\n\t"
                  "s_and_b32 %[r], %[r], 0x003f001f\n\t"
-                 "s_cbranch_scc0 9f\n\t"
                  "s_add_u32 %[st], %[st], %[r]\n\t"
-                 "s_bitcmp1_b32 %[st], 22\n\t"
+                 "s_and_b32 %[t], %[st], 0x400040\n\t"
                  "s_cbranch_scc1 3f\n\t"
-                 "s_bitcmp0_b32 %[st], 6\n\t"
-                 "s_cbranch_scc1 1b\n\t"
-                 "s_branch 8f\n"
-                 "3:\n\t" // the block is complete: next slot, its tables
+                 ".endr\n\t"
+                 "s_branch 1b\n"
+                 "3:\n\t" // k >= 64 and / or the position left the window
+                 "s_bitcmp1_b32 %[st], 22\n\t"
+                 "s_cbranch_scc0 8f\n\t"
+                 "s_and_b32 %[t], %[r], 31\n\t"
+                 "s_cbranch_scc0 7f\n\t"
+                 // the block is complete: next slot, its tables
                  "s_and_b32 %[st], %[st], 0xffff\n\t"
                  "s_add_u32 %[nb], %[nb], 1\n\t"
                  "s_add_u32 %[slot], %[slot], 1\n\t"
@@ -344,6 +351,8 @@ __device__ __forceinline__ unsigned wave_chain(unsigned fa, unsigned fd, unsigne
                  "s_bitcmp0_b32 %[st], 6\n\t"
                  "s_cbranch_scc1 1b\n\t"
                  "s_branch 8f\n"
+                 "7:\n\t" // not a code in AC context: take the step back
+                 "s_sub_u32 %[st], %[st], %[r]\n"
                  "9:\n\t"
                  "s_mov_b32 %[status], 1\n"
                  "8:\n\t"
@@ -353,74 +362,52 @@ __device__ __forceinline__ unsigned wave_chain(unsigned fa, unsigned fd, unsigne
     return status;
 }
 
-__global__ __launch_bounds__(64) void huffdec_sync_wave_kernel(const DecJob *__restrict__ jobs, int round) {
-    const DecJob &J = jobs[blockIdx.y];
-    const int     i = (int)blockIdx.x;
-    if(i >= J.nchunks) return;
-    int *changed = J.flags + 1;
-    if(round >= 2 && __hip_atomic_load(&changed[round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-    const unsigned long long ck_start = uni(J.chunks[i].start), ck_end = uni(J.chunks[i].end);
-    const int                ck_flags = uni(J.chunks[i].flags);
-    const unsigned long long entry = uni(((ck_flags & 1) || round == 0) ? pack_state(ck_start, 0, 0) : __hip_atomic_load(&J.exits[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if(round != 0 && entry == uni(J.seen[i])) return;
-
-    const int                lane = (int)threadIdx.x;
-    const unsigned long long base_bit = (ck_start >> 5) << 5;
-    unsigned long long       p;
-    int                      slot_in, k_in;
-    unpack_state(entry, p, slot_in, k_in);
-    const unsigned wrap = uni((unsigned)J.S.period);
-    unsigned       slot = (unsigned)slot_in >= wrap ? 0u : (unsigned)slot_in, k = (unsigned)k_in, nb = 0;
-    if(p < ck_start) p = ck_start;
-    unsigned long long sub_state[kSubChunks - 1];
-    unsigned           sub_nb[kSubChunks - 1];
-    int                sub_set = 0; // marks reached; the lanes of the others find the final state and nothing to do
-    if(p < ck_end) {
+// the walk of one chunk by one wavefront, for NAC AC tables and NDC DC tables (unused slots of the generic form hold zero tables)
+template <int NAC, int NDC>
+__device__ __forceinline__ void wave_walk(const DecJob &J, const unsigned *wl, int lane, unsigned long long ck_start, unsigned long long ck_end, unsigned long long base_bit, unsigned wrap,
+                                          unsigned long long &p, unsigned &slot, unsigned &k, unsigned &nb, unsigned long long *sub_state, unsigned *sub_nb, int &sub_set) {
+    {
         unsigned       rel = (unsigned)(p - base_bit);
         const unsigned rel_end = (unsigned)(ck_end - base_bit);
         // this lane's word of the chunk (the buffer is padded), handed round with v_readlane
         const unsigned wv = lane < kChunkWords ? __builtin_bswap32(J.words[(ck_start >> 5) + (unsigned)lane]) : 0u;
-        const unsigned *__restrict__ lut = J.tables;
-        const unsigned *__restrict__ sub = J.tables + ((size_t)J.S.ntab << kLutBits);
-        unsigned place[4];
+        // wl: the tables of ready-made fields (built by the host next to the decoding tables, staged in LDS by the workgroup):
+        // first level [kWaveSlots][1 << kLutBits], an entry either the field already shifted into place or kEntryLink | offset
+        // of a second-level table.  (From global memory these gathers — 64 lanes, up to 32 cache lines — are what a round of
+        // a whole image waits for: one L1 per CU serves sixteen wavefronts' worth of them.)
+        const unsigned *wsub = wl + (kWaveSlots << kLutBits);
+        unsigned        FA[kWaveWindows], FD[kWaveWindows];
+        // six windows at a time (the entries in flight are what a wavefront's registers go to: four wavefronts per SIMD fit this way)
 #pragma unroll
-        for(int t = 0; t < 4; ++t) place[t] = uni(J.S.wave_place[t]);
-        unsigned E[kWaveWindows][4], E2[kWaveWindows][4], sub_at[kWaveWindows];
-        // first level for every position and table, all in flight together (a table that is not staged reads table 0 and is dropped) ...
+        for(int g = 0; g < kWaveWindows; g += 6) {
+            unsigned E[6][kWaveSlots], sub_at[6];
+            // first level for every position and table of the group, all in flight together ...
 #pragma unroll
-        for(int w = 0; w < kWaveWindows; ++w) {
-            const unsigned w0 = __builtin_amdgcn_readlane(wv, 2 * w), w1 = __builtin_amdgcn_readlane(wv, 2 * w + 1), w2 = __builtin_amdgcn_readlane(wv, 2 * w + 2);
-            const unsigned hi = lane < 32 ? w0 : w1, lo = lane < 32 ? w1 : w2;
-            const unsigned peek = (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (32 - (lane & 31)));
-            sub_at[w] = (peek >> 16) & ((1u << kSubBits) - 1u);
+            for(int u = 0; u < 6; ++u) {
+                const int w = g + u;
+                if(w < kWaveWindows) {
+                    const unsigned w0 = __builtin_amdgcn_readlane(wv, 2 * w), w1 = __builtin_amdgcn_readlane(wv, 2 * w + 1), w2 = __builtin_amdgcn_readlane(wv, 2 * w + 2);
+                    const unsigned hi = lane < 32 ? w0 : w1, lo = lane < 32 ? w1 : w2;
+                    const unsigned peek = (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (32 - (lane & 31)));
+                    const unsigned at = peek >> (32 - kLutBits);
+                    sub_at[u] = (peek >> 16) & ((1u << kSubBits) - 1u);
 #pragma unroll
-            for(int t = 0; t < 4; ++t) E[w][t] = lut[(((place[t] & 128u) ? t : 0) << kLutBits) + (peek >> (32 - kLutBits))];
-        }
-        // ... then the second level where any lane met a long code (issued, not waited for)
-#pragma unroll
-        for(int w = 0; w < kWaveWindows; ++w) {
-#pragma unroll
-            for(int t = 0; t < 4; ++t) {
-                const bool link = (E[w][t] & kEntryLink) != 0;
-                E2[w][t] = 0;
-                if(__builtin_amdgcn_ballot_w64(link) != 0) E2[w][t] = sub[link ? (E[w][t] & 0xFFFFu) + sub_at[w] : 0u];
+                    for(int t = 0; t < kWaveSlots; ++t) E[u][t] = (t < 2 ? t < NAC : t - 2 < NDC) ? wl[(t << kLutBits) + at] : 0u;
+                }
             }
-        }
-        unsigned FA[kWaveWindows], FD[kWaveWindows];
+            // ... then the second level for the lanes that met a long code
 #pragma unroll
-        for(int w = 0; w < kWaveWindows; ++w) {
-            unsigned fa = 0, fd = 0;
+            for(int u = 0; u < 6; ++u) {
+                const int w = g + u;
+                if(w < kWaveWindows) {
 #pragma unroll
-            for(int t = 0; t < 4; ++t) {
-                const unsigned e = (E[w][t] & kEntryLink) ? E2[w][t] : E[w][t];
-                const unsigned total = (e >> 16) & 31u, kinc = (e >> 22) & 127u; // an entry of 0 (not a code) gives a field of 0
-                const unsigned ac = (total | ((kinc < 63u ? kinc : 63u) << 16)) << (place[t] & 31u), dc = total << (place[t] & 31u);
-                fa |= (place[t] & 192u) == 192u ? ac : 0u;
-                fd |= (place[t] & 192u) == 128u ? dc : 0u;
+                    for(int t = 0; t < kWaveSlots; ++t)
+                        if((t < 2 ? t < NAC : t - 2 < NDC) && (int)E[u][t] < 0) E[u][t] = wsub[(E[u][t] & 0xFFFFu) + sub_at[u]];
+                    const bool inside = 64u * w + (unsigned)lane < rel_end; // positions from the end of the chunk on read as "not a code"
+                    FA[w] = inside ? E[u][0] | E[u][1] : 0x3F3F0000u;
+                    FD[w] = inside ? E[u][2] | E[u][3] | E[u][4] | E[u][5] : 0u;
+                }
             }
-            const bool inside = 64u * w + (unsigned)lane < rel_end; // positions from the end of the chunk on read as "stop"
-            FA[w] = inside ? fa : 0u;
-            FD[w] = inside ? fd : 0u;
         }
         const unsigned sel = uni(J.S.wave_sel);
         unsigned       sd = ((sel >> (3 * slot)) & 3u) << 3, sa = ((sel >> (3 * slot)) & 4u) << 1;
@@ -450,6 +437,55 @@ __global__ __launch_bounds__(64) void huffdec_sync_wave_kernel(const DecJob *__r
         if(!finished) rel = rel_end; // (cannot happen: the last window ends beyond the chunk)
         k = st >> 16;
         p = base_bit + (unsigned long long)rel;
+    }
+}
+
+constexpr int kWaveGroup = 4; // wavefronts (chunks) of a workgroup: they share the staged tables
+
+__global__ __launch_bounds__(64 * kWaveGroup) void huffdec_sync_wave_kernel(const DecJob *__restrict__ jobs, int round) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    const DecJob &J = jobs[blockIdx.y];
+    if((int)blockIdx.x * kWaveGroup >= J.nchunks) return;
+    int *changed = J.flags + 1;
+    if(round >= 2 && __hip_atomic_load(&changed[round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    const int          i = uni((int)blockIdx.x * kWaveGroup + (int)(threadIdx.x >> 6));
+    const bool         in_range = i < J.nchunks;
+    unsigned long long ck_start = 0, ck_end = 0, entry = 0;
+    bool               active = false;
+    if(in_range) {
+        ck_start = uni(J.chunks[i].start);
+        ck_end = uni(J.chunks[i].end);
+        const int ck_flags = uni(J.chunks[i].flags);
+        entry = uni(((ck_flags & 1) || round == 0) ? pack_state(ck_start, 0, 0) : __hip_atomic_load(&J.exits[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        active = round == 0 || entry != uni(J.seen[i]);
+    }
+    if(__syncthreads_or(active ? 1 : 0) == 0) return; // nothing to redo in this workgroup
+    {
+        const int   words = (kWaveSlots << kLutBits) + (J.S.nsub << kSubBits); // a multiple of four
+        const uint4 *src = reinterpret_cast<const uint4 *>(J.wtables);
+        uint4       *dst = reinterpret_cast<uint4 *>(lds);
+        for(int q = threadIdx.x; q < words / 4; q += 64 * kWaveGroup) dst[q] = src[q];
+    }
+    __syncthreads();
+    if(!active) return;
+    const unsigned *wl = lds;
+
+    const int                lane = (int)(threadIdx.x & 63u);
+    const unsigned long long base_bit = (ck_start >> 5) << 5;
+    unsigned long long       p;
+    int                      slot_in, k_in;
+    unpack_state(entry, p, slot_in, k_in);
+    const unsigned wrap = uni((unsigned)J.S.period);
+    unsigned       slot = (unsigned)slot_in >= wrap ? 0u : (unsigned)slot_in, k = (unsigned)k_in, nb = 0;
+    if(p < ck_start) p = ck_start;
+    unsigned long long sub_state[kSubChunks - 1];
+    unsigned           sub_nb[kSubChunks - 1];
+    int                sub_set = 0; // marks reached; the lanes of the others find the final state and nothing to do
+    if(p < ck_end) {
+        const unsigned nac = uni(J.S.wave_nac), ndc = uni(J.S.wave_ndc);
+        if(nac == 2 && ndc == 2) wave_walk<2, 2>(J, wl, lane, ck_start, ck_end, base_bit, wrap, p, slot, k, nb, sub_state, sub_nb, sub_set);
+        else if(nac == 1 && ndc == 1) wave_walk<1, 1>(J, wl, lane, ck_start, ck_end, base_bit, wrap, p, slot, k, nb, sub_state, sub_nb, sub_set);
+        else wave_walk<2, 4>(J, wl, lane, ck_start, ck_end, base_bit, wrap, p, slot, k, nb, sub_state, sub_nb, sub_set);
     }
     if(lane == 0) {
         J.seen[i] = entry;
@@ -522,6 +558,19 @@ __global__ __launch_bounds__(kDecThreads) void huffdec_store_kernel(const DecJob
         }
     }
     if(err) atomicOr(&J.flags[0], 1);
+}
+
+// ---- the planes start from zero (a block's coefficients after its last symbol are never written).  hipMemsetAsync drops
+// to ~8 GB/s somewhere between 17 and 66 MB (measured on the 8K planes: 12.6 ms for 100 MB), a plain store loop does not.
+struct ZeroPlanes {
+    uint4 *p[4];
+    size_t n16[4]; // 16-byte units (plane sizes are multiples of 128 bytes)
+};
+__global__ __launch_bounds__(256) void huffdec_zero_kernel(ZeroPlanes z) {
+    const uint4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for(int c = 0; c < 4; ++c)
+        for(size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < z.n16[c]; q += (size_t)gridDim.x * 256) z.p[c][q] = zero;
 }
 
 // ---- prefix sums over every image of the batch (which = 0: block counts of the chunks, 1: DC differences)
@@ -652,6 +701,34 @@ bool derive(const mjx_huff_spec_t *spec, TableBuilder &B, bool is_dc) {
     }
     B.ntab++;
     return true;
+}
+
+// The decoding tables restated for the wave-per-chunk walk: what the chain needs of a symbol, already where the chain
+// looks for it.  AC table a: total length (code + value bits) at bits 8a..8a+4, zigzag advance at bits 16+8a..21+8a (EOB: 63);
+// DC table d: total length at bits 8d..8d+4.  Not a code: 0 (DC), total 0 with advance 63 (AC).  Long codes keep their link
+// to the second level.
+void wave_tables(const TableBuilder &B, const bool *is_dc, const int *field_of, unsigned *out) {
+    memset(out, 0, ((size_t)kWaveSlots << (kLutBits + 2)) + ((size_t)B.nsub << (kSubBits + 2)));
+    unsigned *wsub = out + ((size_t)kWaveSlots << kLutBits);
+    for(int t = 0; t < B.ntab; ++t) {
+        const int  shift = 8 * field_of[t];
+        unsigned  *wl = out + ((size_t)(is_dc[t] ? 2 + field_of[t] : field_of[t]) << kLutBits);
+        const auto field = [&](unsigned e) -> unsigned {
+            if(e == 0) return is_dc[t] ? 0u : (63u << 16) << shift; // not a code (AC: total 0, advance 63 — see wave_chain)
+            const unsigned total = (e >> 16) & 31u, kinc = (e >> 22) & 127u;
+            return (is_dc[t] ? total : (total | ((kinc < 63u ? kinc : 63u) << 16))) << shift;
+        };
+        for(int i = 0; i < (1 << kLutBits); ++i) {
+            const unsigned e = B.lut[t][i];
+            if(e & kEntryLink) {
+                wl[i] = e;
+                const unsigned *src = B.sub[(e & 0xFFFFu) >> kSubBits];
+                unsigned       *dst = wsub + (e & 0xFFFFu);
+                for(int j = 0; j < (1 << kSubBits); ++j) dst[j] = field(src[j]);
+            }
+            else wl[i] = field(e);
+        }
+    }
 }
 
 // scan data as it stands in the file -> bytes without stuffing, the restart segments' offsets.
@@ -797,6 +874,24 @@ int max_leaders() {
     return n;
 }
 
+bool zero_planes(char *const *ptr, const size_t *len, int ncomp, hipStream_t s) {
+    ZeroPlanes z = {};
+    size_t     most = 0;
+    for(int c = 0; c < ncomp; ++c) {
+        if((reinterpret_cast<uintptr_t>(ptr[c]) & 15u) != 0 || (len[c] & 15u) != 0) { // a caller's plane at an odd address: the library call
+            if(hipMemsetAsync(ptr[c], 0, len[c], s) != hipSuccess) return false;
+            continue;
+        }
+        z.p[c] = reinterpret_cast<uint4 *>(ptr[c]);
+        z.n16[c] = len[c] / 16;
+        if(z.n16[c] > most) most = z.n16[c];
+    }
+    if(most == 0) return true;
+    const size_t wgs = (most + 256 * 8 - 1) / (256 * 8); // about eight stores per lane and plane
+    hipLaunchKernelGGL(huffdec_zero_kernel, dim3((unsigned)(wgs < 1 ? 1 : (wgs > 16384 ? 16384 : wgs))), dim3(256), 0, s, z);
+    return hipGetLastError() == hipSuccess;
+}
+
 // Chunks of a batch up to which the synchronisation rounds run one wavefront per chunk (MJX_DECODE_WAVE_CHUNKS; 0: never).
 // Measured (profiles/r03/decode_wave_rounds.md): a 1080p quality-85 stream (4 000 chunks) 0.57 -> 0.33 ms of kernels, a 4K
 // quality-85 one (15 700) 0.67 -> 0.61; at 28 700 chunks (4K quality 95) the first rounds have seven wavefronts per SIMD
@@ -848,7 +943,7 @@ void run_batch(Request *lead, Request **batch, int n) {
         const int first = round;
         int       nrounds = round == 0 ? 2 : kMoreRounds;
         unsigned  cbx = 1, dbx = 1, gcx = 1, gdx = 1, most_chunks = 1;
-        size_t    lds = 0;
+        size_t    lds = 0, wave_lds = 0;
         for(int k = 0; k < npending; ++k) {
             const Request *r = batch[pending[k]];
             h_jobs[k] = r->job;
@@ -860,6 +955,15 @@ void run_batch(Request *lead, Request **batch, int n) {
             if((unsigned)r->job.chunk_groups > gcx) gcx = (unsigned)r->job.chunk_groups;
             if((unsigned)r->job.dc_groups > gdx) gdx = (unsigned)r->job.dc_groups;
             if(r->lds_bytes > lds) lds = r->lds_bytes;
+            const size_t wl = (((size_t)kWaveSlots << kLutBits) + ((size_t)r->job.S.nsub << kSubBits)) * 4;
+            if(wl > wave_lds) wave_lds = wl;
+        }
+        static const bool debug = getenv("MJX_HUFFDEC_DEBUG") != nullptr;
+        struct timespec   tqs, tq0, tq1, tq2;
+        if(debug) {
+            clock_gettime(CLOCK_MONOTONIC, &tqs);
+            (void)hipStreamSynchronize(s); // what was staged before the batch: separate it from the batch's own kernels
+            clock_gettime(CLOCK_MONOTONIC, &tq0);
         }
         if(hipMemcpyAsync(d_jobs, h_jobs, sizeof(DecJob) * (size_t)npending, hipMemcpyHostToDevice, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
         const unsigned m = (unsigned)npending;
@@ -867,7 +971,7 @@ void run_batch(Request *lead, Request **batch, int n) {
         //    is queued together with everything that follows; the flags are looked at once, at the
         //    end, and only an image that had not settled by then goes round again.
         for(int r = 0; r < nrounds; ++r, ++round) {
-            if(waves) hipLaunchKernelGGL(huffdec_sync_wave_kernel, dim3(most_chunks, m), dim3(64), 0, s, d_jobs, round);
+            if(waves) hipLaunchKernelGGL(huffdec_sync_wave_kernel, dim3((most_chunks + kWaveGroup - 1) / kWaveGroup, m), dim3(64 * kWaveGroup), wave_lds, s, d_jobs, round);
             else hipLaunchKernelGGL(huffdec_sync_kernel, dim3(cbx, m), dim3(kDecThreads), lds, s, d_jobs, round);
         }
         // 2.-4. block offsets, coefficients, DC values (wasted for an image whose rounds had not settled: rare)
@@ -880,7 +984,13 @@ void run_batch(Request *lead, Request **batch, int n) {
         hipLaunchKernelGGL(huffdec_dc_finish_kernel, dim3(dbx, m), dim3(256), 0, s, d_jobs);
         if(hipGetLastError() != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
         if(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * (size_t)kFlagInts * (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+        if(debug) clock_gettime(CLOCK_MONOTONIC, &tq1);
         if(hipStreamSynchronize(s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+        if(debug) {
+            clock_gettime(CLOCK_MONOTONIC, &tq2);
+            fprintf(stderr, "mjx_huff_decode_host: batch of %d, rounds %d..%d %s: staged work took %.3f ms more, queued in %.3f ms, finished %.3f ms later\n", npending, first, round - 1, waves ? "(a wavefront per chunk)" : "(a lane per chunk)",
+                    (tq0.tv_sec - tqs.tv_sec) * 1e3 + (tq0.tv_nsec - tqs.tv_nsec) * 1e-6, (tq1.tv_sec - tq0.tv_sec) * 1e3 + (tq1.tv_nsec - tq0.tv_nsec) * 1e-6, (tq2.tv_sec - tq1.tv_sec) * 1e3 + (tq2.tv_nsec - tq1.tv_nsec) * 1e-6);
+        }
 
         int keep = 0;
         for(int k = 0; k < npending; ++k) {
@@ -896,8 +1006,7 @@ void run_batch(Request *lead, Request **batch, int n) {
                 r->result = MJX_ERR_BAD_ARG; // does not settle: leave it to the sequential decoder
             }
             else { // the store pass ran on unsettled states: wipe what it wrote and go round again
-                for(int c = 0; c < r->job.S.ncomp; ++c)
-                    if(hipMemsetAsync(r->plane_ptr[c], 0, r->plane_len[c], s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
+                if(!zero_planes(r->plane_ptr, r->plane_len, r->job.S.ncomp, s)) return fail_all(MJX_ERR_LAUNCH);
                 if(hipMemsetAsync(r->job.flags, 0, sizeof(int), s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
                 pending[keep++] = pending[k];
             }
@@ -971,14 +1080,15 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     }
     S.nslots = nmcu * S.bpm;
     S.ntab = B->ntab;
-    { // the wave-per-chunk walk keeps up to four DC and two AC fields per bit position
-        int field_of[8], nd = 0, na = 0;
+    int field_of[8]; // the wave-per-chunk walk keeps up to two AC and four DC fields per bit position
+    {
+        int nd = 0, na = 0;
         for(int t = 0; t < B->ntab; ++t) field_of[t] = staged_is_dc[t] ? nd++ : na++;
-        S.wave_ok = B->ntab <= 4 && nd <= 4 && na <= 2;
-        if(S.wave_ok) {
-            for(int t = 0; t < B->ntab; ++t) S.wave_place[t] = 128u | (staged_is_dc[t] ? 0u : 64u) | (unsigned)(8 * field_of[t]);
+        S.wave_ok = nd <= 4 && na <= 2;
+        S.wave_nac = (unsigned)na;
+        S.wave_ndc = (unsigned)nd;
+        if(S.wave_ok)
             for(int b = 0; b < S.bpm; ++b) S.wave_sel |= (unsigned)(field_of[comp_dc[S.slot_comp[b]]] | (field_of[comp_ac[S.slot_comp[b]]] << 2)) << (3 * b);
-        }
     }
     S.nsub = B->nsub;
     if(S.nslots > 0x7FFFFFFFll) return MJX_ERR_BAD_ARG;
@@ -991,8 +1101,10 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
         }
         if(same) break;
     }
-    const size_t table_words = ((size_t)S.ntab << kLutBits) + ((size_t)S.nsub << kSubBits);
-    const size_t lds_bytes = (table_words + (size_t)kChunkWords * kDecThreads) * 4 + sizeof(DecScan);
+    const size_t code_words = ((size_t)S.ntab << kLutBits) + ((size_t)S.nsub << kSubBits);
+    const size_t wave_words = S.wave_ok ? ((size_t)kWaveSlots << kLutBits) + ((size_t)S.nsub << kSubBits) : 0;
+    const size_t table_words = code_words + wave_words;
+    const size_t lds_bytes = (code_words + (size_t)kChunkWords * kDecThreads) * 4 + sizeof(DecScan);
     if(lds_bytes > 64 * 1024) return MJX_ERR_BAD_ARG; // more distinct long-code tables than a workgroup can stage
 
     const long long want_seg = S.ri > 0 ? (nmcu + S.ri - 1) / S.ri : 1;
@@ -1054,6 +1166,7 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     memset(h_data + rawlen, 0, upload_bytes - rawlen);
     memcpy(arena->pin + pin_tables, B->lut, (size_t)S.ntab << (kLutBits + 2));
     memcpy(arena->pin + pin_tables + ((size_t)S.ntab << (kLutBits + 2)), B->sub, (size_t)S.nsub << (kSubBits + 2));
+    if(S.wave_ok) wave_tables(*B, staged_is_dc, field_of, reinterpret_cast<unsigned *>(arena->pin + pin_tables) + code_words);
     DecChunk *hc = reinterpret_cast<DecChunk *>(arena->pin + pin_chunks);
     long long nchunks = 0;
     for(long long g = 0; g < nseg; ++g) {
@@ -1071,6 +1184,13 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     MJX_HIP(hipMemcpyAsync(base + o_chunks, hc, (size_t)nchunks * sizeof(DecChunk), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
     MJX_HIP(hipMemcpyAsync(base + o_words, h_data, upload_bytes, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
     MJX_HIP(hipMemsetAsync(base + o_totals, 0, 256, s), MJX_ERR_LAUNCH);
+    if(debug) {
+        struct timespec a, b;
+        clock_gettime(CLOCK_MONOTONIC, &a);
+        (void)hipStreamSynchronize(s);
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        fprintf(stderr, "mjx_huff_decode_host: uploads done %.3f ms after they were queued\n", (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6);
+    }
     {
         size_t po = o_planes;
         for(int c = 0; c < S.ncomp; ++c) {
@@ -1084,12 +1204,13 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
                 po += up256(plane_bytes[c]);
             }
             req.plane_len[c] = plane_bytes[c];
-            MJX_HIP(hipMemsetAsync(req.plane_ptr[c], 0, plane_bytes[c], s), MJX_ERR_LAUNCH);
         }
+        if(!zero_planes(req.plane_ptr, req.plane_len, S.ncomp, s)) return MJX_ERR_LAUNCH;
     }
     MJX_HIP(hipEventRecord(arena->staged, s), MJX_ERR_LAUNCH);
     DecJob &J = req.job;
     J.tables = reinterpret_cast<const unsigned *>(base + o_tables);
+    J.wtables = J.tables + code_words;
     J.words = reinterpret_cast<const unsigned *>(base + o_words);
     J.chunks = reinterpret_cast<const DecChunk *>(base + o_chunks);
     J.exits = reinterpret_cast<unsigned long long *>(base + o_exit);

@@ -892,6 +892,9 @@ int Arena::prepare(size_t dev_bytes, size_t pin_bytes) {
         if(staged == nullptr) {
             if(int e = check_hip(hipEventCreateWithFlags(&staged, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH)) return e;
         }
+        static const bool arena_debug = getenv("MJX_ARENA_DEBUG") != nullptr;
+        if(arena_debug && (dev_bytes > dev_cap || pin_bytes > pin_cap))
+            fprintf(stderr, "mjx arena %p grows: device %zu -> %zu bytes, pinned %zu -> %zu bytes\n", (void *)this, dev_cap, dev_bytes, pin_cap, pin_bytes);
         if(dev_bytes > dev_cap) {
             if(dev) (void)hipFree(dev);
             dev = nullptr;

@@ -9,7 +9,7 @@ for lim in 0 100000000; do
 done
 for lim in 0 100000000; do
   echo "=== MJX_DECODE_WAVE_CHUNKS=$lim"
-  for cfg in "1920 1080 85" "1920 1080 95" "3840 2160 85" "3840 2160 95" "1920 1080 100"; do
+  for cfg in ${CFGS:-"1920 1080 85" "1920 1080 95" "3840 2160 85" "3840 2160 95" "1920 1080 100"}; do
     set -- $cfg
     echo "-- $1x$2 q$3"
     MJX_DECODE_WAVE_CHUNKS=$lim BENCH_QUALITY=$3 MJX_HUFFDEC_DEBUG=1 timeout -k 10 120 $T/bench_dropin $H/libmodjpeg.so.1 $1 $2 256 256 12 2>&1 | grep -E "mjx_huff_decode_host" | tail -4 | sed 's/mjx_huff_decode_host: //'
