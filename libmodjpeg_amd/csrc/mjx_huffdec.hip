@@ -893,13 +893,15 @@ bool zero_planes(char *const *ptr, const size_t *len, int ncomp, hipStream_t s) 
 }
 
 // Chunks of a batch up to which the synchronisation rounds run one wavefront per chunk (MJX_DECODE_WAVE_CHUNKS; 0: never).
-// Measured (profiles/r03/decode_wave_rounds.md): a 1080p quality-85 stream (4 000 chunks) 0.57 -> 0.33 ms of kernels, a 4K
-// quality-85 one (15 700) 0.67 -> 0.61; at 28 700 chunks (4K quality 95) the first rounds have seven wavefronts per SIMD
-// to get through and one lane per chunk is faster again, as it is for the batches of the multi-threaded tool.
+// Measured kernel time of a single read, lane per chunk -> wavefront per chunk (profiles/r03/decode_wave_rounds.md):
+// 1080p quality 85 (4 000 chunks) 0.59-0.68 -> 0.26-0.31 ms, quality 95 (7 200) 0.69-0.82 -> 0.39-0.44, quality 100 (13 600)
+// 1.9-2.8 -> 1.0-1.4, 4K quality 85 (15 700) 0.69-0.71 -> 0.50, 4K quality 95 (28 700) 0.95-1.2 -> 0.91-1.06; at 62 700
+// chunks (8K) the first rounds have fifteen wavefronts per SIMD to get through and one lane per chunk wins (0.82 against
+// 1.17 ms), as it does for the batches of the multi-threaded tool.
 long long wave_chunk_limit() {
     static const long long n = [] {
         const char *e = getenv("MJX_DECODE_WAVE_CHUNKS");
-        return e ? atoll(e) : 16384ll;
+        return e ? atoll(e) : 32768ll;
     }();
     return n;
 }
