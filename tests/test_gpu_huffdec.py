@@ -39,8 +39,9 @@ def spec(bits, vals):
 EOI = b"\xff\xd9"
 
 
-def gpu_decode(data, geom, mcus_x, mcus_y, restart=0, pitch_extra=0, tables=None):
-    """data: scan data as in a file (stuffed, RSTn, EOI); geom[c] = (hs, vs); returns rc, planes[c] int16[mcus_y*vs, bpr, 64]"""
+def gpu_decode(data, geom, mcus_x, mcus_y, restart=0, pitch_extra=0, tables=None, table_ids=None):
+    """data: scan data as in a file (stuffed, RSTn, EOI); geom[c] = (hs, vs); returns rc, planes[c] int16[mcus_y*vs, bpr, 64].
+    table_ids = (dc id of every component, ac id of every component) with tables = (list of DC specs, list of AC specs)"""
     import torch  # noqa: F401
     from libmodjpeg_amd._lib import lib
     sc = DScan()
@@ -49,9 +50,16 @@ def gpu_decode(data, geom, mcus_x, mcus_y, restart=0, pitch_extra=0, tables=None
     for c, (hs, vs) in enumerate(geom):
         p = np.full((mcus_y * vs, mcus_x * hs + pitch_extra, 64), 0x5555, np.int16)
         planes.append(p)
-        sc.comp[c] = DComponent(p.ctypes.data, p.shape[1], hs, vs, 0, 0)
-    dc, ac = tables or (spec(DC_BITS, DC_VALS), spec(AC_BITS, AC_VALS))
-    sc.dc[0], sc.ac[0] = ctypes.pointer(dc), ctypes.pointer(ac)
+        sc.comp[c] = DComponent(p.ctypes.data, p.shape[1], hs, vs, table_ids[0][c] if table_ids else 0, table_ids[1][c] if table_ids else 0)
+    if table_ids:
+        keep = [list(tables[0]), list(tables[1])]
+        for i, t in enumerate(keep[0]):
+            sc.dc[i] = ctypes.pointer(t)
+        for i, t in enumerate(keep[1]):
+            sc.ac[i] = ctypes.pointer(t)
+    else:
+        dc, ac = tables or (spec(DC_BITS, DC_VALS), spec(AC_BITS, AC_VALS))
+        sc.dc[0], sc.ac[0] = ctypes.pointer(dc), ctypes.pointer(ac)
     buf = np.frombuffer(data, np.uint8).copy()
     sc.data, sc.nbytes = buf.ctypes.data, len(data)
     rc = lib().mjx_huff_decode_host(ctypes.byref(sc))
@@ -103,6 +111,8 @@ def py_encode_restart(planes, geom, mcus_x, mcus_y, dc, ac, restart):
                 out.append(0)
         bits.clear()
 
+    dcs = dc if isinstance(dc, (list, tuple)) else [dc] * len(planes)
+    acs = ac if isinstance(ac, (list, tuple)) else [ac] * len(planes)
     last, n_rst, mcu = [0] * len(planes), 0, 0
     for my in range(mcus_y):
         for mx in range(mcus_x):
@@ -113,6 +123,7 @@ def py_encode_restart(planes, geom, mcus_x, mcus_y, dc, ac, restart):
                 last = [0] * len(planes)
             mcu += 1
             for c, (hs, vs) in enumerate(geom):
+                dc, ac = dcs[c], acs[c]
                 for yi in range(vs):
                     for xi in range(hs):
                         blk = planes[c][my * vs + yi, mx * hs + xi].astype(np.int64)
@@ -156,6 +167,40 @@ def test_against_the_python_encoder_with_restart_segments(restart, geom):
     data = py_encode_restart(planes, geom, mcus_x, mcus_y, derive(DC_BITS, DC_VALS), derive(AC_BITS, AC_VALS), restart)
     assert data.count(b"\xff\xd0") + data.count(b"\xff\xd1") >= (1 if restart else 0)
     rc, got = gpu_decode(data + EOI, geom, mcus_x, mcus_y, restart=restart)
+    assert rc == 0
+    for c in range(len(geom)):
+        assert np.array_equal(got[c], planes[c]), c
+
+
+# T.81 Annex K.3.3 tables for chrominance, and two more DC tables and one more AC table that are merely valid
+DC_C_BITS, DC_C_VALS = [0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0], list(range(12))
+AC_C_BITS = [0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77]
+AC_C_VALS = [0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09,
+             0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38,
+             0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74,
+             0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5,
+             0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+             0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa]
+DC_FLAT_BITS, DC_FLAT_VALS = [0, 0, 0, 12] + [0] * 12, list(range(12))          # twelve codes of four bits
+DC_PAIR_BITS, DC_PAIR_VALS = [0, 2, 2, 2, 2, 2, 2] + [0] * 9, list(range(11, -1, -1))  # two codes of every length 2..7, the categories the other way round
+AC_REV_BITS, AC_REV_VALS = AC_BITS, list(reversed(AC_VALS))                      # the luminance lengths over the symbols in reverse: EOB is a 16-bit code
+
+
+@pytest.mark.parametrize("ids", [((0, 1, 2), (0, 1, 1)), ((0, 1, 2, 3), (0, 1, 0, 1)), ((0, 1), (0, 0)), ((0, 0, 0), (0, 1, 2)), ((1, 0, 1), (1, 0, 1))],
+                         ids=["3dc2ac", "4dc2ac", "2dc1ac", "1dc3ac-lane-rounds", "std-swapped"])
+def test_components_with_their_own_tables(ids):
+    """every mix of DC and AC tables the scan header allows: two AC and up to four DC tables go through the wave-per-chunk rounds
+    (the usual 2 + 2 and 1 + 1 have their own instantiation, the others the generic one), three AC tables through the lane-per-chunk rounds"""
+    dc_ids, ac_ids = ids
+    geom = [(2, 1)] + [(1, 1)] * (len(dc_ids) - 1)
+    mcus_x, mcus_y = 40, 24
+    rng = np.random.default_rng(len(dc_ids) * 7 + sum(ac_ids))
+    planes = random_planes(rng, geom, mcus_x, mcus_y, 0.12, 500)
+    dcs = [(DC_BITS, DC_VALS), (DC_C_BITS, DC_C_VALS), (DC_FLAT_BITS, DC_FLAT_VALS), (DC_PAIR_BITS, DC_PAIR_VALS)]
+    acs = [(AC_BITS, AC_VALS), (AC_C_BITS, AC_C_VALS), (AC_REV_BITS, AC_REV_VALS)]
+    data = py_encode_restart(planes, geom, mcus_x, mcus_y, [derive(*dcs[i]) for i in dc_ids], [derive(*acs[i]) for i in ac_ids], 0)
+    assert len(data) * 8 > 20 * 1024  # a good many chunks
+    rc, got = gpu_decode(data + EOI, geom, mcus_x, mcus_y, tables=([spec(*t) for t in dcs], [spec(*t) for t in acs]), table_ids=(dc_ids, ac_ids))
     assert rc == 0
     for c in range(len(geom)):
         assert np.array_equal(got[c], planes[c]), c
