@@ -43,6 +43,7 @@ constexpr int kDecMaxSlots = 10;
 constexpr int kChunkBits = 1024;
 constexpr int kChunkWords = kChunkBits / 32 + 5; // + byte misalignment of the segment + overshoot + window refill
 constexpr int kDecThreads = 128;
+constexpr int kSubChunks = 4, kSubBitsPerLane = kChunkBits / kSubChunks; // store pass: four lanes share a chunk, from the states the rounds record at the marks inside it
 constexpr int kLutBits = 10, kSubBits = 16 - kLutBits;
 constexpr int kMaxSubTables = 64; // second-level tables of 1 << kSubBits entries
 
@@ -76,7 +77,6 @@ struct DecChunk {
 };
 
 constexpr int kWaveSlots = 6; // wave-per-chunk walk: tables 0, 1 are the AC tables, 2..5 the DC tables
-constexpr int kSubChunks = 4, kSubBitsPerLane = kChunkBits / kSubChunks; // store pass after wave-per-chunk rounds: four lanes share a chunk
 constexpr int kMaxRounds = 192, kMoreRounds = 12;
 constexpr int kFlagInts = kMaxRounds + 2; // per image: [0] error, [1 + r] round r changed something
 constexpr int kMaxBatch = 32;
@@ -91,7 +91,7 @@ struct DecJob {
     unsigned long long *exits, *seen;
     unsigned long long *substate; // [nchunks][kSubChunks - 1]: the state at every kSubBitsPerLane-bit mark inside the chunk (wave-per-chunk rounds)
     unsigned           *subnb;    //                            ... and the blocks completed before it
-    int                 subchunks; // lanes of the store pass per chunk: kSubChunks after wave-per-chunk rounds, else 1
+    int                 subchunks; // lanes of the store pass per chunk (kSubChunks)
     unsigned           *nblk, *cpre;
     unsigned long long *ctot;
     unsigned           *diff, *dpre;
@@ -155,7 +155,8 @@ __device__ __forceinline__ void stage_shared(unsigned *lds, const DecScan &S, co
 // block slot t_stop, stores coefficients and validates.
 template <bool STORE>
 __device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack, unsigned long long acpack, unsigned long long base_bit, unsigned long long &p,
-                                     unsigned long long p_end, int &slot, int wrap, int &k, unsigned &nblocks, long long &t, long long t_stop, int &err) {
+                                     unsigned long long p_end, int &slot, int wrap, int &k, unsigned &nblocks, long long &t, long long t_stop, int &err,
+                                     unsigned long long *sub_state = nullptr, unsigned *sub_nb = nullptr) {
     const unsigned *cw = L.words + threadIdx.x;
     // bit window: two consecutive words {hi, lo} of which the first `sh` (< 32) bits of hi are used
     // up, and the word after them fetched ahead; the next 32 bits of the stream are one funnel shift
@@ -183,7 +184,14 @@ __device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack,
         locate();
     }
 
+    int next_mark = kSubBitsPerLane, marks = 0; // !STORE: the state at the marks inside the chunk, for the store pass's lanes
     while(rel < rel_end && (!STORE || t < t_stop)) {
+        if(!STORE && rel >= next_mark && marks < kSubChunks - 1) { // the first symbol that starts at or after the mark
+            sub_state[marks] = pack_state(base_bit + (unsigned long long)(unsigned)rel, slot, k);
+            sub_nb[marks] = nblocks;
+            marks++;
+            next_mark += kSubBitsPerLane;
+        }
         const unsigned peek = (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (32 - sh)); // (sh == 0: hi)
         const unsigned cand = cw[(widx < kChunkWords ? widx : kChunkWords - 1) * kDecThreads];  // the word after nxt, should this symbol use up hi
         unsigned       e = L.lut[(k == 0 ? dc_at : ac_at) + (peek >> (32 - kLutBits))];
@@ -235,6 +243,11 @@ __device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack,
         }
     }
     p = base_bit + (unsigned long long)(unsigned)rel;
+    if(!STORE)
+        for(; marks < kSubChunks - 1; ++marks) { // marks the walk did not reach: the final state (their lanes find nothing to do)
+            sub_state[marks] = pack_state(p, slot, k);
+            sub_nb[marks] = nblocks;
+        }
 }
 
 // "this round changed something": thousands of chunks say so in the same round, and read-modify-writes of one address
@@ -275,7 +288,14 @@ __global__ __launch_bounds__(kDecThreads) void huffdec_sync_kernel(const DecJob 
     unpack_state(entry, p, slot, k);
     if(slot >= J.S.period) slot = 0;
     if(p < ck.start) p = ck.start; // cannot happen; keeps the LDS window valid whatever the input
-    if(p < ck.end) walk<false>(L, J.S.dcpack, J.S.acpack, (ck.start >> 5) << 5, p, ck.end, slot, J.S.period, k, nb, t, 0, err);
+    unsigned long long *sub_state = J.substate + (size_t)i * (kSubChunks - 1);
+    unsigned           *sub_nb = J.subnb + (size_t)i * (kSubChunks - 1);
+    if(p < ck.end) walk<false>(L, J.S.dcpack, J.S.acpack, (ck.start >> 5) << 5, p, ck.end, slot, J.S.period, k, nb, t, 0, err, sub_state, sub_nb);
+    else
+        for(int j = 0; j < kSubChunks - 1; ++j) {
+            sub_state[j] = pack_state(p, slot, k);
+            sub_nb[j] = 0;
+        }
     J.seen[i] = entry;
     const unsigned long long out = pack_state(p, slot, k);
     if(round == 0 || out != J.exits[i] || nb != J.nblk[i]) {
@@ -506,7 +526,7 @@ __global__ __launch_bounds__(64 * kWaveGroup) void huffdec_sync_wave_kernel(cons
 __global__ __launch_bounds__(kDecThreads) void huffdec_store_kernel(const DecJob *__restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     const DecJob &J = jobs[blockIdx.y];
-    const int     per = J.subchunks; // lanes per chunk: after wave-per-chunk rounds the states at the marks inside a chunk are known too
+    const int     per = J.subchunks; // lanes per chunk: the rounds left the states at the marks inside every chunk
     if((long long)blockIdx.x * kDecThreads >= (long long)J.nchunks * per) return;
     const int  lane_id = blockIdx.x * kDecThreads + threadIdx.x;
     const int  i = lane_id / per, j = lane_id - i * per;
@@ -892,18 +912,26 @@ bool zero_planes(char *const *ptr, const size_t *len, int ncomp, hipStream_t s) 
     return hipGetLastError() == hipSuccess;
 }
 
-// Chunks of a batch up to which the synchronisation rounds run one wavefront per chunk (MJX_DECODE_WAVE_CHUNKS; 0: never).
-// Measured kernel time of a single read, lane per chunk -> wavefront per chunk (profiles/r03/decode_wave_rounds.md):
-// 1080p quality 85 (4 000 chunks) 0.59-0.68 -> 0.26-0.31 ms, quality 95 (7 200) 0.69-0.82 -> 0.39-0.44, quality 100 (13 600)
-// 1.9-2.8 -> 1.0-1.4, 4K quality 85 (15 700) 0.69-0.71 -> 0.50, 4K quality 95 (28 700) 0.95-1.2 -> 0.91-1.06; at 62 700
-// chunks (8K) the first rounds have fifteen wavefronts per SIMD to get through and one lane per chunk wins (0.82 against
-// 1.17 ms), as it does for the batches of the multi-threaded tool.
+// Chunks of a batch up to which ALL synchronisation rounds run one wavefront per chunk (MJX_DECODE_WAVE_CHUNKS; 0: no round
+// ever does); above it the first rounds run one lane per chunk (lane_rounds_of_large_batches).  Measured GPU time of a
+// single read (profiles/r03/decode_wave_rounds.md), all lane / all wave / lane first:
+//   1080p quality 85 (4 000 chunks) 0.45-0.58 / 0.17-0.21 / -;  4K quality 95 (28 700) 0.75 / 0.65 / 0.51 (3 lane rounds);
+//   8K quality 85 (62 700) 0.77 / 1.12 / 0.66 (3), 0.65 (4).
 long long wave_chunk_limit() {
     static const long long n = [] {
         const char *e = getenv("MJX_DECODE_WAVE_CHUNKS");
-        return e ? atoll(e) : 32768ll;
+        return e ? atoll(e) : 16384ll;
     }();
     return n;
+}
+
+// rounds a batch above that limit walks one lane per chunk before it goes over to one wavefront per chunk (MJX_DECODE_LANE_ROUNDS)
+int lane_rounds_of_large_batches(bool very_large) {
+    static const int n = [] {
+        const char *e = getenv("MJX_DECODE_LANE_ROUNDS");
+        return e ? atoi(e) : -1;
+    }();
+    return n >= 0 ? n : (very_large ? 4 : 3);
 }
 
 // the leader's part: one set of kernels over all images of the batch, on the leader's stream
@@ -926,18 +954,24 @@ void run_batch(Request *lead, Request **batch, int n) {
     }
     if(hipMemsetAsync(d_flags, 0, sizeof(int) * (size_t)kFlagInts * (size_t)n, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
 
-    // One wavefront per chunk while the device has the wavefronts to spare (a lone caller, a small batch), one lane per
-    // chunk beyond.  Decided once: the store pass's lanes per chunk rely on what the LAST walk of every chunk left behind.
-    bool waves = true;
+    // One wavefront per chunk while the device has the wavefronts to spare — all rounds of a lone caller or a small batch, and
+    // the later rounds of any batch, when few chunks are left to redo (an idle workgroup of that kernel returns at once, an idle
+    // lane of the other waits for the busiest lane of its wavefront); one lane per chunk for the first rounds of a large batch,
+    // when every chunk is walked and throughput is what counts.  Both kinds record the states at the marks inside a chunk, so
+    // the store pass always runs kSubChunks lanes per chunk.
+    int lane_rounds = 0;
     {
         long long all_chunks = 0;
+        bool      wave_ok = true;
         for(int i = 0; i < n; ++i) {
             all_chunks += batch[i]->job.nchunks;
-            if(!batch[i]->job.S.wave_ok) waves = false;
+            if(!batch[i]->job.S.wave_ok) wave_ok = false;
         }
-        if(all_chunks > wave_chunk_limit()) waves = false;
+        const long long limit = wave_chunk_limit();
+        if(!wave_ok || limit == 0) lane_rounds = kMaxRounds + 1;
+        else if(all_chunks > limit) lane_rounds = lane_rounds_of_large_batches(all_chunks > 4 * limit);
     }
-    const int per = waves ? kSubChunks : 1;
+    const int per = kSubChunks;
 
     int pending[kMaxBatch], npending = n, round = 0;
     for(int i = 0; i < n; ++i) pending[i] = i;
@@ -973,7 +1007,7 @@ void run_batch(Request *lead, Request **batch, int n) {
         //    is queued together with everything that follows; the flags are looked at once, at the
         //    end, and only an image that had not settled by then goes round again.
         for(int r = 0; r < nrounds; ++r, ++round) {
-            if(waves) hipLaunchKernelGGL(huffdec_sync_wave_kernel, dim3((most_chunks + kWaveGroup - 1) / kWaveGroup, m), dim3(64 * kWaveGroup), wave_lds, s, d_jobs, round);
+            if(round >= lane_rounds) hipLaunchKernelGGL(huffdec_sync_wave_kernel, dim3((most_chunks + kWaveGroup - 1) / kWaveGroup, m), dim3(64 * kWaveGroup), wave_lds, s, d_jobs, round);
             else hipLaunchKernelGGL(huffdec_sync_kernel, dim3(cbx, m), dim3(kDecThreads), lds, s, d_jobs, round);
         }
         // 2.-4. block offsets, coefficients, DC values (wasted for an image whose rounds had not settled: rare)
@@ -990,7 +1024,7 @@ void run_batch(Request *lead, Request **batch, int n) {
         if(hipStreamSynchronize(s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
         if(debug) {
             clock_gettime(CLOCK_MONOTONIC, &tq2);
-            fprintf(stderr, "mjx_huff_decode_host: batch of %d, rounds %d..%d %s: staged work took %.3f ms more, queued in %.3f ms, finished %.3f ms later\n", npending, first, round - 1, waves ? "(a wavefront per chunk)" : "(a lane per chunk)",
+            fprintf(stderr, "mjx_huff_decode_host: batch of %d, rounds %d..%d %s: staged work took %.3f ms more, queued in %.3f ms, finished %.3f ms later\n", npending, first, round - 1, lane_rounds == 0 ? "(a wavefront per chunk)" : (lane_rounds > kMaxRounds ? "(a lane per chunk)" : "(a lane per chunk first, then a wavefront)"),
                     (tq0.tv_sec - tqs.tv_sec) * 1e3 + (tq0.tv_nsec - tqs.tv_nsec) * 1e-6, (tq1.tv_sec - tq0.tv_sec) * 1e3 + (tq1.tv_nsec - tq0.tv_nsec) * 1e-6, (tq2.tv_sec - tq1.tv_sec) * 1e3 + (tq2.tv_nsec - tq1.tv_nsec) * 1e-6);
         }
 
@@ -1219,7 +1253,7 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     J.seen = reinterpret_cast<unsigned long long *>(base + o_seen);
     J.substate = reinterpret_cast<unsigned long long *>(base + o_subst);
     J.subnb = reinterpret_cast<unsigned *>(base + o_subnb);
-    J.subchunks = 1;
+    J.subchunks = kSubChunks;
     J.nblk = reinterpret_cast<unsigned *>(base + o_nblk);
     J.cpre = reinterpret_cast<unsigned *>(base + o_cpre);
     J.ctot = reinterpret_cast<unsigned long long *>(base + o_ctot);
