@@ -8,16 +8,19 @@
 //   0. host            0xFF00 stuffing and RSTn markers are removed while the bytes are copied into
 //                      the pinned staging buffer (the one pass over the input that a DMA from
 //                      pageable memory would cost anyway)
-//   1. sync rounds     the stream is cut into chunks of kChunkBits bits, one lane per chunk.  Each
-//                      lane walks its chunk without storing anything, from the exit state of its
-//                      left neighbour (round 0: from a guess), and publishes its own exit state and
-//                      the number of blocks it completed.  Rounds repeat until one changed nothing:
-//                      then every chunk starts exactly where its predecessor stopped.
+//   1. sync rounds     the stream is cut into chunks of kChunkBits bits.  Every chunk is walked
+//                      without storing anything, from the exit state of its left neighbour (round 0:
+//                      from a guess), and publishes its own exit state, the number of blocks it
+//                      completed and the states at the kSubBitsPerLane-bit marks inside it.  Rounds
+//                      repeat until one changed nothing: then every chunk starts exactly where its
+//                      predecessor stopped.  Two forms: one lane per chunk (huffdec_sync_kernel: when
+//                      every chunk of a large batch is walked) and one wavefront per chunk
+//                      (huffdec_sync_wave_kernel: lone callers, and the later rounds of everything)
 //   2. scan            exclusive prefix sum of the block counts -> first block slot of every chunk
-//   3. store pass      every lane walks its chunk once more and stores the coefficients (DC as the
-//                      difference it read)
+//   3. store pass      kSubChunks lanes per chunk walk their part once more and store the
+//                      coefficients (DC as the difference read)
 //   4. DC pass         per component, prefix sum of the differences inside every restart segment
-// The walk is a latency chain (window -> table -> shift), so it is kept to one LDS look-up and a
+// The lane walk is a latency chain (window -> table -> shift), so it is kept to one LDS look-up and a
 // handful of ALU operations per symbol: a two-word bit window in registers, table entries that carry
 // the code length, the total bits to skip and the zigzag advance, a second-level table for codes
 // longer than the first-level index, no data-dependent branch except the end of a block.
@@ -305,17 +308,17 @@ __global__ __launch_bounds__(kDecThreads) void huffdec_sync_kernel(const DecJob 
     }
 }
 
-// ---- the same round with one WAVEFRONT per chunk (few images in flight: latency matters, the GPU is idle) ----
+// ---- the same round with one WAVEFRONT per chunk (few chunks to walk, or few images in flight: latency is what counts) ----
 // The lane-per-chunk walk above is a dependent chain of ~60 vector and scalar instructions and an LDS look-up
 // per symbol, ten cycles each.  Here the 64 lanes first look up, for every bit position of the chunk and every
-// staged table, what a symbol starting there would be — all look-ups independent and in flight together — and keep
-// the answers in two registers per window of 64 positions:
+// table, what a symbol starting there would be — all look-ups independent and in flight together, from tables of
+// ready-made fields (wave_tables() on the host) — and keep the answers in two registers per window of 64 positions:
 //   AC register: table a's total length (code + value bits) at bits 8a..8a+4, its zigzag advance at bits 16+8a..21+8a
-//                (EOB: 63 — in AC context k >= 1, so k + 63 ends the block as k + 64 would)
-//   DC register: table d's total length at bits 8d..8d+4 (the advance is always 1)
-// The chain itself is then scalar, nine instructions per AC symbol: v_readlane at the current position, shift, mask
-// (a zero field: not a code, or past the end of the chunk), one add to a register that holds position | k << 16, two
-// bit tests.  It publishes exactly what walk<false> would.
+//                (EOB: 63 — in AC context k >= 1, so k + 63 ends the block as k + 64 would; not a code: total 0, advance 63)
+//   DC register: table d's total length at bits 8d..8d+4 (the advance is always 1; not a code: 0)
+// The chain itself is then scalar, six instructions per AC symbol: v_readlane at the current position, shift, mask,
+// one add to a register that holds position | k << 16, one test of the two bits that say "block complete" and "window
+// left".  It publishes exactly what walk<false> would, the states at the marks included.
 constexpr int kWaveWindows = (kChunkBits + 31 + 63) / 64 + 1; // positions [0, 1024 + 24) relative to the word the chunk starts in
 
 // a value every lane holds alike, moved to scalar registers (what is computed from it stays there)
