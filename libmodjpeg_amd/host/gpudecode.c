@@ -84,12 +84,14 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
     if(d->restart_interval > 0x7FFFFFFF || nmcu > 0x7FFFFFFF) BAIL(MJH_DECODE_UNSUPPORTED, "image too large");
 
     {
-        /* Is the device worth it for this file?  libjpeg decodes ~100 MB/s of scan data on one core;
-         * the GPU path costs ~0.35 ms of fixed round trips, ~55 us per synchronisation round and a
-         * little per byte, and the rounds grow steeply with the bits per block (a
-         * quality-100 overlay of 127 KB needs 54 rounds, 3.4 ms, against 1.3 ms in libjpeg).  The
-         * result is the same either way.  MJ_GPU_DECODE_MIN_BYTES replaces the model by a plain size
-         * threshold (0: always the device). */
+        /* Is the device worth it for this file?  libjpeg decodes ~100 MB/s of scan data on one core; the GPU path costs
+         * ~0.12 ms of fixed round trips, ~11 us per synchronisation round (one wavefront per chunk: a small stream's rounds
+         * are dispatch floors), 0.35 ns per byte of scan data (unstuffing, the first rounds) and 0.03 ns per byte of
+         * coefficient plane that comes down; the rounds grow steeply with the bits per block.  Fitted to
+         * scripts/r03_decode_crossover.sh (profiles/r03/decoder/small_files_device_vs_libjpeg.txt): 640x480 quality 85
+         * 0.33 ms against libjpeg's 0.76, quality 100 0.91 against 2.5; 320x240 quality 85 0.27 against 0.20 - the
+         * crossover is near 30 KB of scan data.  The result is the same either way.  MJ_GPU_DECODE_MIN_BYTES replaces
+         * the model by a plain size threshold (0: always the device). */
         static long   min_bytes = -2;
         const double  nbytes = (double)d->src->bytes_in_buffer;
         const double  bits_per_block = nbytes * 8.0 / ((double)nmcu * blocks_in_mcu);
@@ -99,7 +101,8 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
             const double seg_rounds = bits_per_block * blocks_in_mcu * (double)d->restart_interval / 1024.0 + 3.0;
             if(seg_rounds < rounds) rounds = seg_rounds;
         }
-        const double  gpu_ms = 0.35 + 0.055 * rounds + nbytes * 0.6e-6, cpu_ms = nbytes * 1.0e-5;
+        const double  plane_bytes = (double)nmcu * blocks_in_mcu * 128.0;
+        const double  gpu_ms = 0.12 + 0.0106 * rounds + nbytes * 0.35e-6 + plane_bytes * 3.0e-8, cpu_ms = nbytes * 0.95e-5;
         if(min_bytes == -2) min_bytes = getenv("MJ_GPU_DECODE_MIN_BYTES") != NULL ? atol(getenv("MJ_GPU_DECODE_MIN_BYTES")) : -1;
         if(min_bytes >= 0 ? nbytes < (double)min_bytes : gpu_ms >= cpu_ms) BAIL(MJH_DECODE_UNSUPPORTED, "libjpeg is faster for this one");
     }
