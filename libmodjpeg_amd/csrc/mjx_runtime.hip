@@ -1038,9 +1038,14 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     // 0.28 ms per call); a wide one goes as whole rows straight out of the caller's buffer (the CPU
     // copies would cost more than the extra PCIe bytes: 4K full frame 8.8 ms against 10.5 ms)
     auto compact = [](const mjx_host_rect_t &r) { return !(r.flags & MJX_RECT_ROWS_ON_DEVICE) && (int64_t)r.cols * 3 <= r.blocks_per_row; };
+    // When every rectangle that travels is a gathered one and the tiles are resident (the drop-in's usual call: three components of
+    // one overlay), the pinned staging area and the device area have the same layout, and packet and rows go up as ONE copy and
+    // the rows come down as one: six copies of 6-10 us with as much again between them become two (mj_compose 0.15 -> 0.09 ms).
+    bool one_span = true;
     for(int i = 0; i < n; ++i) {
         const mjx_host_rect_t &r = rects[i];
         if(r.rows == 0 || r.cols == 0) continue;
+        if(!(r.flags & MJX_RECT_TILES_ON_DEVICE) || (!compact(r) && !(r.flags & MJX_RECT_ROWS_ON_DEVICE))) one_span = false;
         if(compact(r)) {
             data_bytes += round256((size_t)r.rows * r.cols * 128);
             stage_bytes += round256((size_t)r.rows * r.cols * 128);
@@ -1110,7 +1115,7 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
             stage_off.push_back(stage);
             for(int row = 0; row < r.rows; ++row)
                 memcpy(arena->pin + stage + (size_t)row * r.cols * 128, r.rows_ptr + ((size_t)row * r.blocks_per_row + r.col0) * 64, (size_t)r.cols * 128);
-            MJX_HIP(hipMemcpyAsync(base + off, arena->pin + stage, cb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+            if(!one_span) MJX_HIP(hipMemcpyAsync(base + off, arena->pin + stage, cb, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
             off += round256(cb);
             stage += round256(cb);
         }
@@ -1156,11 +1161,16 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     expand_runs(t, t.runs, reinterpret_cast<Run *>(arena->pin + o_runs), nullptr, scheds.data());
     expand_runs(t, t.light, reinterpret_cast<Run *>(arena->pin + o_runs) + t.runs.size(), nullptr, scheds.data());
     memcpy(arena->pin + o_q, t.qrq.data(), t.qrq.size());
-    MJX_HIP(hipMemcpyAsync(base, arena->pin, packet, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
+    if(one_span && stage != off) return MJX_ERR_BAD_ARG; // (cannot happen: both advanced by the gathered rectangles alone)
+    if(one_span && stage > packet_cap) MJX_HIP(hipMemcpyAsync(base, arena->pin, stage, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH); // packet, the slack behind it, rows
+    else MJX_HIP(hipMemcpyAsync(base, arena->pin, packet, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
 
     err = launch_compose(reinterpret_cast<const Run *>(base + o_runs), (int)t.runs.size(), base + o_q, tiles_i16, s);
     if(err == MJX_OK) err = launch_compose_light(reinterpret_cast<const Run *>(base + o_runs) + t.runs.size(), (int)t.light.size(), base + o_q, tiles_i16, s);
-    if(err == MJX_OK) {
+    if(err == MJX_OK && one_span) {
+        if(stage > packet_cap) err = check_hip(hipMemcpyAsync(arena->pin + packet_cap, base + packet_cap, stage - packet_cap, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H)", MJX_ERR_LAUNCH);
+    }
+    else if(err == MJX_OK) {
         k = 0;
         for(int i = 0; i < n && err == MJX_OK; ++i) {
             const mjx_host_rect_t &r = rects[i];
