@@ -586,13 +586,13 @@ __global__ __launch_bounds__(kDecThreads) void huffdec_store_kernel(const DecJob
 // ---- the planes start from zero (a block's coefficients after its last symbol are never written).  hipMemsetAsync drops
 // to ~8 GB/s somewhere between 17 and 66 MB (measured on the 8K planes: 12.6 ms for 100 MB), a plain store loop does not.
 struct ZeroPlanes {
-    uint4 *p[4];
-    size_t n16[4]; // 16-byte units (plane sizes are multiples of 128 bytes)
+    uint4 *p[5]; // the planes, and the image's counters (totals) when it is being staged
+    size_t n16[5]; // 16-byte units (plane sizes are multiples of 128 bytes)
 };
 __global__ __launch_bounds__(256) void huffdec_zero_kernel(ZeroPlanes z) {
     const uint4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for(int c = 0; c < 4; ++c)
+    for(int c = 0; c < 5; ++c)
         for(size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < z.n16[c]; q += (size_t)gridDim.x * 256) z.p[c][q] = zero;
 }
 
@@ -897,9 +897,14 @@ int max_leaders() {
     return n;
 }
 
-bool zero_planes(char *const *ptr, const size_t *len, int ncomp, hipStream_t s) {
+bool zero_planes(char *const *ptr, const size_t *len, int ncomp, hipStream_t s, void *totals = nullptr) {
     ZeroPlanes z = {};
     size_t     most = 0;
+    if(totals != nullptr) { // 256 bytes, 256-byte aligned
+        z.p[4] = reinterpret_cast<uint4 *>(totals);
+        z.n16[4] = 16;
+        most = 16;
+    }
     for(int c = 0; c < ncomp; ++c) {
         if((reinterpret_cast<uintptr_t>(ptr[c]) & 15u) != 0 || (len[c] & 15u) != 0) { // a caller's plane at an odd address: the library call
             if(hipMemsetAsync(ptr[c], 0, len[c], s) != hipSuccess) return false;
@@ -1157,11 +1162,12 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     const size_t    data_bytes = ((scan->nbytes + 3) & ~(size_t)3) + (size_t)(kChunkWords + 1) * 4;
 
     size_t       off = 0;
+    // (tables | chunk table | scan data: the same layout as in the pinned buffer, so they go up as one copy)
     const size_t o_tables = off; off += up256(table_words * 4);
     const size_t o_chunks = off; off += up256((size_t)max_chunks * sizeof(DecChunk));
+    const size_t o_words = off;  off += up256(data_bytes);
     const size_t o_totals = off; off += 256;
     const size_t o_batch = off;  off += kBatchBytes;
-    const size_t o_words = off;  off += up256(data_bytes);
     const size_t o_exit = off;   off += up256((size_t)max_chunks * 8);
     const size_t o_seen = off;   off += up256((size_t)max_chunks * 8);
     const size_t o_subst = off;  off += up256((size_t)max_chunks * (kSubChunks - 1) * 8);
@@ -1219,10 +1225,8 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
         }
     }
     mark(5);
-    MJX_HIP(hipMemcpyAsync(base + o_tables, arena->pin + pin_tables, table_words * 4, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-    MJX_HIP(hipMemcpyAsync(base + o_chunks, hc, (size_t)nchunks * sizeof(DecChunk), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-    MJX_HIP(hipMemcpyAsync(base + o_words, h_data, upload_bytes, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
-    MJX_HIP(hipMemsetAsync(base + o_totals, 0, 256, s), MJX_ERR_LAUNCH);
+    if(o_tables != pin_tables || o_chunks != pin_chunks || o_words != pin_data) return MJX_ERR_BAD_ARG; // (the two layouts above)
+    MJX_HIP(hipMemcpyAsync(base + o_tables, arena->pin + pin_tables, pin_data + upload_bytes, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
     if(debug) {
         struct timespec a, b;
         clock_gettime(CLOCK_MONOTONIC, &a);
@@ -1244,7 +1248,7 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
             }
             req.plane_len[c] = plane_bytes[c];
         }
-        if(!zero_planes(req.plane_ptr, req.plane_len, S.ncomp, s)) return MJX_ERR_LAUNCH;
+        if(!zero_planes(req.plane_ptr, req.plane_len, S.ncomp, s, base + o_totals)) return MJX_ERR_LAUNCH;
     }
     MJX_HIP(hipEventRecord(arena->staged, s), MJX_ERR_LAUNCH);
     DecJob &J = req.job;
