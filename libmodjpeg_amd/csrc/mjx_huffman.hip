@@ -75,9 +75,6 @@ struct EncJob {
 };
 
 // zigzag position -> natural index (jpeg_natural_order)
-__constant__ unsigned char kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                          41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                          30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 struct Slot {
     int  comp, bx, by;
@@ -124,11 +121,26 @@ __device__ __forceinline__ int effective_dc(const HuffScan &S, long long t) {
 
 __device__ __forceinline__ int bit_length(int v) { return 32 - __clz(v); } // v >= 0; 0 -> 0
 
+// LDS of the kernels that walk blocks: every lane's block in a row of kBlockRow shorts (33 dwords: lanes that read the same
+// coefficient of their blocks hit 32 different banks; with rows of 32 dwords they all hit one), the code tables as
+// code | size << 16, the zigzag order
+constexpr int kBlockRow = 66;
+struct EncLds {
+    const unsigned      *tab; // [8][256], 0..3 DC, 4..7 AC (null where only symbols are counted)
+    const unsigned char *zz;  // [64]
+};
+
+constexpr unsigned char kZigzagOrder[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                            41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                            30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
 // symbol stream of one block (jchuff.c encode_one_block / htest_one_block): SYM(table, symbol, bits,
 // nbits) is called for every Huffman symbol with the raw bits that follow it; table = dc_tbl for
 // the DC difference, 4 + ac_tbl for run/size symbols, ZRL and EOB.  false: a value outside the alphabet.
-template <class SYM> __device__ __forceinline__ bool symbolize(const HuffScan &S, long long t, const short *blk /* LDS, 64 coefs; unused for dummies */, bool real,
-                                                              int comp, SYM &&sym) {
+// The AC part first marks the non-zero coefficients in zigzag order (63 independent LDS reads), then visits only those:
+// a wavefront takes as many turns as its busiest block has coefficients, not one per zigzag position any lane uses.
+template <class SYM> __device__ __forceinline__ bool symbolize(const HuffScan &S, const EncLds &L, long long t, const short *blk /* LDS, 64 coefs; unused for dummies */,
+                                                              bool real, int comp, SYM &&sym) {
     const HuffComp &c = S.c[comp];
     bool            ok = true;
     // DC: difference to the previous block of this component
@@ -145,43 +157,52 @@ template <class SYM> __device__ __forceinline__ bool symbolize(const HuffScan &S
     sym(c.dc_tbl, nbits & 255, (unsigned)temp2 & ((1u << nbits) - 1u), nbits);
     // AC: run lengths of zeros in zigzag order
     const int at = 4 + c.ac_tbl;
-    int       r = 0;
+    unsigned  lo = 0, hi = 0; // bit k: coefficient k of the zigzag order is not zero
     if(real) {
-        for(int k = 1; k < 64; ++k) {
-            int v = (int)blk[kZigzag[k]];
-            if(v == 0) {
-                r++;
-                continue;
-            }
-            while(r > 15) {
-                sym(at, 0xF0, 0u, 0); // ZRL
-                r -= 16;
-            }
-            int v2 = v;
-            if(v < 0) {
-                v = -v;
-                v2--;
-            }
-            nbits = bit_length(v);
-            if(nbits > S.max_coef_bits) ok = false;
-            sym(at, ((r << 4) + nbits) & 255, (unsigned)v2 & ((1u << nbits) - 1u), nbits);
-            r = 0;
+#pragma unroll
+        for(int k = 1; k < 32; ++k) lo |= blk[kZigzagOrder[k]] != 0 ? 1u << k : 0u;
+#pragma unroll
+        for(int k = 32; k < 64; ++k) hi |= blk[kZigzagOrder[k]] != 0 ? 1u << (k - 32) : 0u;
+    }
+    int prev = 0;
+    while((lo | hi) != 0) {
+        int k;
+        if(lo != 0) {
+            k = __builtin_ctz(lo);
+            lo &= lo - 1;
         }
+        else {
+            k = 32 + __builtin_ctz(hi);
+            hi &= hi - 1;
+        }
+        int r = k - prev - 1;
+        prev = k;
+        int v = (int)blk[L.zz[k]];
+        while(r > 15) {
+            sym(at, 0xF0, 0u, 0); // ZRL
+            r -= 16;
+        }
+        int v2 = v;
+        if(v < 0) {
+            v = -v;
+            v2--;
+        }
+        nbits = bit_length(v);
+        if(nbits > S.max_coef_bits) ok = false;
+        sym(at, ((r << 4) + nbits) & 255, (unsigned)v2 & ((1u << nbits) - 1u), nbits);
     }
-    else {
-        r = 63;
-    }
-    if(r > 0) sym(at, 0, 0u, 0); // EOB
+    if(prev < 63) sym(at, 0, 0u, 0); // EOB
     return ok;
 }
 
 // the same stream as codes: EMIT(code, size) is called for every code and every bit field
-template <class EMIT> __device__ __forceinline__ bool encode_block(const HuffScan &S, const HuffTables &T, long long t, const short *blk, bool real, int comp, EMIT &&emit) {
+template <class EMIT> __device__ __forceinline__ bool encode_block(const HuffScan &S, const EncLds &L, long long t, const short *blk, bool real, int comp, EMIT &&emit) {
     bool coded = true;
-    const bool ok = symbolize(S, t, blk, real, comp, [&](int table, int symbol, unsigned bits, int nbits) {
-        const int sz = T.size[table][symbol];
+    const bool ok = symbolize(S, L, t, blk, real, comp, [&](int table, int symbol, unsigned bits, int nbits) {
+        const unsigned e = L.tab[table * 256 + symbol];
+        const int      sz = (int)(e >> 16);
         if(sz == 0) coded = false; // a symbol the table has no code for
-        emit(T.code[table][symbol], sz);
+        emit(e & 0xFFFFu, sz);
         if(nbits) emit(bits, nbits);
     });
     return ok && coded;
@@ -192,35 +213,58 @@ __device__ __forceinline__ void stage_block(const HuffScan &S, const Slot &sl, s
     if(!sl.real) return;
     const HuffComp &c = S.c[sl.comp];
     const uint4    *src = reinterpret_cast<const uint4 *>(c.plane + ((size_t)sl.by * (size_t)c.bpr + (size_t)sl.bx) * 64);
-    uint4          *d = reinterpret_cast<uint4 *>(dst);
+    unsigned       *d = reinterpret_cast<unsigned *>(dst); // rows are 4-byte aligned only (kBlockRow)
 #pragma unroll
-    for(int i = 0; i < 8; ++i) d[i] = src[i];
+    for(int i = 0; i < 8; ++i) {
+        const uint4 v = src[i];
+        d[4 * i] = v.x;
+        d[4 * i + 1] = v.y;
+        d[4 * i + 2] = v.z;
+        d[4 * i + 3] = v.w;
+    }
     if(c.fx_n > 0) dst[0] = (short)dc_with_pending(c, (int)dst[0]);
+}
+
+// the tables of a workgroup's image (null: none) and the zigzag order, for every lane to look up; ends with a barrier
+__device__ __forceinline__ EncLds stage_tables(const HuffTables *T, unsigned *tab, unsigned char *zz, int nthreads) {
+    if(T != nullptr)
+        for(int i = threadIdx.x; i < 8 * 256; i += nthreads) tab[i] = (T->code[i >> 8][i & 255] & 0xFFFFu) | ((unsigned)T->size[i >> 8][i & 255] << 16);
+    if(threadIdx.x < 64) zz[threadIdx.x] = kZigzagOrder[threadIdx.x];
+    __syncthreads();
+    return EncLds{T != nullptr ? tab : nullptr, zz};
 }
 
 constexpr int kHuffThreads = 128; // 128 x 128 B of LDS staging
 
 __global__ __launch_bounds__(kHuffThreads) void huff_length_kernel(const EncJob *__restrict__ jobs) {
-    __shared__ __attribute__((aligned(16))) short stage[kHuffThreads][64];
+    __shared__ __attribute__((aligned(16))) short stage[kHuffThreads][kBlockRow];
+    __shared__ unsigned                          tab[8 * 256];
+    __shared__ unsigned char                     zz[64];
     const EncJob   &J = jobs[blockIdx.y];
+    if((long long)blockIdx.x * kHuffThreads >= J.nslots) return;
+    const EncLds    L = stage_tables(J.tables, tab, zz, kHuffThreads);
     const long long t = (long long)blockIdx.x * kHuffThreads + threadIdx.x;
     if(t >= J.nslots) return;
     const Slot sl = decode_slot(J.S, t);
     stage_block(J.S, sl, stage[threadIdx.x]);
     unsigned   bits = 0;
-    const bool ok = encode_block(J.S, *J.tables, t, stage[threadIdx.x], sl.real, sl.comp, [&](unsigned, int size) { bits += (unsigned)size; });
+    const bool ok = encode_block(J.S, L, t, stage[threadIdx.x], sl.real, sl.comp, [&](unsigned, int size) { bits += (unsigned)size; });
     J.len[t] = bits;
     if(!ok) atomicOr(reinterpret_cast<int *>(J.misc + 2), 1);
 }
 
 __global__ __launch_bounds__(kHuffThreads) void huff_emit_kernel(const EncJob *__restrict__ jobs) {
-    __shared__ __attribute__((aligned(16))) short stage[kHuffThreads][64];
+    __shared__ __attribute__((aligned(16))) short stage[kHuffThreads][kBlockRow];
+    __shared__ unsigned                          tab[8 * 256];
+    __shared__ unsigned char                     zz[64];
     const EncJob   &J = jobs[blockIdx.y];
-    const long long t = (long long)blockIdx.x * kHuffThreads + threadIdx.x;
-    if(t >= J.nslots) return;
+    if((long long)blockIdx.x * kHuffThreads >= J.nslots) return;
     // a coefficient outside the JPEG alphabet was seen by the length pass: the host reports the
     // error, and nothing may be written (such symbols can exceed the per-block bit budget)
     if(*reinterpret_cast<const int *>(J.misc + 2) != 0) return;
+    const EncLds    L = stage_tables(J.tables, tab, zz, kHuffThreads);
+    const long long t = (long long)blockIdx.x * kHuffThreads + threadIdx.x;
+    if(t >= J.nslots) return;
     const Slot sl = decode_slot(J.S, t);
     stage_block(J.S, sl, stage[threadIdx.x]);
 
@@ -229,7 +273,7 @@ __global__ __launch_bounds__(kHuffThreads) void huff_emit_kernel(const EncJob *_
     unsigned long long       widx = bit0 >> 5;
     unsigned long long       acc = 0; // the low `nacc` bits are pending; the first word starts with bit0 % 32 foreign bits
     int                      nacc = (int)(bit0 & 31);
-    encode_block(J.S, *J.tables, t, stage[threadIdx.x], sl.real, sl.comp, [&](unsigned code, int size) {
+    encode_block(J.S, L, t, stage[threadIdx.x], sl.real, sl.comp, [&](unsigned code, int size) {
         acc = (acc << size) | (unsigned long long)code;
         nacc += size;
         if(nacc >= 32) {
@@ -244,15 +288,16 @@ __global__ __launch_bounds__(kHuffThreads) void huff_emit_kernel(const EncJob *_
 // symbol statistics for optimised tables (jchuff.c encode_mcu_gather): hist[table][symbol], tables
 // 0..3 DC, 4..7 AC; counted in LDS per workgroup, then added to the global histogram
 __global__ __launch_bounds__(kHuffThreads) void huff_histogram_kernel(HuffScan S, long long nslots, unsigned *__restrict__ hist, int *__restrict__ error) {
-    __shared__ __attribute__((aligned(16))) short stage[kHuffThreads][64];
+    __shared__ __attribute__((aligned(16))) short stage[kHuffThreads][kBlockRow];
     __shared__ unsigned                          local[8 * 256];
+    __shared__ unsigned char                     zz[64];
     for(int i = threadIdx.x; i < 8 * 256; i += kHuffThreads) local[i] = 0;
-    __syncthreads();
+    const EncLds    L = stage_tables(nullptr, nullptr, zz, kHuffThreads);
     const long long t = (long long)blockIdx.x * kHuffThreads + threadIdx.x;
     if(t < nslots) {
         const Slot sl = decode_slot(S, t);
         stage_block(S, sl, stage[threadIdx.x]);
-        const bool ok = symbolize(S, t, stage[threadIdx.x], sl.real, sl.comp, [&](int table, int symbol, unsigned, int) { atomicAdd(&local[table * 256 + symbol], 1u); });
+        const bool ok = symbolize(S, L, t, stage[threadIdx.x], sl.real, sl.comp, [&](int table, int symbol, unsigned, int) { atomicAdd(&local[table * 256 + symbol], 1u); });
         if(!ok) atomicOr(error, 1);
     }
     __syncthreads();
