@@ -305,19 +305,28 @@ __global__ __launch_bounds__(kHuffThreads) void huff_histogram_kernel(HuffScan S
         if(local[i]) atomicAdd(&hist[i], local[i]);
 }
 
+// The buffers are sized for the worst case (1665 bits per block: 2.5 M words for a 1080p image that fills 0.13 M), the
+// stream's length is known on the device once the code lengths have been summed: everything past it, in whole scan groups,
+// is left alone (counts, prefix sums and the write there are neither produced nor read).
+__device__ __forceinline__ long long live_words(const EncJob &J) {
+    const long long words = (long long)((J.misc[0] + 31) >> 5);
+    const long long groups = (words + kScanItems - 1) / kScanItems;
+    const long long live = groups * kScanItems;
+    return live < J.words_cap ? live : J.words_cap;
+}
 // ---- exclusive prefix sums over every image of the batch (bodies in mjx_scan.hpp) -------
 // which = 0: code lengths of the block slots -> bit offsets, 1: 0xFF counts of the words -> byte offsets
 __global__ __launch_bounds__(kScanThreads) void huff_scan_groups_kernel(const EncJob *__restrict__ jobs, int which) {
     const EncJob &J = jobs[blockIdx.y];
     if((int)blockIdx.x >= (which == 0 ? J.groups1 : J.groups2)) return;
     if(which == 0) scan_groups_body(J.len, J.lpre, J.gtot, J.nslots, blockIdx.x);
-    else scan_groups_body(J.cnt, J.cpre, J.ctot, J.words_cap, blockIdx.x);
+    else if((long long)blockIdx.x * kScanItems < live_words(J)) scan_groups_body(J.cnt, J.cpre, J.ctot, live_words(J), blockIdx.x);
 }
 
 __global__ __launch_bounds__(kScanThreads) void huff_scan_totals_kernel(const EncJob *__restrict__ jobs, int which) {
     const EncJob &J = jobs[blockIdx.y];
     if(which == 0) scan_totals_body(J.gtot, J.groups1, J.misc + 0);
-    else scan_totals_body(J.ctot, J.groups2, J.misc + 1);
+    else scan_totals_body(J.ctot, (live_words(J) + kScanItems - 1) / kScanItems, J.misc + 1);
 }
 
 // ---- byte stuffing ---------------------------------------------------------------------
@@ -338,7 +347,7 @@ __device__ __forceinline__ unsigned padded_word(const unsigned *words, unsigned 
 __global__ __launch_bounds__(256) void stuff_count_kernel(const EncJob *__restrict__ jobs) {
     const EncJob   &J = jobs[blockIdx.y];
     const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
-    if(w >= J.words_cap) return;
+    if(w >= live_words(J)) return;
     int            nb;
     const unsigned v = padded_word(J.words, (unsigned long long)w, J.misc[0], nb);
     unsigned       c = 0;
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(256) void stuff_count_kernel(const EncJob *__restri
 __global__ __launch_bounds__(256) void stuff_write_kernel(const EncJob *__restrict__ jobs) {
     const EncJob   &J = jobs[blockIdx.y];
     const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
-    if(w >= J.words_cap) return;
+    if(w >= live_words(J)) return;
     int            nb;
     const unsigned v = padded_word(J.words, (unsigned long long)w, J.misc[0], nb);
     if(nb == 0) return;
