@@ -416,6 +416,29 @@ def test_gpu_entropy_decoder_matches_libjpeg(shim, tmp_path, sampling, case):
     assert res.returncode == 0 and res.stdout.strip() == "same gpu", (res.stdout, res.stderr[-500:])
 
 
+ROUND_MODES = {  # how the decoder's synchronisation rounds are walked (MJX_DECODE_WAVE_CHUNKS, MJX_DECODE_LANE_ROUNDS)
+    "default": {},
+    "a-lane-per-chunk": {"MJX_DECODE_WAVE_CHUNKS": "0"},
+    "a-wavefront-per-chunk": {"MJX_DECODE_WAVE_CHUNKS": "1000000000"},
+    "one-lane-round-then-wavefronts": {"MJX_DECODE_WAVE_CHUNKS": "1", "MJX_DECODE_LANE_ROUNDS": "1"},
+    "four-lane-rounds-then-wavefronts": {"MJX_DECODE_WAVE_CHUNKS": "1", "MJX_DECODE_LANE_ROUNDS": "4"},
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", list(ROUND_MODES))
+def test_gpu_entropy_decoder_rounds_walked_either_way(shim, tmp_path, mode):
+    """the two kinds of synchronisation round (one lane / one wavefront per chunk) and their mixtures leave the same states
+    behind: every choice decodes the same arrays as libjpeg (4:2:0 at two qualities, 4:4:4 with restart markers, grayscale)"""
+    env = dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0", **ROUND_MODES[mode])
+    for i, (size, sampling, knobs) in enumerate([(("1280", "720"), "420", {}), (("800", "600"), "420", {"quality": 97}), (("641", "479"), "444", {"restart": 7}),
+                                                  (("1000", "700"), "gray", {"optimize": 1})]):
+        src = tmp_path / ("in%d.jpg" % i)
+        _make_input(src, size, sampling, **knobs)
+        res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "decodecmp", str(src)], capture_output=True, text=True, env=env)
+        assert res.returncode == 0 and res.stdout.strip() == "same gpu", (mode, size, sampling, res.stdout, res.stderr[-500:])
+
+
 @pytest.mark.gpu
 def test_gpu_entropy_decoder_declines_what_it_does_not_decode(shim, tmp_path):
     """progressive, arithmetic-coded and small files are read by libjpeg exactly as in the reference"""
