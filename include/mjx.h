@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MJX_VERSION 101
+#define MJX_VERSION 102
 
 /* error codes (0 = success).  The libmodjpeg.h shim maps them onto MJ_ERR_* (INTEGRATION.md). */
 #define MJX_OK             0
@@ -388,6 +388,17 @@ int mjx_huff_decode_host(const mjx_huff_dscan_t *scan);
  * (MJX_ERR_NO_DEVICE without AVX2).  MJX_ERR_BAD_ARG: not a plain run of [segment RSTn]* segment EOI. */
 int mjx_huff_unstuff(const uint8_t *data, size_t nbytes, uint8_t *out, size_t *outlen, uint64_t *segment_offsets, int64_t max_segments, int64_t *nsegments,
                      int form);
+
+/* Another host-only test seam: the tables the decoder's wave-per-chunk rounds look symbols up in, as the host builds them
+ * from the scan's Huffman tables (scan->data and the planes are not looked at).  out: 6 first-level tables of 1024 words —
+ * 0, 1: the AC tables in the order the components first name them, 2..5: the DC tables — then info[2] second-level tables of
+ * 64 words.  A first-level word is either the symbol's field, shifted into place, or 0x80000000 | offset of a second-level
+ * table (in words from the end of the first level) for codes longer than 10 bits.  Field of AC table a: total length
+ * (code + value bits) << 8a | zigzag advance << (16 + 8a), EOB's advance being 63; not a code: advance 63, length 0.
+ * Field of DC table d: total length << 8d; not a code: 0.  info[0], info[1]: AC and DC tables in use; info[3]: 3 bits per
+ * block slot of the MCU, DC field index | AC field index << 2.  Returns MJX_ERR_BAD_ARG for tables that are not prefix codes,
+ * for more than two AC tables (such scans take the lane-per-chunk rounds) or when out_words is too small. */
+int mjx_huff_wave_tables(const mjx_huff_dscan_t *scan, uint32_t *out, size_t out_words, int32_t info[4]);
 
 /* ---- synthetic workload generators (bench / test support; definition: mjx_synth.h) ------
  * The *_batch forms fill one array of a whole batch with ONE launch: image i of the batch (global

@@ -121,6 +121,7 @@ SYMBOLS = [
     ("mjx_huff_encode_host", _i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
     ("mjx_huff_decode_host", _i, [_vp]),
     ("mjx_huff_unstuff", _i, [_vp, _sz, _vp, ctypes.POINTER(_sz), _vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), _i]),
+    ("mjx_huff_wave_tables", _i, [_vp, _vp, _sz, _vp]),
     ("mjx_huff_optimal_table", _i, [_vp, _vp]),
     ("mjx_synth_coef_batch", _i, [_vp, _sz, _u64, _u32, _u32, _u64, _sz, _vp, _vp]),
     ("mjx_synth_tile_batch", _i, [_vp, _sz, _u64, _u32, _u32, _u64, _sz, _vp]),

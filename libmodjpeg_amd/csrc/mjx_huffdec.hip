@@ -1061,6 +1061,69 @@ void run_batch(Request *lead, Request **batch, int n) {
 
 } // namespace
 
+// the Huffman tables a scan uses, derived in the order its components first name them (comp_dc / comp_ac: staged index per component)
+static int stage_scan_tables(const mjx_huff_dscan_t *scan, TableBuilder &B, int *comp_dc, int *comp_ac, bool *staged_is_dc) {
+    int dc_of[4] = {-1, -1, -1, -1}, ac_of[4] = {-1, -1, -1, -1}; // table id -> staged index
+    for(int c = 0; c < scan->ncomp; ++c) {
+        const mjx_huff_dcomponent_t &h = scan->comp[c];
+        if(h.dc_tbl < 0 || h.dc_tbl > 3 || h.ac_tbl < 0 || h.ac_tbl > 3 || scan->dc[h.dc_tbl] == nullptr || scan->ac[h.ac_tbl] == nullptr) return MJX_ERR_BAD_ARG;
+        if(dc_of[h.dc_tbl] < 0) {
+            dc_of[h.dc_tbl] = B.ntab;
+            staged_is_dc[B.ntab] = true;
+            if(!derive(scan->dc[h.dc_tbl], B, true)) return MJX_ERR_BAD_ARG;
+        }
+        if(ac_of[h.ac_tbl] < 0) {
+            ac_of[h.ac_tbl] = B.ntab;
+            if(!derive(scan->ac[h.ac_tbl], B, false)) return MJX_ERR_BAD_ARG;
+        }
+        comp_dc[c] = dc_of[h.dc_tbl];
+        comp_ac[c] = ac_of[h.ac_tbl];
+    }
+    return MJX_OK;
+}
+
+// where the wave-per-chunk walk keeps each staged table's field (it has room for two AC and four DC fields per bit position);
+// sel: 3 bits per block slot, DC field index | AC field index << 2
+static bool wave_layout(int ntab, const bool *staged_is_dc, const int *comp_dc, const int *comp_ac, const int *slot_comp, int bpm, int *field_of, unsigned *nac, unsigned *ndc,
+                        unsigned *sel) {
+    int nd = 0, na = 0;
+    for(int t = 0; t < ntab; ++t) field_of[t] = staged_is_dc[t] ? nd++ : na++;
+    *nac = (unsigned)na;
+    *ndc = (unsigned)nd;
+    *sel = 0;
+    if(nd > 4 || na > 2) return false;
+    for(int b = 0; b < bpm; ++b) *sel |= (unsigned)(field_of[comp_dc[slot_comp[b]]] | (field_of[comp_ac[slot_comp[b]]] << 2)) << (3 * b);
+    return true;
+}
+
+extern "C" int mjx_huff_wave_tables(const mjx_huff_dscan_t *scan, uint32_t *out, size_t out_words, int32_t info[4]) {
+    if(scan == nullptr || out == nullptr || info == nullptr) return MJX_ERR_NULL_DATA;
+    if(scan->ncomp < 1 || scan->ncomp > 4) return MJX_ERR_BAD_ARG;
+    TableBuilder *B = new(std::nothrow) TableBuilder;
+    if(B == nullptr) return MJX_ERR_MEMORY;
+    struct Free {
+        TableBuilder *b;
+        ~Free() { delete b; }
+    } free_builder{B};
+    int  comp_dc[4] = {0, 0, 0, 0}, comp_ac[4] = {0, 0, 0, 0}, field_of[8], slot_comp[kDecMaxSlots], bpm = 0;
+    bool staged_is_dc[8] = {false, false, false, false, false, false, false, false};
+    if(int e = stage_scan_tables(scan, *B, comp_dc, comp_ac, staged_is_dc)) return e;
+    for(int c = 0; c < scan->ncomp; ++c) {
+        const int n = scan->comp[c].h_samp * scan->comp[c].v_samp;
+        if(scan->comp[c].h_samp < 1 || scan->comp[c].v_samp < 1 || n > kDecMaxSlots - bpm) return MJX_ERR_BAD_ARG;
+        for(int i = 0; i < n; ++i) slot_comp[bpm++] = c;
+    }
+    unsigned nac, ndc, sel;
+    if(!wave_layout(B->ntab, staged_is_dc, comp_dc, comp_ac, slot_comp, bpm, field_of, &nac, &ndc, &sel)) return MJX_ERR_BAD_ARG;
+    if(out_words < ((size_t)kWaveSlots << kLutBits) + ((size_t)B->nsub << kSubBits)) return MJX_ERR_BAD_ARG;
+    wave_tables(*B, staged_is_dc, field_of, out);
+    info[0] = (int32_t)nac;
+    info[1] = (int32_t)ndc;
+    info[2] = B->nsub;
+    info[3] = (int32_t)sel;
+    return MJX_OK;
+}
+
 extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     if(scan == nullptr || scan->data == nullptr) return MJX_ERR_NULL_DATA;
     if(scan->ncomp < 1 || scan->ncomp > 4 || scan->mcus_x <= 0 || scan->mcus_y <= 0 || scan->restart_interval < 0 || scan->nbytes < 2) return MJX_ERR_BAD_ARG;
@@ -1076,7 +1139,6 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     size_t          plane_bytes[4] = {0, 0, 0, 0}, planes_total = 0;
     long long       ndc = 0;
     const bool      on_device = (scan->flags & MJX_HUFF_PLANES_ON_DEVICE) != 0;
-    int             dc_of[4] = {-1, -1, -1, -1}, ac_of[4] = {-1, -1, -1, -1}; // table id -> staged index
     TableBuilder   *B = new(std::nothrow) TableBuilder;
     if(B == nullptr) return MJX_ERR_MEMORY;
     struct Free {
@@ -1088,20 +1150,11 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     for(int c = 0; c < S.ncomp; ++c) {
         const mjx_huff_dcomponent_t &h = scan->comp[c];
         if(h.plane == nullptr) return MJX_ERR_NULL_DATA;
-        if(h.h_samp < 1 || h.h_samp > 4 || h.v_samp < 1 || h.v_samp > 4 || (long long)h.blocks_per_row < (long long)S.mcus_x * h.h_samp || h.dc_tbl < 0 ||
-           h.dc_tbl > 3 || h.ac_tbl < 0 || h.ac_tbl > 3 || scan->dc[h.dc_tbl] == nullptr || scan->ac[h.ac_tbl] == nullptr)
-            return MJX_ERR_BAD_ARG;
-        if(dc_of[h.dc_tbl] < 0) {
-            dc_of[h.dc_tbl] = B->ntab;
-            staged_is_dc[B->ntab] = true;
-            if(!derive(scan->dc[h.dc_tbl], *B, true)) return MJX_ERR_BAD_ARG;
-        }
-        if(ac_of[h.ac_tbl] < 0) {
-            ac_of[h.ac_tbl] = B->ntab;
-            if(!derive(scan->ac[h.ac_tbl], *B, false)) return MJX_ERR_BAD_ARG;
-        }
-        comp_dc[c] = dc_of[h.dc_tbl];
-        comp_ac[c] = ac_of[h.ac_tbl];
+        if(h.h_samp < 1 || h.h_samp > 4 || h.v_samp < 1 || h.v_samp > 4 || (long long)h.blocks_per_row < (long long)S.mcus_x * h.h_samp) return MJX_ERR_BAD_ARG;
+    }
+    if(int e = stage_scan_tables(scan, *B, comp_dc, comp_ac, staged_is_dc)) return e;
+    for(int c = 0; c < S.ncomp; ++c) {
+        const mjx_huff_dcomponent_t &h = scan->comp[c];
         DecComp &d = S.c[c];
         d.bpr = h.blocks_per_row;
         d.hs = h.h_samp;
@@ -1124,16 +1177,8 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     }
     S.nslots = nmcu * S.bpm;
     S.ntab = B->ntab;
-    int field_of[8]; // the wave-per-chunk walk keeps up to two AC and four DC fields per bit position
-    {
-        int nd = 0, na = 0;
-        for(int t = 0; t < B->ntab; ++t) field_of[t] = staged_is_dc[t] ? nd++ : na++;
-        S.wave_ok = nd <= 4 && na <= 2;
-        S.wave_nac = (unsigned)na;
-        S.wave_ndc = (unsigned)nd;
-        if(S.wave_ok)
-            for(int b = 0; b < S.bpm; ++b) S.wave_sel |= (unsigned)(field_of[comp_dc[S.slot_comp[b]]] | (field_of[comp_ac[S.slot_comp[b]]] << 2)) << (3 * b);
-    }
+    int field_of[8];
+    S.wave_ok = wave_layout(B->ntab, staged_is_dc, comp_dc, comp_ac, S.slot_comp, S.bpm, field_of, &S.wave_nac, &S.wave_ndc, &S.wave_sel);
     S.nsub = B->nsub;
     if(S.nslots > 0x7FFFFFFFll) return MJX_ERR_BAD_ARG;
     for(S.period = 1; S.period < S.bpm; ++S.period) {

@@ -268,6 +268,10 @@ int mjx_huff_unstuff(const uint8_t *data, size_t nbytes, uint8_t *out, size_t *o
     (void)data; (void)nbytes; (void)out; (void)outlen; (void)segment_offsets; (void)max_segments; (void)nsegments; (void)form;
     return MJX_ERR_BAD_ARG;
 }
+int mjx_huff_wave_tables(const mjx_huff_dscan_t *scan, uint32_t *out, size_t out_words, int32_t info[4]) {
+    (void)scan; (void)out; (void)out_words; (void)info;
+    return MJX_ERR_BAD_ARG;
+}
 
 /* everything below belongs to the plan / test-seam / generator API the drop-in's host code never calls */
 #define UNUSED_INT(name, args) int name args { return MJX_ERR_NO_DEVICE; }
