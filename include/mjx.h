@@ -383,9 +383,9 @@ int mjx_huff_decode_host(const mjx_huff_dscan_t *scan);
 
 /* The decoder's first step on its own (pure host code, no device; a test seam): scan data as it stands in
  * the file -> the bytes without 0xFF00 stuffing and RSTn markers, and the offset (in `out`) at which every
- * restart segment starts (segment_offsets[0] = 0).  `out` needs nbytes + 32 bytes.  form 0: what the
- * decoder uses on this host (AVX2 when the CPU has it), 1: the portable form, 2: the AVX2 form
- * (MJX_ERR_NO_DEVICE without AVX2).  MJX_ERR_BAD_ARG: not a plain run of [segment RSTn]* segment EOI. */
+ * restart segment starts (segment_offsets[0] = 0).  `out` needs nbytes + 64 bytes.  form 0: what the
+ * decoder uses on this host (AVX-512 byte compress or AVX2 when the CPU has them), 1: the portable form, 2: the AVX2
+ * form, 3: the AVX-512 form (MJX_ERR_NO_DEVICE when the CPU lacks it).  MJX_ERR_BAD_ARG: not a plain run of [segment RSTn]* segment EOI. */
 int mjx_huff_unstuff(const uint8_t *data, size_t nbytes, uint8_t *out, size_t *outlen, uint64_t *segment_offsets, int64_t max_segments, int64_t *nsegments,
                      int form);
 

@@ -57,8 +57,7 @@ def call(L, data, max_segs, form):
 
 
 def forms(L):
-    has_avx2 = call(L, b"\x00\xff\xd9", 1, 2)[0] != 1
-    return [0, 1] + ([2] if has_avx2 else [])
+    return [0, 1] + [f for f in (2, 3) if call(L, b"\x00\xff\xd9", 1, f)[0] != 1]  # 2: AVX2, 3: AVX-512 byte compress, where the CPU has them
 
 
 def test_random_streams_with_markers_everywhere(L):
@@ -102,3 +101,30 @@ def test_segment_limit_and_long_runs(L):
         rc, got = call(L, data, 3, form)
         assert rc == 0 and got == unstuff_py(data, 3) and got[1] == [0, 1000, 2000]
         assert call(L, data, 2, form)[0] == 4  # more restart segments than the frame header promises
+
+
+def test_long_streams_with_0xff_at_every_offset_of_the_vector_width(L):
+    """0xFF 0x00 pairs and markers placed at every offset modulo 64 (the widest form's block), runs of them back to back,
+    a 0xFF in the last byte of a block, stuffed zeros in the first: every form gives what the portable one gives"""
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        n = int(rng.integers(200, 5000))
+        raw = rng.integers(0, 255, n, dtype=np.uint8)  # no 0xFF of its own
+        body = bytearray()
+        rst = 0
+        where = set(int(v) for v in rng.integers(0, n, n // int(rng.integers(3, 60))))
+        where |= {o for o in range(trial % 64, n, 64)} | {o for o in range((trial + 63) % 64, n, 64 * 3)}
+        for i in range(n):
+            if i in where:
+                kind = int(rng.integers(0, 20))
+                if kind == 0:
+                    body += bytes([0xFF, 0xD0 + rst])
+                    rst = (rst + 1) & 7
+                else:
+                    body += b"\xff\x00" * (1 if kind < 15 else int(rng.integers(2, 40)))
+            body.append(int(raw[i]))
+        data = bytes(body) + b"\xff\xd9" + bytes(rng.integers(0, 256, int(rng.integers(0, 100)), dtype=np.uint8))
+        want = call(L, data, 4096, 1)
+        assert want[0] == 0 and want[1] == unstuff_py(data, 4096)
+        for form in forms(L):
+            assert call(L, data, 4096, form) == want, (trial, form, n)
