@@ -7,7 +7,7 @@ T=$PWD/tests/tools
 OUT=$PWD/gpurun_out/enctrace
 rm -rf $OUT; mkdir -p $OUT
 export BENCH_QUALITY=${Q:-85}
-(cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/t -- $T/bench_dropin $H/libmodjpeg.so.1 ${W:-1920} ${HH:-1080} 256 256 6 > $OUT/t.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/t -- $T/bench_dropin $H/libmodjpeg.so.1 ${W:-1920} ${HH:-1080} ${DW:-256} ${DH:-256} ${N:-6} > $OUT/t.log 2>&1)
 python3 - $OUT <<'PY'
 import csv, sys, glob
 out = sys.argv[1]
