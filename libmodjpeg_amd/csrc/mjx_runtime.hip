@@ -1005,6 +1005,8 @@ int mjx_free_host(void *host) {
     return MJX_OK;
 }
 
+constexpr size_t kInPlaceBytes = 1u << 20; // gathered rows up to this size are blended where they are, in pinned memory
+
 int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     if(n < 0) return MJX_ERR_BAD_ARG;
     if(n == 0) return MJX_OK;
@@ -1088,6 +1090,13 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     hipStream_t s = arena->stream;
     char       *base = arena->dev;
 
+    // A small span does not travel at all: the kernels work on the pinned buffer itself (it is mapped into the device's address
+    // space; a quarter of a megabyte over PCIe costs the kernel a few microseconds, the two copies and their set-up cost thirty).
+    // MJX_COMPOSE_COPIES=1: always copy.
+    static const bool always_copy = getenv("MJX_COMPOSE_COPIES") != nullptr;
+    const bool        in_place = one_span && !always_copy && stage_bytes > 0 && stage_bytes <= kInPlaceBytes;
+    char             *rows_base = in_place ? arena->pin : base; // where the kernels find packet and gathered rows
+
     // second pass: real device addresses, uploads
     size_t off = packet_cap, k = 0, stage = packet_cap;
     std::vector<size_t> stage_off;
@@ -1110,7 +1119,7 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
             off += round256(wb);
         }
         else {
-            j.coef = reinterpret_cast<int16_t *>(base + off);
+            j.coef = reinterpret_cast<int16_t *>(rows_base + off);
             coef_off.push_back(off);
             stage_off.push_back(stage);
             for(int row = 0; row < r.rows; ++row)
@@ -1162,12 +1171,14 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     expand_runs(t, t.light, reinterpret_cast<Run *>(arena->pin + o_runs) + t.runs.size(), nullptr, scheds.data());
     memcpy(arena->pin + o_q, t.qrq.data(), t.qrq.size());
     if(one_span && stage != off) return MJX_ERR_BAD_ARG; // (cannot happen: both advanced by the gathered rectangles alone)
-    if(one_span && stage > packet_cap) MJX_HIP(hipMemcpyAsync(base, arena->pin, stage, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH); // packet, the slack behind it, rows
+    if(in_place) {} // nothing goes up
+    else if(one_span && stage > packet_cap) MJX_HIP(hipMemcpyAsync(base, arena->pin, stage, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH); // packet, the slack behind it, rows
     else MJX_HIP(hipMemcpyAsync(base, arena->pin, packet, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
 
-    err = launch_compose(reinterpret_cast<const Run *>(base + o_runs), (int)t.runs.size(), base + o_q, tiles_i16, s);
-    if(err == MJX_OK) err = launch_compose_light(reinterpret_cast<const Run *>(base + o_runs) + t.runs.size(), (int)t.light.size(), base + o_q, tiles_i16, s);
-    if(err == MJX_OK && one_span) {
+    err = launch_compose(reinterpret_cast<const Run *>(rows_base + o_runs), (int)t.runs.size(), rows_base + o_q, tiles_i16, s);
+    if(err == MJX_OK) err = launch_compose_light(reinterpret_cast<const Run *>(rows_base + o_runs) + t.runs.size(), (int)t.light.size(), rows_base + o_q, tiles_i16, s);
+    if(err == MJX_OK && in_place) {} // nothing comes down
+    else if(err == MJX_OK && one_span) {
         if(stage > packet_cap) err = check_hip(hipMemcpyAsync(arena->pin + packet_cap, base + packet_cap, stage - packet_cap, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H)", MJX_ERR_LAUNCH);
     }
     else if(err == MJX_OK) {
