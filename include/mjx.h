@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MJX_VERSION 102
+#define MJX_VERSION 103
 
 /* error codes (0 = success).  The libmodjpeg.h shim maps them onto MJ_ERR_* (INTEGRATION.md). */
 #define MJX_OK             0
@@ -53,6 +53,30 @@ extern "C" {
 #define MJX_ERR_LAUNCH     5 /* kernel launch or synchronisation failed */
 
 typedef void *mjx_stream_t; /* a hipStream_t, or NULL for the default stream */
+
+/* ---- ordering contract for DEVICE memory handed to the synchronous entry points ------------------
+ * Two kinds of entry point take device memory:
+ *  (1) the asynchronous ones that take a `mjx_stream_t stream` argument and only ENQUEUE on it - mjx_compose_run,
+ *      mjx_convolve, mjx_effect_zero, mjx_dc_plan_run, the mjx_synth_* generators: stream order is the caller's;
+ *  (2) the synchronous, host-style ones that replace a blocking call of the reference (image.c:94 jpeg_read_coefficients,
+ *      image.c:194 jpeg_write_coefficients, compose.c:175 mj_compose_with_mask, effect.c) and may be handed memory
+ *      that is already on the device: mjx_huff_decode_host / mjx_huff_encode_host with MJX_HUFF_PLANES_ON_DEVICE,
+ *      mjx_compose_host with MJX_RECT_ROWS_ON_DEVICE / MJX_RECT_TILES_ON_DEVICE, mjx_tiles_prepare,
+ *      mjx_tile_schedule_create, mjx_effect_dc_device, mjx_effect_zero_device.  These work on a PRIVATE non-blocking
+ *      stream from the library's pool, which is ordered against nothing by itself.  The contract:
+ *        at entry  the library's first device operation is ordered (by an event) after everything that had been
+ *                  queued, when the call was made, on the caller's stream: the `stream` member of the call's
+ *                  struct, or its `after` argument.  NULL is the legacy default stream (which in turn waits for
+ *                  every blocking stream of the device); a struct that was zero-initialised therefore waits for
+ *                  the default stream.  MJX_STREAM_IDLE says that nothing is pending on the memory handed over
+ *                  (the caller has synchronised, or the library itself produced it in an earlier call of this
+ *                  kind): no event, no wait.
+ *        at exit   the call returns only after its own device work has completed, so whatever the caller
+ *                  queues afterwards, on any stream, sees the results.
+ *      Work the caller queues on OTHER streams before the call is the caller's to order (make `stream` wait for it).
+ *  mjx_compose_plan_create_ex with MJX_PLAN_GROUP_BY_DENSITY reads the alpha tiles on the legacy default stream
+ *  and is synchronous: tiles written on a non-blocking stream must be complete before the call. */
+#define MJX_STREAM_IDLE ((mjx_stream_t)(intptr_t)-1)
 
 /* ---- device plumbing (so that C callers need no HIP headers) -------------------------- */
 int         mjx_device_count(void);                 /* number of HIP devices, 0 if none */
@@ -162,6 +186,8 @@ typedef struct mjx_host_rect {
     int32_t         flags;          /* MJX_RECT_* */
     int32_t         reserved;
     const struct mjx_tile_schedule *schedule; /* NULL, or how the blocks of THESE tiles are best shared out (below) */
+    mjx_stream_t    stream;         /* the caller's stream of the ordering contract above, for the DEVICE memory of this
+                                       rectangle (MJX_RECT_ROWS_ON_DEVICE / MJX_RECT_TILES_ON_DEVICE); ignored without them */
 } mjx_host_rect_t;
 /* tile and alpha are DEVICE pointers (tiles kept resident across calls, e.g. one dropon composed
  * into many images): only the plane rows cross PCIe */
@@ -181,7 +207,8 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n);
  * the schedule with them and hands both to mjx_compose_host.  The alpha tiles must not change while
  * the schedule is in use.  flags: MJX_JOB_TILES_I16 when the tiles are int16. */
 typedef struct mjx_tile_schedule mjx_tile_schedule_t;
-int     mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha /* DEVICE */, int rows, int cols, int flags);
+int     mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha /* DEVICE */, int rows, int cols, int flags,
+                                 mjx_stream_t after /* ordering contract: the stream alpha was written on */);
 void    mjx_tile_schedule_destroy(mjx_tile_schedule_t *sched);
 /* octets formed by pattern (0: the tiles are uniform enough for consecutive octets) */
 int64_t mjx_tile_schedule_gather_octets(const mjx_tile_schedule_t *sched);
@@ -228,6 +255,8 @@ typedef struct mjx_tileprep {
     float               *alpha_tile[4];
     int32_t              flags;                          /* MJX_PREP_* */
     int32_t              reserved;
+    mjx_stream_t         stream;                         /* ordering contract: the stream on which tile[] / alpha_tile[] were last
+                                                            used (they are overwritten) */
 } mjx_tileprep_t;
 /* write the tiles as int16 coefficients (the form MJX_JOB_TILES_I16 consumes): tile[] / alpha_tile[]
  * then point at int16_t[rows*cols][64] */
@@ -275,9 +304,10 @@ int mjx_effect_zero(int16_t *coef /* DEVICE */, int blocks_per_row, int rows, in
 int mjx_effect_dc_host(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value);
 int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc);
 int mjx_convolve_host(const float *x, float *y, float w, int k, int l, int nblocks);
-/* the same effects on a plane that is resident on the DEVICE (synchronous, own stream) */
-int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value);
-int mjx_effect_zero_device(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc);
+/* the same effects on a plane that is resident on the DEVICE (synchronous, own stream; `after`: the ordering contract
+ * at the top of this header - the stream the plane was last touched on, NULL, or MJX_STREAM_IDLE) */
+int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value, mjx_stream_t after);
+int mjx_effect_zero_device(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc, mjx_stream_t after);
 
 /* ---- baseline Huffman entropy encoder (write side) ------------------
  * Replaces, for fixed tables, what the reference gets from libjpeg at image.c:194-196
@@ -308,7 +338,7 @@ typedef struct mjx_huff_component {
      * plane itself is not changed.  dc_fx_n = 0: none. */
     int32_t        dc_fx_n;         /* 0 .. MJX_HUFF_MAX_DC_FX */
     int32_t        dc_fx_value[4];
-    uint16_t       dc_fx_q0, dc_fx_reserved;
+    uint16_t       dc_fx_q0, dc_fx_reserved; /* dc_fx_reserved must be 0: zero-initialise the struct (memset / = {0}) */
 } mjx_huff_component_t;
 #define MJX_HUFF_MAX_DC_FX 4
 
@@ -322,6 +352,9 @@ typedef struct mjx_huff_scan {
     int32_t                 flags;          /* MJX_HUFF_* */
     struct mjx_huff_spec   *optimal_dc[4];  /* MJX_HUFF_OPTIMIZE: out, the tables that were built and used ... */
     struct mjx_huff_spec   *optimal_ac[4];  /* ... for every table index a component refers to (caller's storage) */
+    mjx_stream_t            stream;         /* MJX_HUFF_PLANES_ON_DEVICE: the caller's stream of the ordering contract at the top of
+                                               this header (the planes are READ after everything queued on it; NULL = legacy default
+                                               stream, MJX_STREAM_IDLE = nothing pending).  The call returns after its device work. */
 } mjx_huff_scan_t;
 /* the component planes are DEVICE pointers (an image decoded on the device and kept there): no
  * coefficient crosses PCIe, only the compressed bytes come back */
@@ -374,6 +407,10 @@ typedef struct mjx_huff_dscan {
     size_t                 nbytes;           /* bytes available at `data` (may extend past EOI) */
     int32_t                restart_interval; /* MCUs per restart segment (DRI), 0 = none */
     int32_t                flags;            /* MJX_HUFF_PLANES_ON_DEVICE: the planes are DEVICE pointers and stay there */
+    mjx_stream_t           stream;           /* MJX_HUFF_PLANES_ON_DEVICE: the caller's stream of the ordering contract at the top of this
+                                                header: the planes are zeroed and WRITTEN after everything queued on it (a fill, an
+                                                earlier reader); NULL = legacy default stream, MJX_STREAM_IDLE = nothing pending.  The
+                                                call returns after the planes are complete. */
 } mjx_huff_dscan_t;
 
 /* MJX_ERR_BAD_ARG when the data is not a clean baseline scan of this geometry: markers other than

@@ -43,7 +43,7 @@ class HostRect(ctypes.Structure):
     """struct mjx_host_rect (include/mjx.h)"""
     _fields_ = [("rows_ptr", ctypes.c_void_p), ("tile", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("q", ctypes.c_void_p),
                 ("blocks_per_row", ctypes.c_int32), ("col0", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
-                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32), ("schedule", ctypes.c_void_p)]
+                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32), ("schedule", ctypes.c_void_p), ("stream", ctypes.c_void_p)]
 
 
 class PlanStats(ctypes.Structure):
@@ -73,7 +73,17 @@ class TilePrep(ctypes.Structure):
                 ("crop_x", ctypes.c_int32), ("crop_y", ctypes.c_int32), ("crop_w", ctypes.c_int32), ("crop_h", ctypes.c_int32),
                 ("off_x", ctypes.c_int32), ("off_y", ctypes.c_int32), ("source", ctypes.c_int32), ("target", ctypes.c_int32), ("ncomp", ctypes.c_int32),
                 ("h_samp", ctypes.c_int32 * 4), ("v_samp", ctypes.c_int32 * 4), ("tile", ctypes.c_void_p * 4), ("alpha_tile", ctypes.c_void_p * 4),
-                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stream", ctypes.c_void_p)]
+
+
+MJX_STREAM_IDLE = ctypes.c_void_p(-1).value  # "nothing is pending on the device memory handed over" (ordering contract of mjx.h)
+
+
+def caller_stream():
+    """the stream device tensors of the calling thread were last written on (torch's current stream; 0 = the legacy
+    default stream): what the synchronous entry points that take device memory are ordered after"""
+    import torch
+    return torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
 
 
 MJX_PREP_SOURCE_RGB, MJX_PREP_SOURCE_YCC, MJX_PREP_TARGET_RGB, MJX_PREP_TARGET_YCC = 1, 5, 2, 3
@@ -94,7 +104,7 @@ SYMBOLS = [
     ("mjx_compose_plan_create_ex", _i, [ctypes.POINTER(_vp), ctypes.POINTER(RectJob), _i, _vp, _i, _i]),
     ("mjx_compose_plan_gather_octets", ctypes.c_int64, [_vp]),
     ("mjx_compose_plan_stats", _i, [_vp, ctypes.POINTER(PlanStats)]),
-    ("mjx_tile_schedule_create", _i, [ctypes.POINTER(_vp), _vp, _i, _i, _i]),
+    ("mjx_tile_schedule_create", _i, [ctypes.POINTER(_vp), _vp, _i, _i, _i, _vp]),
     ("mjx_tile_schedule_destroy", None, [_vp]),
     ("mjx_tile_schedule_gather_octets", ctypes.c_int64, [_vp]),
     ("mjx_tile_schedule_stats", _i, [_vp, ctypes.POINTER(PlanStats)]),
@@ -116,8 +126,8 @@ SYMBOLS = [
     ("mjx_dc_plan_destroy", None, [_vp]),
     ("mjx_dc_plan_run", _i, [_vp, _vp]),
     ("mjx_effect_zero", _i, [_vp, _i, _i, _i, _i, _vp]),
-    ("mjx_effect_dc_device", _i, [_vp, _i, _i, _i, ctypes.c_uint16, _i]),
-    ("mjx_effect_zero_device", _i, [_vp, _i, _i, _i, _i]),
+    ("mjx_effect_dc_device", _i, [_vp, _i, _i, _i, ctypes.c_uint16, _i, _vp]),
+    ("mjx_effect_zero_device", _i, [_vp, _i, _i, _i, _i, _vp]),
     ("mjx_huff_encode_host", _i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
     ("mjx_huff_decode_host", _i, [_vp]),
     ("mjx_huff_unstuff", _i, [_vp, _sz, _vp, ctypes.POINTER(_sz), _vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), _i]),

@@ -778,11 +778,14 @@ int launch_compose_light(const Run *runs, int nruns, const void *qrq, bool tiles
     return check_hip(hipGetLastError(), "compose_light_kernel launch", MJX_ERR_LAUNCH);
 }
 
-int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s) {
+int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s, bool shared) {
     if(nruns <= 0) return MJX_OK;
     const int groups = (nruns + MJX_GROUP_WAVES - 1) / MJX_GROUP_WAVES;
-    if(tiles_i16) hipLaunchKernelGGL(compose_kernel<true>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
-    else hipLaunchKernelGGL(compose_kernel<false>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
+    // experiment: extra (unused) dynamic LDS caps the workgroups per CU, i.e. leaves registers for another kernel's waves
+    static const unsigned pad = [] { const char *e = getenv("MJX_BLEND_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    const unsigned dyn = shared ? pad : 0u;
+    if(tiles_i16) hipLaunchKernelGGL(compose_kernel<true>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), dyn, s, runs, nruns, qrq);
+    else hipLaunchKernelGGL(compose_kernel<false>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), dyn, s, runs, nruns, qrq);
     return check_hip(hipGetLastError(), "compose_kernel launch", MJX_ERR_LAUNCH);
 }
 

@@ -1291,6 +1291,11 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     if(err != MJX_OK) return err;
     char       *base = arena->dev;
     hipStream_t s = arena->stream;
+    // Planes that live on the device are the caller's, and the first thing that happens to them here is zero_planes() on THIS
+    // stream, which is ordered against nothing: after what the caller has queued on its own stream (mjx.h; round 3's red test
+    // was a fill of the planes on the caller's stream that ran after - or into - the zeroing).  Everything later is on this
+    // stream or on a batch leader's stream, which waits for the `staged` event recorded below.
+    if(on_device && (err = arena->order_after(scan->stream)) != MJX_OK) return err;
 
     static const bool debug = getenv("MJX_HUFFDEC_DEBUG") != nullptr;
     double            t_mark[6] = {0, 0, 0, 0, 0, 0};

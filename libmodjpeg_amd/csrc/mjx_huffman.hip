@@ -567,7 +567,7 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
         d.vs = h.v_samp;
         d.dc_tbl = h.dc_tbl;
         d.ac_tbl = h.ac_tbl;
-        if(h.dc_fx_n < 0 || h.dc_fx_n > MJX_HUFF_MAX_DC_FX || (h.dc_fx_n > 0 && h.dc_fx_q0 == 0)) return MJX_ERR_BAD_ARG;
+        if(h.dc_fx_n < 0 || h.dc_fx_n > MJX_HUFF_MAX_DC_FX || (h.dc_fx_n > 0 && h.dc_fx_q0 == 0) || h.dc_fx_reserved != 0) return MJX_ERR_BAD_ARG;
         d.fx_n = h.dc_fx_n;
         for(int i = 0; i < MJX_HUFF_MAX_DC_FX; ++i) d.fx_value[i] = i < h.dc_fx_n ? h.dc_fx_value[i] : 0;
         d.fx_q0 = h.dc_fx_q0;
@@ -616,6 +616,8 @@ extern "C" int mjx_huff_encode_host(const mjx_huff_scan_t *scan, unsigned char *
     if(err != MJX_OK) return err;
     char       *base = arena->dev;
     hipStream_t s = arena->stream;
+    // planes that live on the device are the caller's: read them after what the caller has queued on its stream (mjx.h)
+    if(on_device && (err = arena->order_after(scan->stream)) != MJX_OK) return err;
 
     size_t po = o_planes;
     for(int c = 0; c < S.ncomp; ++c) {

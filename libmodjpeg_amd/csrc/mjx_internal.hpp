@@ -86,7 +86,11 @@ struct Arena {
     size_t      pin_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t  staged = nullptr; // recorded by a caller whose uploads another stream must wait for
+    hipEvent_t  entry = nullptr;  // recorded on the CALLER's stream when a call is handed device memory (order_after)
     void        release();
+    // The ordering contract of include/mjx.h for the synchronous entry points that are handed device memory: this arena's
+    // stream waits for everything queued so far on the caller's stream (nullptr = legacy default stream); MJX_STREAM_IDLE: no wait.
+    int         order_after(mjx_stream_t caller);
     int         prepare(size_t dev_bytes, size_t pin_bytes);
 };
 
@@ -103,7 +107,8 @@ struct ArenaLease {
 
 // launchers implemented in the kernel translation units
 // qrq: kQuantTableBytes per quantisation table (see above)
-int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s);
+// shared = true: the launch leaves room on every CU for the waves of compose_light_kernel running beside it on another stream
+int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s, bool shared = false);
 // runs of kind kRunZeroAlpha / kRunDcOnly only: the blocks that need no blend stream through a lean kernel of their own
 int launch_compose_light(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s);
 // pattern[first block of the job in the plan + n] = bit (8k + l) set when weight (k, l) of tile block n is not zero

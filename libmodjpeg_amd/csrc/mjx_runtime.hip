@@ -129,6 +129,10 @@ struct mjx_compose_plan {
     bool        tiles_i16 = false;
     SchedStats  stats;
     int         slots = 0, run_max = 0, run_min = 0;
+    // co-run of the two kernels of a step (mjx_compose_run): the streams of the blocks that need no blend run on a side stream
+    // of the plan's, forked from and joined to the caller's stream by events
+    hipStream_t side = nullptr;
+    hipEvent_t  fork = nullptr, join = nullptr;
 };
 
 struct mjx_dc_plan {
@@ -213,6 +217,9 @@ void mjx_compose_plan_destroy(mjx_compose_plan_t *p) {
     if(p->d_runs) (void)hipFree(p->d_runs);
     if(p->d_qrq) (void)hipFree(p->d_qrq);
     if(p->d_gather) (void)hipFree(p->d_gather);
+    if(p->fork) (void)hipEventDestroy(p->fork);
+    if(p->join) (void)hipEventDestroy(p->join);
+    if(p->side) (void)hipStreamDestroy(p->side);
     delete p;
 }
 
@@ -610,7 +617,8 @@ void expand_runs(const Tables &t, const std::vector<RunRef> &refs, Run *out, con
 }
 
 // zero patterns of the alpha tiles of every job in t (one launch over temporary consecutive runs)
-int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<uint32_t> &w00) {
+// `after`: the stream the alpha tiles were written on (ordering contract of mjx.h)
+int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<uint32_t> &w00, mjx_stream_t after) {
     std::vector<Run> tmp;
     for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
         const DevJob &d = t.jobs[(size_t)jid];
@@ -634,6 +642,7 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<u
         int        err = arena->prepare(run_bytes + pat_bytes + w_bytes, run_bytes + pat_bytes + w_bytes);
         if(err != MJX_OK) return err;
         hipStream_t s = arena->stream;
+        if((err = arena->order_after(after)) != MJX_OK) return err;
         memcpy(arena->pin, tmp.data(), tmp.size() * sizeof(Run));
         err = check_hip(hipMemcpyAsync(arena->dev, arena->pin, tmp.size() * sizeof(Run), hipMemcpyHostToDevice, s), "hipMemcpyAsync(scan runs)", MJX_ERR_LAUNCH);
         if(err == MJX_OK)
@@ -647,6 +656,8 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<u
         }
         return err != MJX_OK ? err : serr;
     }
+    // (large scans run on the legacy default stream, which a non-blocking stream of the caller's is not ordered against)
+    if(after != nullptr && after != MJX_STREAM_IDLE) MJX_HIP(hipStreamSynchronize((hipStream_t)after), MJX_ERR_LAUNCH);
     Run      *d_tmp = nullptr;
     uint64_t *d_pat = nullptr;
     uint32_t *d_w = nullptr;
@@ -720,7 +731,7 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
             // without weights leave their tiles behind, which is why that needs the caller's promise
             std::vector<uint64_t> pattern;
             std::vector<uint32_t> w00;
-            if((err = scan_patterns(t, pattern, w00)) != MJX_OK) break;
+            if((err = scan_patterns(t, pattern, w00, nullptr)) != MJX_OK) break; // after the legacy default stream (mjx.h)
             std::vector<JobSegment> all;
             std::vector<Segment>    one;
             for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
@@ -751,6 +762,11 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
         expand_runs(t, t.light, runs.data() + t.runs.size(), p->d_gather, nullptr);
         if((err = check_hip(hipMalloc((void **)&p->d_runs, runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMemcpy(p->d_runs, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
+        if(p->nruns > 0 && p->nlight > 0) { // both kernels have work: they may run side by side (mjx_compose_run)
+            if((err = check_hip(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking), "hipStreamCreate(side)", MJX_ERR_LAUNCH))) break;
+            if((err = check_hip(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH))) break;
+            if((err = check_hip(hipEventCreateWithFlags(&p->join, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH))) break;
+        }
     } while(0);
     if(err != MJX_OK) {
         mjx_compose_plan_destroy(p);
@@ -789,6 +805,17 @@ int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
     // the blend first (the long-running waves), then the streams of the blocks that need none; the two kernels
     // touch disjoint blocks
+    static const int corun = [] { const char *e = getenv("MJX_CORUN"); return e ? atoi(e) : 0; }();
+    if(corun && plan->nruns > 0 && plan->nlight > 0 && plan->side != nullptr) {
+        hipStream_t s = (hipStream_t)stream;
+        MJX_HIP(hipEventRecord(plan->fork, s), MJX_ERR_LAUNCH);
+        MJX_HIP(hipStreamWaitEvent(plan->side, plan->fork, 0), MJX_ERR_LAUNCH);
+        int err = launch_compose(plan->d_runs, plan->nruns, plan->d_qrq, plan->tiles_i16, s, true);
+        if(err == MJX_OK) err = launch_compose_light(plan->d_runs + plan->nruns, plan->nlight, plan->d_qrq, plan->tiles_i16, plan->side);
+        MJX_HIP(hipEventRecord(plan->join, plan->side), MJX_ERR_LAUNCH);
+        MJX_HIP(hipStreamWaitEvent(s, plan->join, 0), MJX_ERR_LAUNCH);
+        return err;
+    }
     int err = launch_compose(plan->d_runs, plan->nruns, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
     if(err == MJX_OK) err = launch_compose_light(plan->d_runs + plan->nruns, plan->nlight, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
     return err;
@@ -801,7 +828,7 @@ void mjx_tile_schedule_destroy(mjx_tile_schedule_t *s) {
     delete s;
 }
 
-int mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha, int rows, int cols, int flags) {
+int mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha, int rows, int cols, int flags, mjx_stream_t after) {
     if(sched == nullptr) return MJX_ERR_NULL_DATA;
     *sched = nullptr;
     if(rows <= 0 || cols <= 0 || (int64_t)rows * cols >= (1ll << 24) || (flags & ~MJX_JOB_TILES_I16)) return MJX_ERR_BAD_ARG;
@@ -820,7 +847,7 @@ int mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha, int
     t.blocks = d.nblocks;
     std::vector<uint64_t> pattern;
     std::vector<uint32_t> w00;
-    int                   err = scan_patterns(t, pattern, w00);
+    int                   err = scan_patterns(t, pattern, w00, after);
     if(err != MJX_OK) return err;
     mjx_tile_schedule *s = new(std::nothrow) mjx_tile_schedule;
     if(s == nullptr) return MJX_ERR_MEMORY;
@@ -875,8 +902,18 @@ void Arena::release() {
         if(dev) (void)hipFree(dev);
         if(pin) (void)hipHostFree(pin);
         if(staged) (void)hipEventDestroy(staged);
+        if(entry) (void)hipEventDestroy(entry);
         if(stream) (void)hipStreamDestroy(stream);
-        dev = nullptr; pin = nullptr; stream = nullptr; staged = nullptr; dev_cap = pin_cap = 0; device = -1;
+        dev = nullptr; pin = nullptr; stream = nullptr; staged = nullptr; entry = nullptr; dev_cap = pin_cap = 0; device = -1;
+}
+
+// The caller's planes / tiles may still be being written (or read) by work the caller queued on its own stream; this arena's
+// stream is non-blocking and ordered against nothing.  Round 3's red test was exactly this pair: a fill of the planes on
+// torch's stream and the decoder's zeroing kernel on the arena's stream, nothing between them.
+int Arena::order_after(mjx_stream_t caller) {
+        if(caller == MJX_STREAM_IDLE) return MJX_OK;
+        if(int e = check_hip(hipEventRecord(entry, (hipStream_t)caller), "hipEventRecord(caller's stream)", MJX_ERR_LAUNCH)) return e;
+        return check_hip(hipStreamWaitEvent(stream, entry, 0), "hipStreamWaitEvent(caller's stream)", MJX_ERR_LAUNCH);
 }
 
 int Arena::prepare(size_t dev_bytes, size_t pin_bytes) {
@@ -891,6 +928,9 @@ int Arena::prepare(size_t dev_bytes, size_t pin_bytes) {
         }
         if(staged == nullptr) {
             if(int e = check_hip(hipEventCreateWithFlags(&staged, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH)) return e;
+        }
+        if(entry == nullptr) {
+            if(int e = check_hip(hipEventCreateWithFlags(&entry, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH)) return e;
         }
         static const bool arena_debug = getenv("MJX_ARENA_DEBUG") != nullptr;
         if(arena_debug && (dev_bytes > dev_cap || pin_bytes > pin_cap))
@@ -1011,7 +1051,8 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     if(n < 0) return MJX_ERR_BAD_ARG;
     if(n == 0) return MJX_OK;
     if(rects == nullptr) return MJX_ERR_NULL_DATA;
-    int live = 0, with_i16 = 0;
+    int  live = 0, with_i16 = 0;
+    bool have_schedule = false;
     for(int i = 0; i < n; ++i) {
         const mjx_host_rect_t &r = rects[i];
         if(r.rows < 0 || r.cols < 0 || r.col0 < 0 || r.blocks_per_row <= 0 || r.col0 + (int64_t)r.cols > r.blocks_per_row) return MJX_ERR_BAD_ARG;
@@ -1020,6 +1061,7 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
         if(r.rows_ptr == nullptr || r.tile == nullptr || r.alpha == nullptr || r.q == nullptr) return MJX_ERR_NULL_DATA;
         if(r.schedule != nullptr && (r.schedule->rows != r.rows || r.schedule->cols != r.cols || r.schedule->tiles_i16 != ((r.flags & MJX_RECT_TILES_I16) != 0)))
             return MJX_ERR_BAD_ARG; // a schedule belongs to the tiles it was made from
+        if(r.schedule != nullptr) have_schedule = true;
         ++live;
         with_i16 += (r.flags & MJX_RECT_TILES_I16) != 0;
     }
@@ -1028,6 +1070,12 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     const bool   tiles_i16 = with_i16 != 0;
     const size_t tile_block_bytes = tiles_i16 ? 128 : 256;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
+    if(have_schedule) { // a schedule's gather table is plain memory of the device it was made on: another device's kernel would fault on it
+        int cur = -1;
+        MJX_HIP(hipGetDevice(&cur), MJX_ERR_NO_DEVICE);
+        for(int i = 0; i < n; ++i)
+            if(rects[i].rows > 0 && rects[i].cols > 0 && rects[i].schedule != nullptr && rects[i].schedule->device != cur) return MJX_ERR_BAD_ARG;
+    }
 
     // device layout: [descriptor packet | per rectangle: plane rows, tile, alpha (unless resident)]
     std::vector<mjx_rect_job_t> jobs;
@@ -1089,6 +1137,19 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
     if(err != MJX_OK) return err;
     hipStream_t s = arena->stream;
     char       *base = arena->dev;
+    {   // device memory of the caller's (rows that live on the device, resident tiles): after the caller's pending work (mjx.h)
+        mjx_stream_t waited[4];
+        int          nwaited = 0;
+        for(int i = 0; i < n; ++i) {
+            const mjx_host_rect_t &r = rects[i];
+            if(r.rows == 0 || r.cols == 0 || !(r.flags & (MJX_RECT_ROWS_ON_DEVICE | MJX_RECT_TILES_ON_DEVICE)) || r.stream == MJX_STREAM_IDLE) continue;
+            bool seen = false;
+            for(int k = 0; k < nwaited; ++k) seen = seen || waited[k] == r.stream;
+            if(seen) continue;
+            if((err = arena->order_after(r.stream)) != MJX_OK) return err;
+            if(nwaited < 4) waited[nwaited++] = r.stream;
+        }
+    }
 
     // A small span does not travel at all: the kernels work on the pinned buffer itself (it is mapped into the device's address
     // space; a quarter of a megabyte over PCIe costs the kernel a few microseconds, the two copies and their set-up cost thirty).
@@ -1224,6 +1285,7 @@ int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, in
     r.flags = 0;
     r.reserved = 0;
     r.schedule = nullptr;
+    r.stream = nullptr;
     return mjx_compose_host(&r, 1);
 }
 
@@ -1382,7 +1444,7 @@ int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols,
 }
 
 // the effects on a plane that already lives on the device: one launch on a pooled stream
-int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value) {
+int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value, mjx_stream_t after) {
     if(rows < 0 || cols < 0 || blocks_per_row < cols) return MJX_ERR_BAD_ARG;
     if(rows == 0 || cols == 0) return MJX_OK;
     if(plane == nullptr) return MJX_ERR_NULL_DATA;
@@ -1400,6 +1462,7 @@ int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols,
     j->q0 = q0;
     j->rq0 = rq_of(q0);
     hipStream_t s = arena->stream;
+    if((err = arena->order_after(after)) != MJX_OK) return err;
     MJX_HIP(hipMemcpyAsync(arena->dev, j, sizeof(DevDcJob), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
     err = launch_effect_dc(reinterpret_cast<const DevDcJob *>(arena->dev), 1, (int64_t)rows * cols, s);
     if(err != MJX_OK) return err;
@@ -1407,7 +1470,7 @@ int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols,
     return MJX_OK;
 }
 
-int mjx_effect_zero_device(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc) {
+int mjx_effect_zero_device(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc, mjx_stream_t after) {
     if(rows < 0 || cols < 0 || blocks_per_row < cols) return MJX_ERR_BAD_ARG;
     if(rows == 0 || cols == 0) return MJX_OK;
     if(plane == nullptr) return MJX_ERR_NULL_DATA;
@@ -1415,6 +1478,7 @@ int mjx_effect_zero_device(int16_t *plane, int blocks_per_row, int rows, int col
     ArenaLease arena;
     int        err = arena->prepare(256, 256);
     if(err != MJX_OK) return err;
+    if((err = arena->order_after(after)) != MJX_OK) return err;
     err = launch_effect_zero(plane, blocks_per_row, rows, cols, keep_dc ? 1 : 0, arena->stream);
     if(err != MJX_OK) return err;
     MJX_HIP(hipStreamSynchronize(arena->stream), MJX_ERR_LAUNCH);

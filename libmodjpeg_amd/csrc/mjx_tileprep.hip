@@ -240,6 +240,7 @@ extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
     }
     const double t1 = dbg ? now() : 0;
     hipStream_t  s = arena->stream;
+    if((err = arena->order_after(p->stream)) != MJX_OK) return err; // the tile buffers are overwritten: after whoever still reads them (mjx.h)
     MJX_HIP(hipMemcpyAsync(arena->dev, src, win_al + win, hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
     if(dbg) (void)hipStreamSynchronize(s);
     const double t2 = dbg ? now() : 0;

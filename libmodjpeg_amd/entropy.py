@@ -9,7 +9,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import check, lib
+from ._lib import caller_stream, check, lib
 
 PLANES_ON_DEVICE = 1  # MJX_HUFF_PLANES_ON_DEVICE
 OPTIMIZE = 2          # MJX_HUFF_OPTIMIZE
@@ -57,7 +57,7 @@ class HuffScan(ctypes.Structure):
     """struct mjx_huff_scan"""
     _fields_ = [("ncomp", ctypes.c_int32), ("mcus_x", ctypes.c_int32), ("mcus_y", ctypes.c_int32), ("comp", HuffComponent * 4),
                 ("dc", ctypes.POINTER(HuffTable) * 4), ("ac", ctypes.POINTER(HuffTable) * 4), ("max_coef_bits", ctypes.c_int32), ("flags", ctypes.c_int32),
-                ("optimal_dc", ctypes.POINTER(HuffSpec) * 4), ("optimal_ac", ctypes.POINTER(HuffSpec) * 4)]
+                ("optimal_dc", ctypes.POINTER(HuffSpec) * 4), ("optimal_ac", ctypes.POINTER(HuffSpec) * 4), ("stream", ctypes.c_void_p)]
 
 
 class HuffDComponent(ctypes.Structure):
@@ -70,7 +70,7 @@ class HuffDScan(ctypes.Structure):
     """struct mjx_huff_dscan"""
     _fields_ = [("ncomp", ctypes.c_int32), ("mcus_x", ctypes.c_int32), ("mcus_y", ctypes.c_int32), ("comp", HuffDComponent * 4),
                 ("dc", ctypes.POINTER(HuffSpec) * 4), ("ac", ctypes.POINTER(HuffSpec) * 4), ("data", ctypes.c_void_p), ("nbytes", ctypes.c_size_t),
-                ("restart_interval", ctypes.c_int32), ("flags", ctypes.c_int32)]
+                ("restart_interval", ctypes.c_int32), ("flags", ctypes.c_int32), ("stream", ctypes.c_void_p)]
 
 
 def spec(table):
@@ -119,6 +119,8 @@ def encode_scan(planes, true_dims, samp, mcus_x, mcus_y, dc_tables=(STD_DC_LUMA,
         sc.comp[c] = HuffComponent(ptr, p.shape[1], true_dims[c][0], true_dims[c][1], samp[c][0], samp[c][1], t, t)
     assert all(on_dev) or not any(on_dev), "planes must all be on the host or all on the device"
     sc.flags = (PLANES_ON_DEVICE if on_dev[0] else 0) | (OPTIMIZE if optimize else 0)
+    if on_dev[0]:
+        sc.stream = caller_stream()  # the encoder reads the planes after whatever torch has queued on them (mjx.h, ordering contract)
     keep = [derived(t) for t in dc_tables], [derived(t) for t in ac_tables]
     for i, t in enumerate(keep[0]):
         sc.dc[i] = ctypes.pointer(t)
@@ -155,6 +157,8 @@ def decode_scan(data, planes, samp, mcus_x, mcus_y, restart_interval=0, dc_table
         sc.comp[c] = HuffDComponent(ptr, p.shape[1], samp[c][0], samp[c][1], t, t)
     assert all(on_dev) or not any(on_dev)
     sc.flags = PLANES_ON_DEVICE if on_dev[0] else 0
+    if on_dev[0]:
+        sc.stream = caller_stream()  # the decoder zeroes and writes the planes after whatever torch has queued on them
     keep = [spec(t) for t in dc_tables], [spec(t) for t in ac_tables]
     for i, t in enumerate(keep[0]):
         sc.dc[i] = ctypes.pointer(t)

@@ -163,6 +163,9 @@ static int blend_components(mj_jpeg_t *m, int n, const comp_tiles_t *ct, int til
         row0[c] = block_y * ci->v_samp_factor;      /* compose.c:265 */
         rect[c].flags = tiles_flags;
         rect[c].schedule = ct[c].schedule;
+        /* cached tiles and a shadow's planes are produced and used by synchronous library calls only (tilecache.c, shadow.c):
+         * nothing is ever pending on them when a call starts */
+        rect[c].stream = MJX_STREAM_IDLE;
         if(rect[c].rows <= 0 || rect[c].cols <= 0) {
             rect[c].rows = rect[c].cols = 0;
             continue;

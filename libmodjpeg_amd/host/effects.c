@@ -32,7 +32,7 @@ static int on_component(mj_jpeg_t *m, int c, plane_op_t op, int arg) {
              * pending ones may stay pending; grayscale zeroes the DCs as well, so what was pending on
              * them is moot */
             if(!arg) s->fx_n[c] = 0;
-            return mjh_from_mjx(mjx_effect_zero_device(s->plane[c], s->pitch[c], rows, cols, arg));
+            return mjh_from_mjx(mjx_effect_zero_device(s->plane[c], s->pitch[c], rows, cols, arg, MJX_STREAM_IDLE));
         }
         if(ci->quant_table == NULL || ci->quant_table->quantval[0] == 0) return MJ_ERR_NULL_DATA;
         /* A DC effect touches 2 bytes of every 128-byte block: as a pass of its own it moves a whole line
@@ -48,7 +48,7 @@ static int on_component(mj_jpeg_t *m, int c, plane_op_t op, int arg) {
             s->fx_value[c][s->fx_n[c]++] = arg;
             return MJ_OK;
         }
-        return mjh_from_mjx(mjx_effect_dc_device(s->plane[c], s->pitch[c], rows, cols, ci->quant_table->quantval[0], arg));
+        return mjh_from_mjx(mjx_effect_dc_device(s->plane[c], s->pitch[c], rows, cols, ci->quant_table->quantval[0], arg, MJX_STREAM_IDLE));
     }
     {
         int pitch = 0; /* libjpeg keeps a plane of this size in one chunk: work on it in place */

@@ -176,6 +176,7 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
             plane = shadow->plane[c];
             pitch = shadow->pitch[c];
             sc.flags = MJX_HUFF_PLANES_ON_DEVICE;
+            sc.stream = MJX_STREAM_IDLE; /* a shadow's planes are only ever touched by synchronous library calls (shadow.c) */
         }
         /* decode straight into libjpeg's array when it is one piece and exactly the MCU grid */
         else if(mjh_row_count(m, c) == sc.mcus_y * vs) plane = mjh_plane_direct(m, c, &pitch);

@@ -188,6 +188,7 @@ int mjh_write_gpu_entropy(mj_jpeg_t *m, unsigned char **memory, size_t *len, int
             plane = shadow->plane[c];
             pitch = shadow->pitch[c];
             sc.flags = MJX_HUFF_PLANES_ON_DEVICE;
+            sc.stream = MJX_STREAM_IDLE; /* a shadow's planes are only ever touched by synchronous library calls (shadow.c) */
         }
         else {
             plane = mjh_plane_direct(m, c, &pitch);

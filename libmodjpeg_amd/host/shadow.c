@@ -155,10 +155,18 @@ int mjh_shadow_settle(mj_jpeg_t *m, int only) {
         jpeg_component_info *ci = &m->cinfo.comp_info[c];
         if(only >= 0 && c != only) continue;
         for(i = 0; i < s->fx_n[c]; i++) {
-            int rv;
-            if(ci->quant_table == NULL || ci->quant_table->quantval[0] == 0) return MJ_ERR_NULL_DATA;
-            rv = mjh_from_mjx(mjx_effect_dc_device(s->plane[c], s->pitch[c], (int)ci->height_in_blocks, (int)ci->width_in_blocks, ci->quant_table->quantval[0], s->fx_value[c][i]));
-            if(rv != MJ_OK) return rv;
+            int rv = MJ_OK;
+            if(ci->quant_table == NULL || ci->quant_table->quantval[0] == 0) rv = MJ_ERR_NULL_DATA;
+            if(rv == MJ_OK)
+                rv = mjh_from_mjx(mjx_effect_dc_device(s->plane[c], s->pitch[c], (int)ci->height_in_blocks, (int)ci->width_in_blocks, ci->quant_table->quantval[0], s->fx_value[c][i],
+                                                       MJX_STREAM_IDLE));
+            if(rv != MJ_OK) {
+                /* effects 0..i-1 are on the plane now: only the rest stays pending, or a later settle / encode would apply
+                 * them a second time */
+                memmove(&s->fx_value[c][0], &s->fx_value[c][i], (size_t)(s->fx_n[c] - i) * sizeof(s->fx_value[c][0]));
+                s->fx_n[c] -= i;
+                return rv;
+            }
         }
         s->fx_n[c] = 0;
     }
@@ -171,6 +179,7 @@ int mjh_host_sync(mj_jpeg_t *m) {
     int           c, rv = MJ_OK;
     if(s == NULL) return MJ_OK;
     rv = mjh_shadow_settle(m, -1);
+    if(rv != MJ_OK) return rv; /* the image stays a device image (what is still pending stays noted): the caller sees the error, and so does whoever asks again */
     m->cinfo.client_data = NULL; /* the array accessors below must not come back here */
     for(c = 0; c < s->ncomp && rv == MJ_OK; c++) {
         const size_t bytes = (size_t)s->pitch[c] * (size_t)s->rows[c] * sizeof(JBLOCK);
@@ -186,6 +195,10 @@ int mjh_host_sync(mj_jpeg_t *m) {
             if(rv == MJ_OK) mjh_rows_scatter(m, c, 0, s->rows[c], tmp);
             free(tmp);
         }
+    }
+    if(rv != MJ_OK) { /* a failed download: libjpeg's arrays are not the image, the shadow still is */
+        m->cinfo.client_data = s;
+        return rv;
     }
     s->magic = 0;
     pool_put(s->buffer, s->bytes, s->device);

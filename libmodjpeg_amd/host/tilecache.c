@@ -293,7 +293,7 @@ static int contents_schedule(struct mjh_tiles *t) {
     for(c = 0; c < t->ncomp; c++) {
         if(t->rows[c] <= 0 || t->cols[c] <= 0 || t->dev_alpha[c] == NULL) continue;
         if((int64_t)t->rows[c] * t->cols[c] >= (1 << 24)) continue; /* beyond what one schedule covers: consecutive octets */
-        if((e = mjx_tile_schedule_create(&t->sched[c], t->dev_alpha[c], t->rows[c], t->cols[c], t->i16 ? MJX_JOB_TILES_I16 : 0)) != MJX_OK) return e;
+        if((e = mjx_tile_schedule_create(&t->sched[c], t->dev_alpha[c], t->rows[c], t->cols[c], t->i16 ? MJX_JOB_TILES_I16 : 0, MJX_STREAM_IDLE)) != MJX_OK) return e;
     }
     return MJX_OK;
 }
@@ -416,6 +416,7 @@ static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COL
         t->bytes += 2 * bytes;
     }
     t1 = debug_tiles() ? now_ms() : 0;
+    p.stream = MJX_STREAM_IDLE; /* fresh or recycled buffers of an entry nobody holds: nothing pending */
     if((e = mjx_tiles_prepare(&p)) != MJX_OK) return e;
     t2 = debug_tiles() ? now_ms() : 0;
     if(debug_tiles())

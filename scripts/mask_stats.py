@@ -62,7 +62,7 @@ def main():
         acc = dict(blocks=0, octets=0, gather=0, zero=0, dc=0, terms=0, union=0, union_cons=0)
         for c, (rows, cols) in enumerate(dims):
             sc = ctypes.c_void_p()
-            check(L.mjx_tile_schedule_create(ctypes.byref(sc), ctypes.c_void_p(keep[c][1].data_ptr()), rows, cols, MJX_JOB_TILES_I16), "mjx_tile_schedule_create")
+            check(L.mjx_tile_schedule_create(ctypes.byref(sc), ctypes.c_void_p(keep[c][1].data_ptr()), rows, cols, MJX_JOB_TILES_I16, None), "mjx_tile_schedule_create")
             st = PlanStats()
             check(L.mjx_tile_schedule_stats(sc, ctypes.byref(st)), "stats")
             L.mjx_tile_schedule_destroy(sc)

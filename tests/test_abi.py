@@ -43,16 +43,16 @@ def test_ctypes_mirrors_have_the_c_layout(hiplib, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     mirrors = {
         "mjx_rect_job_t": (hiplib.RectJob, ["coef", "blocks_per_row", "qtable", "flags"]),
-        "mjx_host_rect_t": (hiplib.HostRect, ["rows_ptr", "q", "blocks_per_row", "flags", "schedule"]),
+        "mjx_host_rect_t": (hiplib.HostRect, ["rows_ptr", "q", "blocks_per_row", "flags", "schedule", "stream"]),
         "mjx_plan_stats_t": (hiplib.PlanStats, ["blocks", "runs", "union_terms", "dc_only_octets", "resident_waves", "run_octets_min"]),
         "mjx_dc_job_t": (hiplib.DcJob, ["coef", "value", "q0"]),
-        "mjx_tileprep_t": (hiplib.TilePrep, ["image", "crop_w", "off_y", "source", "ncomp", "h_samp", "v_samp", "tile", "alpha_tile", "flags"]),
+        "mjx_tileprep_t": (hiplib.TilePrep, ["image", "crop_w", "off_y", "source", "ncomp", "h_samp", "v_samp", "tile", "alpha_tile", "flags", "stream"]),
         "mjx_huff_table_t": (E.HuffTable, ["code", "size"]),
         "mjx_huff_component_t": (E.HuffComponent, ["plane", "blocks_per_row", "h_samp", "ac_tbl", "dc_fx_n", "dc_fx_value", "dc_fx_q0"]),
-        "mjx_huff_scan_t": (E.HuffScan, ["ncomp", "comp", "dc", "ac", "max_coef_bits", "flags", "optimal_dc", "optimal_ac"]),
+        "mjx_huff_scan_t": (E.HuffScan, ["ncomp", "comp", "dc", "ac", "max_coef_bits", "flags", "optimal_dc", "optimal_ac", "stream"]),
         "mjx_huff_spec_t": (E.HuffSpec, ["bits", "vals"]),
         "mjx_huff_dcomponent_t": (E.HuffDComponent, ["plane", "blocks_per_row", "ac_tbl"]),
-        "mjx_huff_dscan_t": (E.HuffDScan, ["ncomp", "comp", "dc", "ac", "data", "nbytes", "restart_interval", "flags"]),
+        "mjx_huff_dscan_t": (E.HuffDScan, ["ncomp", "comp", "dc", "ac", "data", "nbytes", "restart_interval", "flags", "stream"]),
     }
     lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "mjx.h"', 'int main(void) {']
     for name, (_, fields) in mirrors.items():

@@ -12,19 +12,8 @@ from tests.test_gpu_huffman import AC_BITS, AC_VALS, DC_BITS, DC_VALS, ZIGZAG, d
 pytestmark = pytest.mark.gpu
 
 
-class HuffSpec(ctypes.Structure):
-    _fields_ = [("bits", ctypes.c_uint8 * 16), ("vals", ctypes.c_uint8 * 256)]
-
-
-class DComponent(ctypes.Structure):
-    _fields_ = [("plane", ctypes.c_void_p), ("blocks_per_row", ctypes.c_int32), ("h_samp", ctypes.c_int32), ("v_samp", ctypes.c_int32),
-                ("dc_tbl", ctypes.c_int32), ("ac_tbl", ctypes.c_int32)]
-
-
-class DScan(ctypes.Structure):
-    _fields_ = [("ncomp", ctypes.c_int32), ("mcus_x", ctypes.c_int32), ("mcus_y", ctypes.c_int32), ("comp", DComponent * 4),
-                ("dc", ctypes.POINTER(HuffSpec) * 4), ("ac", ctypes.POINTER(HuffSpec) * 4), ("data", ctypes.c_void_p), ("nbytes", ctypes.c_size_t),
-                ("restart_interval", ctypes.c_int32), ("flags", ctypes.c_int32)]
+# the ctypes mirrors of include/mjx.h (layout pinned by tests/test_abi.py)
+from libmodjpeg_amd.entropy import HuffDComponent as DComponent, HuffDScan as DScan, HuffSpec  # noqa: E402
 
 
 def spec(bits, vals):

@@ -477,7 +477,7 @@ def test_tile_schedules_travel_with_resident_tiles_through_the_host_buffer_call(
             tf, af = tile, alpha
         d_t, d_a = _t(tile), _t(alpha)
         sc = vp()
-        check(lib().mjx_tile_schedule_create(ctypes.byref(sc), vp(d_a.data_ptr()), rows, cols, MJX_JOB_TILES_I16 if i16 else 0), "mjx_tile_schedule_create")
+        check(lib().mjx_tile_schedule_create(ctypes.byref(sc), vp(d_a.data_ptr()), rows, cols, MJX_JOB_TILES_I16 if i16 else 0, mj._lib.caller_stream()), "mjx_tile_schedule_create")
         st = PlanStats()
         check(lib().mjx_tile_schedule_stats(sc, ctypes.byref(st)), "mjx_tile_schedule_stats")
         assert st.blocks == n and st.block_terms == int(mask.sum())
@@ -575,3 +575,23 @@ def test_rectangles_made_of_blocks_that_need_no_blend(mj, i16):
             O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 2]), tf, af)
         assert np.array_equal(results[1][j].reshape(-1), want), ("plain plan", j)
         assert np.array_equal(results[0][j].reshape(-1), want), ("lean kernel", j, kind)
+
+
+def test_host_paths_in_place_and_staged_give_the_same_bytes(mj):
+    """mjx_compose_host / mjx_effect_dc_host work IN PLACE on pinned memory by default (spans up to 1 MB) and through staged
+    copies with MJX_COMPOSE_COPIES=1 / MJX_EFFECT_COPIES=1 or above 1 MB: both forms == oracle and == each other
+    (tests/tools/host_paths_check.py, one process per setting because the library reads the switches once)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for copies in (False, True):
+        env = {k: v for k, v in os.environ.items() if k not in ("MJX_COMPOSE_COPIES", "MJX_EFFECT_COPIES")}
+        if copies:
+            env.update(MJX_COMPOSE_COPIES="1", MJX_EFFECT_COPIES="1")
+        out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "host_paths_check.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        last = out.stdout.strip().splitlines()[-1].split()
+        assert last[:3] == ["host", "paths", "ok"] and last[3] == ("1" if copies else "-")
+        digests.append(last[-1])
+    assert digests[0] == digests[1]

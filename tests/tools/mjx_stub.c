@@ -183,7 +183,8 @@ int mjx_release_thread_cache(void) { return MJX_OK; }
 struct mjx_tile_schedule {
     int device, rows, cols, i16;
 };
-int mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha, int rows, int cols, int flags) {
+int mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha, int rows, int cols, int flags, mjx_stream_t after) {
+    (void)after;
     if(sched == NULL || alpha == NULL) return MJX_ERR_NULL_DATA;
     NEED_DEVICE();
     must_be_mine(alpha, "mjx_tile_schedule_create(alpha)");
@@ -245,13 +246,15 @@ int mjx_effect_zero_host(int16_t *plane, int blocks_per_row, int rows, int cols,
     NEED_DEVICE();
     return MJX_OK;
 }
-int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value) {
+int mjx_effect_dc_device(int16_t *plane, int blocks_per_row, int rows, int cols, uint16_t q0, int value, mjx_stream_t after) {
+    (void)after;
     (void)blocks_per_row; (void)rows; (void)cols; (void)q0; (void)value;
     NEED_DEVICE();
     must_be_mine(plane, "mjx_effect_dc_device");
     return MJX_OK;
 }
-int mjx_effect_zero_device(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc) {
+int mjx_effect_zero_device(int16_t *plane, int blocks_per_row, int rows, int cols, int keep_dc, mjx_stream_t after) {
+    (void)after;
     (void)blocks_per_row; (void)rows; (void)cols; (void)keep_dc;
     NEED_DEVICE();
     must_be_mine(plane, "mjx_effect_zero_device");
