@@ -72,6 +72,9 @@ def parse(argv=None):
                     help="f32 (default, the workload as SURVEY 8d defines it: 768 B per block); i16: the prepared tiles kept as the int16 "
                          "coefficients they are made from, converted in the kernel (512 B per block; secondary, labelled)")
     ap.add_argument("--no-group", action="store_true", help="compose: keep every octet 8 consecutive blocks (no grouping of blocks by what they need)")
+    ap.add_argument("--launch", choices=["auto", "serial", "side-by-side"], default="auto",
+                    help="compose, plans with blocks that are blended AND blocks that need no blend (regimes A4, A5): the two kernels of a step one after "
+                         "the other, side by side, or as the library decides (default; side by side when both fill the device)")
     ap.add_argument("--keep-zero-alpha", action="store_true",
                     help="compose: blocks without any weight still stream their tile and alpha blocks (no MJX_PLAN_ALPHA_IS_FINAL)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
@@ -415,7 +418,7 @@ def bench_compose(args, rank, world):
     batch = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, regime, image0=image0, tiles_i16=(args.tiles == "i16"))
     bytes_per_block = 512 if args.tiles == "i16" else BYTES_PER_BLOCK  # int16 tiles: 128 + 128 + 128 read, 128 written
     batch.fill_synthetic()
-    batch.build_plan(group_by_density=not args.no_group, alpha_is_final=not args.keep_zero_alpha)
+    batch.build_plan(group_by_density=not args.no_group, alpha_is_final=not args.keep_zero_alpha, side_by_side={"auto": None, "serial": False, "side-by-side": True}[args.launch])
     plan_stats = batch.plan_stats()
     blocks_per_step = batch.total_blocks()
     sync = torch.cuda.synchronize
@@ -510,11 +513,14 @@ def bench_compose(args, rank, world):
                        "dropon": f"{dw}x{dh} alpha-masked, per-image tiles, MCU ({mcu_x},{mcu_y})",
                        "alpha_regime": args.regime, "tiles": "float (768 B per block)" if args.tiles == "f32" else "int16 coefficients, converted in the kernel (512 B per block)",
                        "density_grouping": (not args.no_group), "gather_octets_per_gpu": int(batch.gather_octets), "plan": plan_stats,
+                       "launch": ("side by side: %d light runs streamed beside the lean blend kernel, the rest after it" % plan_stats["runs_beside"]) if plan_stats.get("runs_beside") else "one kernel after the other",
                        "blocks_per_step_total": tot_blocks, "blocks_per_step_per_gpu": blocks_per_step, "spinup_ms": args.spinup_ms,
                        "parallelism": f"images sharded x{world} ({args.scaling}), no collective, no RCCL"},
             "parity": verdicts.pop() if len(verdicts) == 1 else "mixed: see per_rank",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mjx::compose_kernel", "kernel_ms_mean": mean_kern_ms,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "mjx::compose_kernel" if not plan_stats.get("zero_alpha_octets") and not plan_stats.get("dc_only_octets") else "one step = mjx::compose_kernel (or its lean build) + mjx::compose_light_kernel (+ mjx::compose_light_shared_kernel beside it)",
+                         "kernel_ms_mean": mean_kern_ms,
                          "kernel_ms_mean_is": "distance of two HIP events around the K timed launches on the launch stream / K",
                          "kernel_ms_pristine": pristine_ms, "kernel_ms_pristine_min": min(ms) if ms else None,
                          "kernel_ms_pristine_median": sorted(ms)[len(ms) // 2] if ms else None,

@@ -146,6 +146,14 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
 #define MJX_PLAN_GROUP_BY_DENSITY 1
 #define MJX_PLAN_ALPHA_IS_FINAL   2
 #define MJX_PLAN_TILES_I16        4
+/* How the two kernels of a step are launched when a plan has both kinds of work (blocks that are blended: bound by the vector
+ * ALU; blocks that need no blend: bound by the memory system).  By default a plan whose launches fill the device runs them SIDE
+ * BY SIDE - a lean build of the blend kernel, a long-lived stream kernel in the registers it leaves on every CU, forked from
+ * and joined to the caller's stream by events inside mjx_compose_run (legal in a stream capture) - and a small one runs them
+ * one after the other.  MJX_PLAN_SERIAL: always one after the other; MJX_PLAN_SIDE_BY_SIDE: side by side whatever the size
+ * (tests).  Purely a schedule: the results are identical. */
+#define MJX_PLAN_SERIAL           8
+#define MJX_PLAN_SIDE_BY_SIDE     16
 int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs,
                                const uint16_t *qtables, int nq, int flags);
 /* octets (8 blocks) of the plan that were formed by pattern rather than by position */
@@ -160,7 +168,7 @@ typedef struct mjx_plan_stats {
     int64_t union_terms_consecutive; /* what union_terms would be with every octet 8 consecutive blocks (over all of them) */
     int32_t resident_waves; /* wavefronts of the compose kernel the device holds at once: what runs are cut for */
     int32_t run_octets_max, run_octets_min;
-    int32_t reserved;
+    int32_t runs_beside; /* runs of blocks that need no blend that are streamed BESIDE the blend kernel (0: the kernels run one after the other) */
 } mjx_plan_stats_t;
 int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out);
 void mjx_compose_plan_destroy(mjx_compose_plan_t *plan);

@@ -18,6 +18,8 @@ MJX_ERR_LAUNCH = 5
 MJX_PLAN_GROUP_BY_DENSITY = 1
 MJX_PLAN_ALPHA_IS_FINAL = 2
 MJX_PLAN_TILES_I16 = 4
+MJX_PLAN_SERIAL = 8         # the two kernels of a step always one after the other
+MJX_PLAN_SIDE_BY_SIDE = 16  # ... always side by side (the default decides by the size of the launch)
 MJX_JOB_TILES_I16 = 1
 MJX_RECT_TILES_ON_DEVICE = 1
 MJX_RECT_ROWS_ON_DEVICE = 2
@@ -50,7 +52,7 @@ class PlanStats(ctypes.Structure):
     """struct mjx_plan_stats (include/mjx.h)"""
     _fields_ = [("blocks", ctypes.c_int64), ("octets", ctypes.c_int64), ("gather_octets", ctypes.c_int64), ("zero_alpha_octets", ctypes.c_int64),
                 ("runs", ctypes.c_int64), ("block_terms", ctypes.c_int64), ("union_terms", ctypes.c_int64), ("dc_only_octets", ctypes.c_int64), ("union_terms_consecutive", ctypes.c_int64),
-                ("resident_waves", ctypes.c_int32), ("run_octets_max", ctypes.c_int32), ("run_octets_min", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("resident_waves", ctypes.c_int32), ("run_octets_max", ctypes.c_int32), ("run_octets_min", ctypes.c_int32), ("runs_beside", ctypes.c_int32)]
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}

@@ -142,11 +142,15 @@ class ComposeBatch:
             self.alpha[c][:] = one[c][1]
 
     # ---- launch plan ------------------------------------------------------------------------
-    def build_plan(self, group_by_density=True, alpha_is_final=True):
+    def build_plan(self, group_by_density=True, alpha_is_final=True, side_by_side=None):
         """group_by_density: octets are formed from blocks that need the same terms where a rectangle
         mixes patterns (mjx_compose_plan_create_ex); a schedule only, same results.  alpha_is_final (with
         it): the alpha tiles will not change any more, so blocks without any weight leave their tile and
-        alpha blocks behind (the reference skips every term of theirs, convolve.c:32)"""
+        alpha blocks behind (the reference skips every term of theirs, convolve.c:32).  side_by_side: None = the
+        library decides by the size of the launch whether the blend kernel and the streams of the blocks that need
+        no blend run side by side; True / False force it (MJX_PLAN_SIDE_BY_SIDE / MJX_PLAN_SERIAL)"""
+        from ._lib import MJX_PLAN_SERIAL, MJX_PLAN_SIDE_BY_SIDE
+        how = 0 if side_by_side is None else (MJX_PLAN_SIDE_BY_SIDE if side_by_side else MJX_PLAN_SERIAL)
         jobs = (RectJob * (3 * self.n))()
         j = 0
         for i in range(self.n):
@@ -159,7 +163,7 @@ class ComposeBatch:
         qt = np.ascontiguousarray(np.stack(self.quant))
         self.destroy_plan()
         check(lib().mjx_compose_plan_create_ex(ctypes.byref(self.plan), jobs, 3 * self.n, qt.ctypes.data_as(ctypes.c_void_p), 3,
-                                               (MJX_PLAN_GROUP_BY_DENSITY | (MJX_PLAN_ALPHA_IS_FINAL if alpha_is_final else 0)) if group_by_density else 0),
+                                               ((MJX_PLAN_GROUP_BY_DENSITY | (MJX_PLAN_ALPHA_IS_FINAL if alpha_is_final else 0)) if group_by_density else 0) | how),
               "mjx_compose_plan_create_ex")
         assert lib().mjx_compose_plan_blocks(self.plan) == self.n * self.blocks_per_image
         self.gather_octets = lib().mjx_compose_plan_gather_octets(self.plan)

@@ -105,7 +105,8 @@ constexpr unsigned long long row_mask(int K) {
 //   cd[u]   dequantised coefficients (after step D), x[u] = tile - cd, al[u] = alpha row
 // returns Y in row layout
 // ------------------------------------------------------------------------------------------
-template <class WRow>
+// SZ0: keep M_SQRT2 * (double)z_l[0] of all eight l in registers (16 VGPRs) instead of recomputing it per term (cvt + mul)
+template <bool SZ0, class WRow>
 MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow)[8], WRow &&weight_row, float *imgZ, int b, int r) {
     // which terms does this octet need?  bit (8b + rp) of m[l] <=> alpha_b[(rp - 2b) & 7][l] != 0
     unsigned long long m[8];
@@ -117,9 +118,7 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
     // execute in order, so the next put_row may be issued before this get_col has returned.
     float        z[8][8];
     const double sx0 = kSqrt2 * (double)x[0];
-#if MJX_SZ0_CACHE
-    double       sz0[8]; // M_SQRT2 * (double)z_l[0], used by the row v == k of every term (k >= 1, l)
-#endif
+    double       sz0[SZ0 ? 8 : 1]; // M_SQRT2 * (double)z_l[0], used by the row v == k of every term (k >= 1, l)
     static_for<8>([&](auto L) {
         if(m[L] != 0ull) {
             float zr[8];
@@ -128,9 +127,7 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
             wave_sync();
             lds_get_col(imgZ, b, r, z[L]);
             wave_sync();
-#if MJX_SZ0_CACHE
-            sz0[L] = kSqrt2 * (double)z[L][0];
-#endif
+            if constexpr(SZ0) sz0[L] = kSqrt2 * (double)z[L][0];
         }
     });
 
@@ -153,12 +150,8 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
                         vstage_first(y, z[L], w);
                     }
                     else {
-#if MJX_SZ0_CACHE
-                        vstage<K>(y, z[L], K == 0 ? 0.0 : sz0[L], w);
-#else
-                        // M_SQRT2*(double)z_l[0] recomputed per term (cvt + mul)
-                        vstage<K>(y, z[L], K == 0 ? 0.0 : kSqrt2 * (double)z[L][0], w);
-#endif
+                        if constexpr(SZ0) vstage<K>(y, z[L], K == 0 ? 0.0 : sz0[L], w);
+                        else vstage<K>(y, z[L], K == 0 ? 0.0 : kSqrt2 * (double)z[L][0], w);
                     }
                 }
             });
@@ -286,12 +279,13 @@ MJX_DEV void tile_rc(const DevJob &job, int nc, int &trow, int &tcol) {
 }
 
 // per-lane addressing state of a run: describes the octet whose pieces were issued last
+// (the tile / alpha pieces of a consecutive octet are addressed as scalar base + n0 * block bytes, a wave-uniform 64-bit
+// value, plus this lane's constant chunk offset: no per-lane running offsets)
 struct OctetAddr {
     int      tcol;  // tile column of this lane's JCOEF block (lane>>3)
-    unsigned pblk;  // its block index inside the plane
-    unsigned toff;  // byte offset of this lane's tile chunk inside job.tile (alpha: aoff)
-    unsigned aoff;
+    unsigned pblk;  // its block index inside the plane: also where the octet will be stored (store_ptr)
 };
+MJX_DEV int16_t *store_ptr(const DevJob &job, unsigned pblk, int lane) { return job.coef + (size_t)pblk * 64 + (lane & 7) * 8; }
 
 // tile / alpha pieces: piece j holds blocks 4j .. 4j+3, 16 chunks of 16 B per block.  Chunk (row
 // position rp, half position hp) of block b holds half hp ^ ph(b) of tile row rp, resp. of alpha
@@ -323,11 +317,11 @@ MJX_DEV unsigned plane_block_of(const DevJob &job, int n) {
 }
 
 template <bool I16>
-MJX_DEV int16_t *dma_octet_gather(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned a_in, unsigned dC, unsigned dT, unsigned dA) {
-    const int bq = lane >> 4;
-    const int n = G[o * kWaveBlocks + (lane >> 3)];
-    int16_t  *cptr = job.coef + (size_t)plane_block_of(job, n) * 64 + (lane & 7) * 8;
-    dma16(cptr, dC);
+MJX_DEV unsigned dma_octet_gather(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned a_in, unsigned dC, unsigned dT, unsigned dA) {
+    const int      bq = lane >> 4;
+    const int      n = G[o * kWaveBlocks + (lane >> 3)];
+    const unsigned cptr = plane_block_of(job, n);
+    dma16(store_ptr(job, cptr, lane), dC);
     if constexpr(I16) { // int16 tiles: one piece each, 8 x 128-byte segments, lane (b, r) <- row r of its block
         const unsigned off = (unsigned)n * 128u + (unsigned)(lane & 7) * 16u;
         dma16_so(job.tile, off, dT);
@@ -345,7 +339,7 @@ MJX_DEV int16_t *dma_octet_gather(const DevJob &job, int o, int lane, const int 
 // generic (slow) form: any octet, lanes past the end of the job clamp to its last block.
 // Issues the pieces and leaves `a` describing this octet.
 template <bool I16>
-MJX_DEV int16_t *dma_octet_generic(const DevJob &job, int n0, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
+MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
     const int last = job.nblocks - 1;
     int       nb = n0 + (lane >> 3);
     nb = nb < last ? nb : last;
@@ -353,11 +347,9 @@ MJX_DEV int16_t *dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
     tile_rc(job, nb, trow, a.tcol);
     // plane block index < 2^31 (rows, pitch < 2^24 each: 24-bit multiply), byte offset in 64 bit
     a.pblk = __umul24((unsigned)(job.row0 + trow), (unsigned)job.bpr) + (unsigned)(job.col0 + a.tcol);
-    int16_t *cptr = job.coef + (size_t)a.pblk * 64 + (lane & 7) * 8;
-    dma16(cptr, dC);
+    const unsigned cptr = a.pblk;
+    dma16(store_ptr(job, cptr, lane), dC);
     if constexpr(I16) { // int16 tiles: natural order, 16 bytes per lane, the clamped block like the JCOEF piece
-        a.toff = (unsigned)n0 * 128u + (unsigned)lane * 16u;
-        a.aoff = a.toff;
         const size_t at = (size_t)nb * 128 + (size_t)(lane & 7) * 16;
         dma16(reinterpret_cast<const char *>(job.tile) + at, dT);
         dma16(reinterpret_cast<const char *>(job.alpha) + at, dT + 1024);
@@ -366,11 +358,9 @@ MJX_DEV int16_t *dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
     const int bq = lane >> 4;
     unsigned  t_in, a_in;
     chunk_in_block(lane, t_in, a_in);
-    a.toff = (unsigned)(n0 + bq) * 256u + t_in;
-    a.aoff = (unsigned)(n0 + bq) * 256u + a_in;
     if(n0 + 7 <= last) {
-        dma16x2(job.tile, a.toff, dT);
-        dma16x2(job.alpha, a.aoff, dA);
+        dma16x2(reinterpret_cast<const char *>(job.tile) + (size_t)n0 * 256, (unsigned)bq * 256u + t_in, dT);
+        dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, (unsigned)bq * 256u + a_in, dA);
     }
     else {
         int n_lo = n0 + bq, n_hi = n0 + 4 + bq;
@@ -386,7 +376,7 @@ MJX_DEV int16_t *dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
 
 // fast form: the octet after the one described by `a`, which must be a full octet (no clamping)
 template <bool I16>
-MJX_DEV int16_t *dma_octet_next(const DevJob &job, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
+MJX_DEV unsigned dma_octet_next(const DevJob &job, int n0, int lane, unsigned t_in, unsigned a_in, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
     a.tcol += kWaveBlocks;
     a.pblk += kWaveBlocks;
     const unsigned row_skip = (unsigned)(job.bpr - job.cols);
@@ -394,18 +384,16 @@ MJX_DEV int16_t *dma_octet_next(const DevJob &job, int lane, OctetAddr &a, unsig
         a.tcol -= job.cols;
         a.pblk += row_skip;
     }
-    int16_t *cptr = job.coef + (size_t)a.pblk * 64 + (lane & 7) * 8;
-    dma16(cptr, dC);
+    const unsigned cptr = a.pblk;
+    dma16(store_ptr(job, cptr, lane), dC);
     if constexpr(I16) {
-        a.toff += kWaveBlocks * 128u;
-        dma16_so(job.tile, a.toff, dT);
-        dma16_so(job.alpha, a.toff, dT + 1024);
+        dma16_so(reinterpret_cast<const char *>(job.tile) + (size_t)n0 * 128, (unsigned)lane * 16u, dT);
+        dma16_so(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 128, (unsigned)lane * 16u, dT + 1024);
         return cptr;
     }
-    a.toff += kWaveBlocks * 256u;
-    a.aoff += kWaveBlocks * 256u;
-    dma16x2(job.tile, a.toff, dT);
-    dma16x2(job.alpha, a.aoff, dA);
+    const unsigned bq256 = (unsigned)(lane >> 4) * 256u;
+    dma16x2(reinterpret_cast<const char *>(job.tile) + (size_t)n0 * 256, bq256 + t_in, dT);
+    dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, bq256 + a_in, dA);
     return cptr;
 }
 
@@ -417,12 +405,20 @@ struct RunCtx {
     const int *G;       // gather: the run's table in LDS
     unsigned   t_in, a_in;
 };
+// returns the plane block this lane's JCOEF row belongs to (where the octet is stored: store_ptr)
 template <bool I16>
-MJX_DEV int16_t *dma_octet(const DevJob &job, const RunCtx &rc, int o, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
+MJX_DEV unsigned dma_octet(const DevJob &job, const RunCtx &rc, int o, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
     if(rc.gather) return dma_octet_gather<I16>(job, o, lane, rc.G, rc.t_in, rc.a_in, dC, dT, dA);
     const int n = rc.first + o * kWaveBlocks;
-    if(o != 0 && n + kWaveBlocks <= job.nblocks) return dma_octet_next<I16>(job, lane, a, dC, dT, dA);
+    if(o != 0 && n + kWaveBlocks <= job.nblocks) return dma_octet_next<I16>(job, n, lane, rc.t_in, rc.a_in, a, dC, dT, dA);
     return dma_octet_generic<I16>(job, n, lane, a, dC, dT, dA);
+}
+// the same for the lean build of the kernel, which does not keep the lane's two chunk offsets in registers
+template <bool I16>
+MJX_DEV unsigned dma_octet_lean(const DevJob &job, const RunCtx &rc0, int o, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
+    RunCtx rc = rc0;
+    if constexpr(!I16) chunk_in_block(lane, rc.t_in, rc.a_in);
+    return dma_octet<I16>(job, rc, o, lane, a, dC, dT, dA);
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
@@ -529,7 +525,8 @@ MJX_DEV void octet_dc_only_rq(int16_t *cptr, const uint4 q4, const float (&rq)[8
 }
 
 // one octet whose operands have landed in (pC, pT, pA): registers, blend, store to cptr
-MJX_DEV void octet_compute(int16_t *cptr, int lane, int b, int r, const float *qrow, const uint4 c4, const float4 t_lo, const float4 t_hi, const float4 a_lo,
+template <bool SZ0>
+MJX_DEV void octet_compute(const DevJob &job, unsigned cblk, int lane, int b, int r, const float *qrow, const uint4 c4, const float4 t_lo, const float4 t_hi, const float4 a_lo,
                            const float4 a_hi, const float *pA, float *imgZ) {
     const uint4 q4 = *reinterpret_cast<const uint4 *>(qrow); // this lane's quant row, 8 x u16
     // D: (short)(coef * q), two coefficients per register (compose.c:277-286)
@@ -548,7 +545,7 @@ MJX_DEV void octet_compute(int16_t *cptr, int lane, int b, int r, const float *q
     (void)ph; (void)pA; (void)imgZ;
     static_for<8>([&](auto U) { y[U] = x[U] * al[U]; });
 #else
-    octet_blend(x, al, y,
+    octet_blend<SZ0>(x, al, y,
                 [&](int K, float (&wk)[8]) {
                     const float *wrow = pA + b * 64 + ((K + 2 * b) & 7) * 8;
                     const float4 lo = *reinterpret_cast<const float4 *>(wrow + 4 * ph), hi = *reinterpret_cast<const float4 *>(wrow + 4 - 4 * ph);
@@ -557,7 +554,7 @@ MJX_DEV void octet_compute(int16_t *cptr, int lane, int b, int r, const float *q
                 imgZ, b, r); // compose.c:300-312
 #endif
 
-    octet_tail(cptr, qrow, cd, y);
+    octet_tail(store_ptr(job, cblk, lane), qrow, cd, y);
 }
 
 #ifndef MJX_COMPOSE_MIN_WAVES
@@ -569,8 +566,11 @@ MJX_DEV void octet_compute(int16_t *cptr, int lane, int b, int r, const float *q
 // into the kernel: tile = (float)coef exactly, weight = (float)((double)(float)coef * K) with the
 // reference's double constants, computed by the lane that holds the row and written into the same
 // rotated, half-swapped LDS image the float path's DMA fills.
-template <bool I16>
-__global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void compose_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
+// LEAN: the build that shares a CU with the waves of compose_light_kernel (launch_compose(shared)): at most 144 registers, so
+// that three of its waves leave 80 of a SIMD's 512 to a wave of the other kernel - M_SQRT2 * (double)z_l[0] is recomputed per
+// term (+2 of ~31 instructions per term k >= 1) and the lane's chunk offsets per octet (+8 instructions).
+template <bool I16, bool LEAN>
+MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
     __shared__ __attribute__((aligned(16))) WaveLds lds[MJX_GROUP_WAVES];
 
     const int lane = threadIdx.x & 63;
@@ -592,7 +592,8 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
     rc.first = first;
     rc.gather = kind != kRunConsecutive;
     rc.G = L.G;
-    chunk_in_block(lane, rc.t_in, rc.a_in);
+    rc.t_in = rc.a_in = 0;
+    if constexpr(!LEAN) chunk_in_block(lane, rc.t_in, rc.a_in);
 
     // The job's quantisation rows (8 x u16 and their 8 reciprocals per row, 384 bytes laid out as the
     // kernel reads them) come in as one more LDS-DMA piece: nothing the compiler sees as a VMEM load
@@ -610,10 +611,10 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
 
     // prologue: the first DEPTH octets of the run
     OctetAddr addr;
-    int16_t  *cp[MJX_DEPTH + 1]; // cp[d] = store address of octet i + d
+    unsigned  cp[MJX_DEPTH + 1]; // cp[d] = plane block of this lane's row of octet i + d (its store address: store_ptr)
     static_for<MJX_DEPTH>([&](auto D) {
-        cp[D] = nullptr;
-        if(D < noct) cp[D] = dma_octet<I16>(job, rc, D, lane, addr, lds_addr(L.C[D]), lds_addr(L.T[D]), lds_addr(L.A[D]));
+        cp[D] = 0;
+        if(D < noct) cp[D] = (LEAN ? dma_octet_lean<I16> : dma_octet<I16>)(job, rc, D, lane, addr, lds_addr(L.C[D]), lds_addr(L.T[D]), lds_addr(L.A[D]));
     });
 
     const int     ph = (b >> 1) & 1;
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
         int sn = sa + MJX_DEPTH; // alpha slot of octet i + DEPTH
         sn = sn > MJX_DEPTH ? sn - (MJX_DEPTH + 1) : sn;
         cp[MJX_DEPTH] = cp[0];
-        if(i + MJX_DEPTH < noct) cp[MJX_DEPTH] = dma_octet<I16>(job, rc, i + MJX_DEPTH, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(L.A[sn]));
+        if(i + MJX_DEPTH < noct) cp[MJX_DEPTH] = (LEAN ? dma_octet_lean<I16> : dma_octet<I16>)(job, rc, i + MJX_DEPTH, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(L.A[sn]));
 
         if constexpr(I16) {
             const unsigned tw[4] = {ti4.x, ti4.y, ti4.z, ti4.w}, aw[4] = {ai4.x, ai4.y, ai4.z, ai4.w};
@@ -672,12 +673,23 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
             *reinterpret_cast<float4 *>(pA + lane * 8 + 4 - 4 * ph) = a_hi;
             wave_sync();
         }
-        octet_compute(cp[0], lane, b, r, qrow, c4, t_lo, t_hi, a_lo, a_hi, pA, L.Z);
+        octet_compute<!LEAN && MJX_SZ0_CACHE>(job, cp[0], lane, b, r, qrow, c4, t_lo, t_hi, a_lo, a_hi, pA, L.Z);
 
         static_for<MJX_DEPTH>([&](auto D) { cp[D] = cp[D + 1]; });
         sc = sc + 1 == MJX_DEPTH ? 0 : sc + 1;
         sa = sa == MJX_DEPTH ? 0 : sa + 1;
     }
+}
+
+template <bool I16>
+__global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void compose_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
+    compose_body<I16, false>(runs, nruns, qrq);
+}
+// (amdgpu_num_vgpr counts the architected half of the unified register file: 72 = 144 registers per lane)
+template <bool I16>
+__global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) __attribute__((amdgpu_num_vgpr(72))) void compose_lean_kernel(const Run *__restrict__ runs, int nruns,
+                                                                                                                                const void *__restrict__ qrq) {
+    compose_body<I16, true>(runs, nruns, qrq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -690,17 +702,21 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
 // non-temporal loads to registers, runs of a few octets; the arithmetic is the same device functions.
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
+// (the pointer is cast to the global address space: a pointer that was itself loaded from memory - a job's plane or tiles - is
+// generic to the compiler, and a generic load is a FLAT instruction, which counts on vmcnt AND lgkmcnt: every wait for a scalar
+// load or an LDS read would then wait for the whole stream as well)
 MJX_DEV uint4 global_load16_nt(const void *p) {
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    const u32x4 v = __builtin_nontemporal_load((g_cu32x4 *)(uintptr_t)p);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <bool I16>
-__global__ __launch_bounds__(256) void compose_light_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
+// DEPTH: octets a wave has in flight (registers).  2 for the launch that has the device to itself (8 waves per SIMD hide the
+// rest); the build that runs BESIDE the blend kernel (launch_compose_light(shared)) has one wave per SIMD to do it with - three
+// lean blend waves leave 80 of a SIMD's 512 registers - and so keeps more of its own in flight, over longer runs.
+template <bool I16, int DEPTH>
+MJX_DEV void compose_light_body(const Run *__restrict__ runs, int ridx, const void *__restrict__ qrq) {
     const int lane = threadIdx.x & 63;
     const int b = lane >> 3, r = lane & 7;
-    const int ridx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if(ridx >= nruns) return;
     const Run    run = runs[ridx];
     const int    noct = __builtin_amdgcn_readfirstlane(run.noctets);
     const bool   dc = __builtin_amdgcn_readfirstlane(run.kind) == kRunDcOnly;
@@ -717,15 +733,15 @@ __global__ __launch_bounds__(256) void compose_light_kernel(const Run *__restric
 
     // this lane's operands of one octet: the JCOEF row, and for DC-only runs the tile row and the block's weight
     struct Octet {
-        int16_t *cptr;
+        unsigned pblk;       // plane block of this lane's row (store_ptr)
         uint4    c4, t0, t1; // t0 (,t1): the tile row, 8 x int16 or 8 x float
         unsigned w;          // alpha[0][0]: float bits, or the int16 coefficient in the low half
     };
     auto fetch = [&](const int *g) {
         const int n = g[0];
         Octet     o;
-        o.cptr = job.coef + (size_t)plane_block_of(job, n) * 64 + r * 8;
-        o.c4 = global_load16_nt(o.cptr);
+        o.pblk = plane_block_of(job, n);
+        o.c4 = global_load16_nt(store_ptr(job, o.pblk, lane));
         o.t0 = o.t1 = make_uint4(0, 0, 0, 0);
         o.w = 0;
         if(dc) {
@@ -741,8 +757,9 @@ __global__ __launch_bounds__(256) void compose_light_kernel(const Run *__restric
         return o;
     };
     auto finish = [&](const Octet &o) {
+        int16_t *cptr = store_ptr(job, o.pblk, lane);
         if(!dc) {
-            octet_zero_alpha_rq(o.cptr, q4, rq, o.c4);
+            octet_zero_alpha_rq(cptr, q4, rq, o.c4);
             return;
         }
         float t[8];
@@ -757,7 +774,7 @@ __global__ __launch_bounds__(256) void compose_light_kernel(const Run *__restric
             t[0] = __uint_as_float(o.t0.x); t[1] = __uint_as_float(o.t0.y); t[2] = __uint_as_float(o.t0.z); t[3] = __uint_as_float(o.t0.w);
             t[4] = __uint_as_float(o.t1.x); t[5] = __uint_as_float(o.t1.y); t[6] = __uint_as_float(o.t1.z); t[7] = __uint_as_float(o.t1.w);
         }
-        octet_dc_only_rq(o.cptr, q4, rq, o.c4, t, __uint_as_float(o.w));
+        octet_dc_only_rq(cptr, q4, rq, o.c4, t, __uint_as_float(o.w));
     };
     // two octets in flight: the next octet's loads are issued before this one is finished and stored
     Octet cur = fetch(G);
@@ -770,6 +787,193 @@ __global__ __launch_bounds__(256) void compose_light_kernel(const Run *__restric
     }
 }
 
+// The same streams for a wave that has a SIMD's memory pipeline almost to itself: the kernel that runs BESIDE the blend kernel
+// (launch_compose_light(shared)).  Three lean blend waves leave 80 of a SIMD's 512 registers, i.e. one wave of this kernel per
+// SIMD, which has to keep the CU's share of the stream in flight alone: DEPTH octets of its own, over one run after the other
+// (few long-lived workgroups - a workgroup that ended would give its registers to the next workgroup in either queue, and the
+// blend kernel's do not fit).  What a wave with several octets in flight must not do is wait for the NEWEST of its loads: vector
+// loads return in order, so the wait drains everything older.  The table that names an octet's blocks is therefore read by
+// SCALAR loads (their own counter), one octet ahead of the vector loads that use it: 8 tile indices (and 8 weights) arrive in
+// SGPRs and every lane picks its block's.
+// one run of the stream kernel.  DC: a DC-only run (JCOEF row, tile row and the block's weight travel) or a zero-alpha run (the
+// JCOEF row alone: 5 registers per octet in flight, so many more of them)
+template <bool I16, bool DC, int DEPTH>
+MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
+    const int    b = lane >> 3, r = lane & 7;
+    const int    noct = __builtin_amdgcn_readfirstlane(run.noctets);
+    const DevJob job = run.job;
+    struct Tab { // one octet's table entry, wave-uniform
+        int      n[kWaveBlocks];
+        unsigned w[DC ? kWaveBlocks : 1];
+    };
+    struct Octet {
+        unsigned pblk;
+        uint4    c4;
+        uint4    t[DC ? (I16 ? 1 : 2) : 0]; // the tile row, 8 x int16 or 8 x float
+        unsigned w[DC ? 1 : 0];
+    };
+    constexpr int gstride = DC ? 2 * kWaveBlocks : kWaveBlocks;
+    const int    *T = run.gather + (size_t)__builtin_amdgcn_readfirstlane(run.first) * kWaveBlocks; // wave-uniform: scalar loads
+
+    // (read through the constant address space: the tables are never written while a launch that reads them is in flight, and
+    // a uniform load from that space is a scalar load - from plain global memory the compiler has to assume that the kernel's
+    // own stores may alias it and uses vector loads)
+    typedef const __attribute__((address_space(4))) int cint_t;
+    auto table = [&](int o) {
+        Tab     t;
+        cint_t *g = (cint_t *)(uintptr_t)(T + (size_t)o * gstride);
+        static_for<kWaveBlocks>([&](auto K) { t.n[K] = g[K]; });
+        if constexpr(DC) static_for<kWaveBlocks>([&](auto K) { t.w[K] = (unsigned)g[kWaveBlocks + K]; });
+        return t;
+    };
+    auto fetch = [&](const Tab &t) {
+        int n = t.n[0];
+        static_for<kWaveBlocks - 1>([&](auto K) { n = b == K + 1 ? t.n[K + 1] : n; });
+        // scalar base + 32-bit byte offset (launch_compose_light_pair is only used for planes and tile arrays below 4 GiB): a
+        // 64-bit address per load would cost two registers each, and this kernel has 80
+        Octet o;
+        o.pblk = plane_block_of(job, n);
+        o.c4 = global_load16_nt(reinterpret_cast<const char *>(job.coef) + (o.pblk * 128u + (unsigned)r * 16u));
+        if constexpr(DC) {
+            unsigned w = t.w[0];
+            static_for<kWaveBlocks - 1>([&](auto K) { w = b == K + 1 ? t.w[K + 1] : w; });
+            o.w[0] = w;
+            if constexpr(I16) {
+                o.t[0] = global_load16_nt(reinterpret_cast<const char *>(job.tile) + ((unsigned)n * 128u + (unsigned)r * 16u));
+            }
+            else {
+                o.t[0] = global_load16_nt(reinterpret_cast<const char *>(job.tile) + ((unsigned)n * 256u + (unsigned)r * 32u));
+                o.t[1] = global_load16_nt(reinterpret_cast<const char *>(job.tile) + ((unsigned)n * 256u + (unsigned)r * 32u + 16u));
+            }
+        }
+        return o;
+    };
+    auto finish = [&](const Octet &o) {
+        int16_t       *cptr = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(job.coef) + (o.pblk * 128u + (unsigned)r * 16u));
+        // this lane's quantisation row from the wave's LDS copy: 8 x u16 now, the 8 reciprocals when the tail needs them
+        const uint4    q4 = *reinterpret_cast<const uint4 *>(qrow);
+        const unsigned cd[4] = {pk_mul_lo_u16(o.c4.x, q4.x), pk_mul_lo_u16(o.c4.y, q4.y), pk_mul_lo_u16(o.c4.z, q4.z), pk_mul_lo_u16(o.c4.w, q4.w)};
+        if constexpr(!DC) {
+            const float y[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; // (octet_zero_alpha_rq)
+            octet_tail(cptr, qrow, cd, y);
+        }
+        else {
+            float t[8];
+            if constexpr(I16) {
+                const unsigned tw[4] = {o.t[0].x, o.t[0].y, o.t[0].z, o.t[0].w};
+                static_for<4>([&](auto P) {
+                    t[2 * P] = s16_lo_to_f32(tw[P]);
+                    t[2 * P + 1] = s16_hi_to_f32(tw[P]);
+                });
+            }
+            else {
+                t[0] = __uint_as_float(o.t[0].x); t[1] = __uint_as_float(o.t[0].y); t[2] = __uint_as_float(o.t[0].z); t[3] = __uint_as_float(o.t[0].w);
+                t[4] = __uint_as_float(o.t[1].x); t[5] = __uint_as_float(o.t[1].y); t[6] = __uint_as_float(o.t[1].z); t[7] = __uint_as_float(o.t[1].w);
+            }
+            float x[8], y[8]; // (octet_dc_only_rq)
+            static_for<4>([&](auto P) {
+                x[2 * P] = t[2 * P] - s16_lo_to_f32(cd[P]);
+                x[2 * P + 1] = t[2 * P + 1] - s16_hi_to_f32(cd[P]);
+            });
+            static_for<8>([&](auto U) { x[U] = x[U] + x[U]; });
+            static_for<8>([&](auto U) { y[U] = 0.0f; });
+            vstage_first(y, x, __uint_as_float(o.w[0]));
+            octet_tail(cptr, qrow, cd, y);
+        }
+    };
+
+    // slot d holds octets d, d + DEPTH, ...; `ahead` is the table entry of the octet that will be asked for next
+    Octet q[DEPTH];
+    Tab   ahead = table(0);
+    static_for<DEPTH>([&](auto D) {
+        const Tab now = ahead;
+        ahead = table(D + 1 < noct ? D + 1 : 0);
+        q[D] = fetch(now); // (slots beyond the run's end ask for its first octet again: same bytes, never finished)
+    });
+#pragma unroll 1
+    for(int i = 0; i < noct; i += DEPTH) {
+        static_for<DEPTH>([&](auto D) {
+            if(i + D < noct) { // wave-uniform
+                const Octet cur = q[D];
+                if(i + D + DEPTH < noct) {
+                    const Tab now = ahead;
+                    ahead = table(i + D + DEPTH + 1 < noct ? i + D + DEPTH + 1 : 0);
+                    q[D] = fetch(now);
+                }
+                finish(cur);
+                // (keeps the instruction scheduler from interleaving the arithmetic of consecutive octets, whose temporaries
+                // would otherwise all be live at once on top of the DEPTH octets in flight)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    }
+}
+
+// octets in flight per wave in the kernel that runs beside the blend kernel (80 registers: more does not fit) ...
+#ifndef MJX_STREAM_DEPTH_ZA
+#define MJX_STREAM_DEPTH_ZA 8
+#endif
+#ifndef MJX_STREAM_DEPTH_DC_I16
+#define MJX_STREAM_DEPTH_DC_I16 4
+#endif
+#ifndef MJX_STREAM_DEPTH_DC_F32
+#define MJX_STREAM_DEPTH_DC_F32 3
+#endif
+// ... and in the kernel that has the device to itself (8 waves per SIMD)
+#ifndef MJX_LIGHT_DEPTH_ZA
+#define MJX_LIGHT_DEPTH_ZA 4
+#endif
+#ifndef MJX_LIGHT_DEPTH_DC
+#define MJX_LIGHT_DEPTH_DC 2
+#endif
+template <bool I16, bool SHARED>
+MJX_DEV void compose_light_stream(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq, int ridx0, int stride) {
+    // the quantisation table of the wave's current rectangle, as the blend kernel stages it (row r: 8 x u16, 8 reciprocals)
+    __shared__ __attribute__((aligned(16))) float Q[4][kQuantTableBytes / 4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float    *mine = Q[wave];
+    int       have_q = -1;
+#pragma unroll 1
+    for(int ridx = ridx0; ridx < nruns; ridx += stride) {
+        const Run run = runs[ridx];
+        const int qidx = __builtin_amdgcn_readfirstlane(run.job.qidx);
+        if(qidx != have_q) { // consecutive runs mostly belong to one rectangle
+            if(lane < kQuantTableBytes / 16)
+                reinterpret_cast<uint4 *>(mine)[lane] = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(qrq) + (size_t)(unsigned)qidx * kQuantTableBytes)[lane];
+            wave_sync();
+            have_q = qidx;
+        }
+        const float *qrow = mine + (lane & 7) * kQuantRowDwords;
+        constexpr int kDepthDc = SHARED ? (I16 ? MJX_STREAM_DEPTH_DC_I16 : MJX_STREAM_DEPTH_DC_F32) : MJX_LIGHT_DEPTH_DC;
+        constexpr int kDepthZa = SHARED ? MJX_STREAM_DEPTH_ZA : MJX_LIGHT_DEPTH_ZA;
+        if(__builtin_amdgcn_readfirstlane(run.kind) == kRunDcOnly) light_stream_run<I16, true, kDepthDc>(run, qrow, lane);
+        else light_stream_run<I16, false, kDepthZa>(run, qrow, lane);
+    }
+}
+
+#ifdef MJX_LIGHT_VGPR_CAP
+#define MJX_LIGHT_ATTR __attribute__((amdgpu_num_vgpr(MJX_LIGHT_VGPR_CAP)))
+#else
+#define MJX_LIGHT_ATTR
+#endif
+template <bool I16>
+__global__ __launch_bounds__(256) MJX_LIGHT_ATTR void compose_light_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
+    const int ridx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef MJX_LIGHT_R03
+    if(ridx < nruns) compose_light_body<I16, 2>(runs, ridx, qrq);
+#else
+    compose_light_stream<I16, false>(runs, ridx < nruns ? ridx + 1 : 0, qrq, ridx, 1 << 30); // this wave's one run
+#endif
+}
+// (amdgpu_num_vgpr counts the architected half of the unified register file: 40 = 80 registers per lane; three octets of int16
+// tiles or two of float tiles in flight fit without spilling)
+template <bool I16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(40))) void compose_light_shared_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
+    // few long-lived workgroups (launch_compose_light_pair: one per CU): each wave takes every (4 x gridDim.x)-th run
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    compose_light_stream<I16, true>(runs, nruns, qrq, blockIdx.x * 4 + wave, gridDim.x * 4);
+}
+
 int launch_compose_light(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
     const int groups = (nruns + 3) / 4;
@@ -778,14 +982,32 @@ int launch_compose_light(const Run *runs, int nruns, const void *qrq, bool tiles
     return check_hip(hipGetLastError(), "compose_light_kernel launch", MJX_ERR_LAUNCH);
 }
 
+// The streams that need no blend, shared out between two launches: the first `nbeside` runs go to `beside`, one long-lived
+// workgroup per CU (what three lean blend waves per SIMD leave of the registers), which runs NEXT TO the blend kernel; the rest
+// to the ordinary lean kernel on `after`, the blend kernel's own stream, i.e. when the blend kernel has finished.
+int launch_compose_light_pair(const Run *runs, int nruns, int nbeside, const void *qrq, bool tiles_i16, hipStream_t beside, hipStream_t after) {
+    if(nruns <= 0) return MJX_OK;
+    nbeside = nbeside < 0 ? 0 : (nbeside > nruns ? nruns : nbeside);
+    if(nbeside > 0) {
+        int dev = 0, cus = 256;
+        if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        const unsigned g = (unsigned)((nbeside + 3) / 4 < cus ? (nbeside + 3) / 4 : cus);
+        if(tiles_i16) hipLaunchKernelGGL(compose_light_shared_kernel<true>, dim3(g), dim3(256), 0, beside, runs, nbeside, qrq);
+        else hipLaunchKernelGGL(compose_light_shared_kernel<false>, dim3(g), dim3(256), 0, beside, runs, nbeside, qrq);
+        if(int e = check_hip(hipGetLastError(), "compose_light_shared_kernel launch", MJX_ERR_LAUNCH)) return e;
+    }
+    return launch_compose_light(runs + nbeside, nruns - nbeside, qrq, tiles_i16, after);
+}
+
 int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s, bool shared) {
     if(nruns <= 0) return MJX_OK;
     const int groups = (nruns + MJX_GROUP_WAVES - 1) / MJX_GROUP_WAVES;
-    // experiment: extra (unused) dynamic LDS caps the workgroups per CU, i.e. leaves registers for another kernel's waves
-    static const unsigned pad = [] { const char *e = getenv("MJX_BLEND_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
-    const unsigned dyn = shared ? pad : 0u;
-    if(tiles_i16) hipLaunchKernelGGL(compose_kernel<true>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), dyn, s, runs, nruns, qrq);
-    else hipLaunchKernelGGL(compose_kernel<false>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), dyn, s, runs, nruns, qrq);
+    if(shared) { // the lean build (144 registers): leaves a wave of the stream kernel room on every SIMD
+        if(tiles_i16) hipLaunchKernelGGL(compose_lean_kernel<true>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
+        else hipLaunchKernelGGL(compose_lean_kernel<false>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
+    }
+    else if(tiles_i16) hipLaunchKernelGGL(compose_kernel<true>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
+    else hipLaunchKernelGGL(compose_kernel<false>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
     return check_hip(hipGetLastError(), "compose_kernel launch", MJX_ERR_LAUNCH);
 }
 

@@ -111,6 +111,9 @@ struct ArenaLease {
 int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s, bool shared = false);
 // runs of kind kRunZeroAlpha / kRunDcOnly only: the blocks that need no blend stream through a lean kernel of their own
 int launch_compose_light(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s);
+// the first nbeside runs on `beside`, by few long-lived workgroups that run next to the (lean) blend kernel; the rest on `after`,
+// the blend kernel's own stream, when it has finished
+int launch_compose_light_pair(const Run *runs, int nruns, int nbeside, const void *qrq, bool tiles_i16, hipStream_t beside, hipStream_t after);
 // pattern[first block of the job in the plan + n] = bit (8k + l) set when weight (k, l) of tile block n is not zero
 // ... and w00[same index] = its weight (0,0) as float bits
 int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, uint32_t *w00, bool tiles_i16, hipStream_t s);

@@ -133,6 +133,7 @@ struct mjx_compose_plan {
     // of the plan's, forked from and joined to the caller's stream by events
     hipStream_t side = nullptr;
     hipEvent_t  fork = nullptr, join = nullptr;
+    int         nbeside = 0; // leading light runs that go to the kernel running beside the blend kernel (0: the two kernels run one after the other)
 };
 
 struct mjx_dc_plan {
@@ -674,6 +675,41 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<u
     return err;
 }
 
+// How many of a plan's light runs (the blocks that need no blend, t.light) go to the stream kernel that runs BESIDE the blend
+// kernel; 0: the two kernels run one after the other.  The share is what that kernel gets through while the blend kernel runs:
+// both are priced per octet with figures measured on MI355X (profiles/r04/corun_*.txt: regimes A4 and A5, float and int16
+// tiles) - a blend octet about 0.45 ns plus 0.055 ns per term of its union while the stream kernel is beside it, an octet of
+// the stream kernel (one wave per SIMD, 2-8 octets in flight) 0.55 ns without its tile, 1.5 ns with a float tile, 1.15 ns with
+// an int16 tile.  What is wrong with the estimate costs the difference once: whichever kernel finishes first leaves the other
+// to finish alone.  MJX_SIDE_BY_SIDE=0 switches the mode off, MJX_LIGHT_SPLIT=f fixes the share (measurements).
+int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, int flags) {
+    if(t.runs.empty() || t.light.empty() || (flags & MJX_PLAN_SERIAL)) return 0;
+    static const bool off = [] { const char *e = getenv("MJX_SIDE_BY_SIDE"); return e != nullptr && e[0] == '0'; }();
+    if(off) return 0;
+    // the stream kernel addresses planes and tiles with 32-bit byte offsets
+    for(int i = 0; i < njobs; ++i) {
+        if(jobs[i].rows <= 0 || jobs[i].cols <= 0) continue;
+        if((int64_t)jobs[i].blocks_per_row * jobs[i].plane_rows * 128 >= (1ll << 32) || (int64_t)jobs[i].rows * jobs[i].cols * 256 >= (1ll << 32)) return 0;
+    }
+    int64_t blend_octets = 0, light_octets = 0;
+    for(const RunRef &r : t.runs) blend_octets += r.noctets;
+    for(const RunRef &r : t.light) light_octets += r.noctets;
+    // worth two more launches and two events per step only when both kernels fill the device for a while
+    if(!(flags & MJX_PLAN_SIDE_BY_SIDE) && (blend_octets < 8 * (int64_t)t.slots || light_octets < 8 * (int64_t)t.slots)) return 0;
+    const double terms = blend_octets > 0 ? (double)t.stats.union_terms / (double)blend_octets : 0.0;
+    const double blend_ns = (double)blend_octets * (0.45 + 0.055 * terms);
+    static const double fixed = [] { const char *e = getenv("MJX_LIGHT_SPLIT"); return e ? atof(e) : -1.0; }();
+    if(fixed >= 0.0) return (int)((double)t.light.size() * (fixed > 1.0 ? 1.0 : fixed));
+    double spent = 0.0;
+    int    n = 0;
+    for(const RunRef &r : t.light) {
+        spent += (double)r.noctets * (r.kind == kRunDcOnly ? (t.tiles_i16 ? 1.15 : 1.5) : 0.55);
+        if(spent > blend_ns) break;
+        ++n;
+    }
+    return n;
+}
+
 void fill_stats(mjx_plan_stats_t *out, const SchedStats &st, int64_t runs, int slots, int run_max, int run_min) {
     memset(out, 0, sizeof(*out));
     out->blocks = st.blocks;
@@ -696,7 +732,8 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
     *plan = nullptr;
     if(njobs < 0 || nq < 0) return MJX_ERR_BAD_ARG;
     if(njobs > 0 && (jobs == nullptr || qtables == nullptr || nq == 0)) return MJX_ERR_NULL_DATA;
-    if(flags & ~(MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_TILES_I16)) return MJX_ERR_BAD_ARG;
+    if(flags & ~(MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_TILES_I16 | MJX_PLAN_SERIAL | MJX_PLAN_SIDE_BY_SIDE)) return MJX_ERR_BAD_ARG;
+    if((flags & MJX_PLAN_SERIAL) && (flags & MJX_PLAN_SIDE_BY_SIDE)) return MJX_ERR_BAD_ARG;
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
 
     // one tile format per plan: the plan flag, or MJX_JOB_TILES_I16 on every job
@@ -762,8 +799,12 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
         expand_runs(t, t.light, runs.data() + t.runs.size(), p->d_gather, nullptr);
         if((err = check_hip(hipMalloc((void **)&p->d_runs, runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMemcpy(p->d_runs, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
-        if(p->nruns > 0 && p->nlight > 0) { // both kernels have work: they may run side by side (mjx_compose_run)
-            if((err = check_hip(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking), "hipStreamCreate(side)", MJX_ERR_LAUNCH))) break;
+        p->nbeside = side_by_side_share(t, jobs, njobs, flags);
+        if(p->nbeside > 0) { // the two kernels of a step run side by side (mjx_compose_run)
+            // lowest priority: where a workgroup of either kernel fits, the blend kernel's goes first (its waves are the long-lived ones)
+            int prio_low = 0, prio_high = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+            if((err = check_hip(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_low), "hipStreamCreate(side)", MJX_ERR_LAUNCH))) break;
             if((err = check_hip(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH))) break;
             if((err = check_hip(hipEventCreateWithFlags(&p->join, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH))) break;
         }
@@ -798,6 +839,7 @@ int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan) { return plan ? 
 int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out) {
     if(plan == nullptr || out == nullptr) return MJX_ERR_NULL_DATA;
     fill_stats(out, plan->stats, (int64_t)plan->nruns + plan->nlight, plan->slots, plan->run_max, plan->run_min);
+    out->runs_beside = plan->nbeside;
     return MJX_OK;
 }
 
@@ -805,13 +847,17 @@ int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
     // the blend first (the long-running waves), then the streams of the blocks that need none; the two kernels
     // touch disjoint blocks
-    static const int corun = [] { const char *e = getenv("MJX_CORUN"); return e ? atoi(e) : 0; }();
-    if(corun && plan->nruns > 0 && plan->nlight > 0 && plan->side != nullptr) {
+    if(plan->nbeside > 0) {
+        // Side by side: the blend kernel is bound by the vector ALU, the streams of the blocks that need no blend by the
+        // memory system, and one after the other each leaves the other's resource idle.  The lean build of the blend kernel (144
+        // registers) leaves every SIMD room for ONE wave of the stream kernel (80 registers): one long-lived workgroup of it per CU
+        // works through the first nbeside runs on the plan's side stream, forked from and joined to the caller's stream by events
+        // (legal inside a stream capture); what is left of the runs follows the blend kernel on the caller's stream.
         hipStream_t s = (hipStream_t)stream;
         MJX_HIP(hipEventRecord(plan->fork, s), MJX_ERR_LAUNCH);
         MJX_HIP(hipStreamWaitEvent(plan->side, plan->fork, 0), MJX_ERR_LAUNCH);
         int err = launch_compose(plan->d_runs, plan->nruns, plan->d_qrq, plan->tiles_i16, s, true);
-        if(err == MJX_OK) err = launch_compose_light(plan->d_runs + plan->nruns, plan->nlight, plan->d_qrq, plan->tiles_i16, plan->side);
+        if(err == MJX_OK) err = launch_compose_light_pair(plan->d_runs + plan->nruns, plan->nlight, plan->nbeside, plan->d_qrq, plan->tiles_i16, plan->side, s);
         MJX_HIP(hipEventRecord(plan->join, plan->side), MJX_ERR_LAUNCH);
         MJX_HIP(hipStreamWaitEvent(s, plan->join, 0), MJX_ERR_LAUNCH);
         return err;

@@ -355,10 +355,14 @@ def test_compose_step_time_does_not_depend_on_the_plane_contents(torch_mod):
         assert int(_rect_view(b, c).to(torch.int32).abs().max()) * int(b.quant[c].max()) < 2 ** 31
 
 
-def test_compose_inside_a_hip_graph(torch_mod):
-    """mjx_compose_run does no allocation / host sync: it can be captured and replayed"""
+@pytest.mark.parametrize("side_by_side", [False, True])
+def test_compose_inside_a_hip_graph(torch_mod, side_by_side):
+    """mjx_compose_run does no allocation / host sync: it can be captured and replayed - also when the step's two kernels run
+    side by side (regime A4: blocks of every kind), i.e. when the capture forks to the plan's side stream and joins again"""
     torch = torch_mod
-    a, b = _batch(2, 64).build_plan(), _batch(2, 64).build_plan()
+    regime = 4 if side_by_side else 2
+    a, b = _batch(regime, 64).build_plan(side_by_side=False), _batch(regime, 64).build_plan(side_by_side=side_by_side)
+    assert (b.plan_stats()["runs_beside"] > 0) == side_by_side
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         b.run()  # warm-up on the capture stream

@@ -340,7 +340,7 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
     density from 0 to 64 non-zero weights (signed zeros, denormals and NaN weights included), ragged
     sizes, several jobs per plan sharing quant tables: grouped plan == plain plan == oracle"""
     import torch
-    from libmodjpeg_amd._lib import MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, PlanStats, RectJob, check, lib
+    from libmodjpeg_amd._lib import MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_SERIAL, MJX_PLAN_SIDE_BY_SIDE, PlanStats, RectJob, check, lib
     rng = np.random.default_rng(seed)
     shapes = [(40, 50, 3, 5, 13, 21), (20, 25, 0, 0, 20, 25), (9, 33, 2, 30, 7, 3), (64, 16, 10, 4, 37, 9), (8, 8, 1, 1, 1, 1)]  # prow, bpr, row0, col0, rows, cols
     quants = np.stack([rng.integers(1, 256, 64), rng.integers(1, 65536, 64)]).astype(np.uint16)
@@ -366,7 +366,10 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
     results = []
     # the zero pattern the device scan must find: a weight counts when `w != 0` (convolve.c:32): -0.0 does not, denormals and NaN do
     terms = sum(int(np.count_nonzero(a != 0)) for _, _, a in host)
-    for flags in (MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, 0):
+    # (the last two: the blend kernel and the streams of the blocks that need no blend side by side - the lean build of the one, the
+    # long-lived stream kernel for the other, forked from and joined to the caller's stream - and strictly one after the other)
+    final = MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL
+    for flags in (final, MJX_PLAN_GROUP_BY_DENSITY, 0, final | MJX_PLAN_SIDE_BY_SIDE, final | MJX_PLAN_SERIAL):
         dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
         for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
             jobs[j] = RectJob(dev[j][0].data_ptr(), dev[j][1].data_ptr(), dev[j][2].data_ptr(), bpr, prow, row0, col0, rows, cols, j % 2)
@@ -381,6 +384,7 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
             assert st.union_terms >= (st.block_terms + 7) // 8
             assert (st.zero_alpha_octets > 0) == bool(flags & MJX_PLAN_ALPHA_IS_FINAL)
             assert (st.dc_only_octets > 0) == bool(flags & MJX_PLAN_ALPHA_IS_FINAL)
+        assert (st.runs_beside > 0) == bool(flags & MJX_PLAN_SIDE_BY_SIDE), "small plans run their kernels one after the other unless told otherwise"
         check(lib().mjx_compose_run(plan, None), "run")
         torch.cuda.synchronize()
         lib().mjx_compose_plan_destroy(plan)
@@ -391,6 +395,9 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
         assert np.array_equal(results[2][j].reshape(-1), want), ("plain plan", j)
         assert np.array_equal(results[1][j].reshape(-1), want), ("grouped plan", j)
         assert np.array_equal(results[0][j].reshape(-1), want), ("grouped plan, zero-alpha blocks without their tiles", j)
+        assert np.array_equal(results[3][j].reshape(-1), want), ("the two kernels side by side", j)
+        assert np.array_equal(results[4][j].reshape(-1), want), ("the two kernels one after the other", j)
+    assert lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 2, final | MJX_PLAN_SERIAL | MJX_PLAN_SIDE_BY_SIDE) == mj._lib.MJX_ERR_BAD_ARG
 
 
 @pytest.mark.parametrize("seed", [2027] + _EXTRA_SEEDS)
@@ -400,7 +407,7 @@ def test_int16_tile_plans_vs_oracle_on_full_range_values(mj, seed):
     tile = (float)coef and weight = (float)((double)(float)coef * K) equal the host's, so the planes
     equal the oracle's fed with the converted float tiles"""
     import torch
-    from libmodjpeg_amd._lib import MJX_JOB_TILES_I16, MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, RectJob, check, lib
+    from libmodjpeg_amd._lib import MJX_JOB_TILES_I16, MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_SIDE_BY_SIDE, RectJob, check, lib
     rng = np.random.default_rng(seed)
     c0, c1 = 0.3535534, 0.5
     kk = np.array([(c0 if j // 8 == 0 else c1) * (c0 if j % 8 == 0 else c1) / 1020.0 for j in range(64)], np.float64)
@@ -417,7 +424,7 @@ def test_int16_tile_plans_vs_oracle_on_full_range_values(mj, seed):
         alpha[dc] = 0
         alpha[dc, 0] = rng.choice(np.array([2040, 1, -1, 32767, -32768, 777], np.int16), int(dc.sum()))
         host.append((coef, np.ascontiguousarray(tile), np.ascontiguousarray(alpha)))
-    for flags in (0, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL):
+    for flags in (0, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_SIDE_BY_SIDE):
         dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
         for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
             jobs[j] = RectJob(dev[j][0].data_ptr(), dev[j][1].data_ptr(), dev[j][2].data_ptr(), bpr, prow, row0, col0, rows, cols, j % 2, MJX_JOB_TILES_I16)
