@@ -892,8 +892,8 @@ __attribute__((target("avx512f,avx512bw,avx512vbmi2,bmi,popcnt"))) static bool u
 }
 
 bool unstuff(const unsigned char *src, size_t n, unsigned char *dst, size_t *outlen, unsigned long long *segs, long long max_segs, long long *nsegs) {
-    static const bool avx2 = __builtin_cpu_supports("avx2") && getenv("MJX_UNSTUFF_SCALAR") == nullptr;
-    static const bool avx512 = avx2 && has_avx512_compress() && getenv("MJX_UNSTUFF_AVX2") == nullptr;
+    static const bool avx2 = __builtin_cpu_supports("avx2") && tuning_env("MJX_UNSTUFF_SCALAR") == nullptr;
+    static const bool avx512 = avx2 && has_avx512_compress() && tuning_env("MJX_UNSTUFF_AVX2") == nullptr;
     if(avx512) return unstuff_avx512(src, n, dst, outlen, segs, max_segs, nsegs);
     return avx2 ? unstuff_avx2(src, n, dst, outlen, segs, max_segs, nsegs) : unstuff_scalar(src, n, dst, outlen, segs, max_segs, nsegs);
 }
@@ -948,7 +948,7 @@ Combiner<Request, kMaxBatch> g_combiner;
 // (profiles/r01_final/batch_cli_decode_batches.log).
 int max_leaders() {
     static const int n = [] {
-        const char *e = getenv("MJX_DECODE_BATCHES");
+        const char *e = tuning_env("MJX_DECODE_BATCHES");
         const int   v = e ? atoi(e) : 1;
         return v < 1 ? 1 : (v > 8 ? 8 : v);
     }();
@@ -978,26 +978,24 @@ bool zero_planes(char *const *ptr, const size_t *len, int ncomp, hipStream_t s, 
     return hipGetLastError() == hipSuccess;
 }
 
-// Chunks of a batch up to which ALL synchronisation rounds run one wavefront per chunk (MJX_DECODE_WAVE_CHUNKS; 0: no round
-// ever does); above it the first rounds run one lane per chunk (lane_rounds_of_large_batches).  Measured GPU time of a
-// single read (profiles/r03/decode_wave_rounds.md), all lane / all wave / lane first:
-//   1080p quality 85 (4 000 chunks) 0.45-0.58 / 0.17-0.21 / -;  4K quality 95 (28 700) 0.75 / 0.65 / 0.51 (3 lane rounds);
-//   8K quality 85 (62 700) 0.77 / 1.12 / 0.66 (3), 0.65 (4).
-long long wave_chunk_limit() {
-    static const long long n = [] {
-        const char *e = getenv("MJX_DECODE_WAVE_CHUNKS");
-        return e ? atoll(e) : 16384ll;
+// How the synchronisation rounds of a batch are walked.  Measured GPU time of a single read (profiles/r03/decode_wave_rounds.md),
+// all lane / all wave / lane first: 1080p quality 85 (4 000 chunks) 0.45-0.58 / 0.17-0.21 / -;  4K quality 95 (28 700) 0.75 / 0.65 /
+// 0.51 (3 lane rounds);  8K quality 85 (62 700) 0.77 / 1.12 / 0.66 (3), 0.65 (4).  Hence: up to kWaveChunkLimit chunks in a batch every
+// round runs one wavefront per chunk; above it the first 3 rounds (4 above four times the limit) run one lane per chunk.
+// MJX_DECODE_ROUNDS overrides the choice (the one documented switch; the parity tests walk every form with it):
+//   "wave"    every round one wavefront per chunk        "lane"    every round one lane per chunk
+//   "lane:N"  N rounds one lane per chunk, then wavefronts
+constexpr long long kWaveChunkLimit = 16384;
+int lane_rounds_override() { // -1: none
+    static const int n = [] {
+        const char *e = getenv("MJX_DECODE_ROUNDS");
+        if(e == nullptr || e[0] == 0) return -1;
+        if(strcmp(e, "wave") == 0) return 0;
+        if(strcmp(e, "lane") == 0) return 1 << 20;
+        if(strncmp(e, "lane:", 5) == 0 && atoi(e + 5) >= 0) return atoi(e + 5);
+        return -1;
     }();
     return n;
-}
-
-// rounds a batch above that limit walks one lane per chunk before it goes over to one wavefront per chunk (MJX_DECODE_LANE_ROUNDS)
-int lane_rounds_of_large_batches(bool very_large) {
-    static const int n = [] {
-        const char *e = getenv("MJX_DECODE_LANE_ROUNDS");
-        return e ? atoi(e) : -1;
-    }();
-    return n >= 0 ? n : (very_large ? 4 : 3);
 }
 
 // the leader's part: one set of kernels over all images of the batch, on the leader's stream
@@ -1033,9 +1031,10 @@ void run_batch(Request *lead, Request **batch, int n) {
             all_chunks += batch[i]->job.nchunks;
             if(!batch[i]->job.S.wave_ok) wave_ok = false;
         }
-        const long long limit = wave_chunk_limit();
-        if(!wave_ok || limit == 0) lane_rounds = kMaxRounds + 1;
-        else if(all_chunks > limit) lane_rounds = lane_rounds_of_large_batches(all_chunks > 4 * limit);
+        const int forced = lane_rounds_override();
+        if(!wave_ok) lane_rounds = kMaxRounds + 1;
+        else if(forced >= 0) lane_rounds = forced > kMaxRounds ? kMaxRounds + 1 : forced;
+        else if(all_chunks > kWaveChunkLimit) lane_rounds = all_chunks > 4 * kWaveChunkLimit ? 4 : 3;
     }
     const int per = kSubChunks;
 
@@ -1060,7 +1059,7 @@ void run_batch(Request *lead, Request **batch, int n) {
             const size_t wl = (((size_t)kWaveSlots << kLutBits) + ((size_t)r->job.S.nsub << kSubBits)) * 4;
             if(wl > wave_lds) wave_lds = wl;
         }
-        static const bool debug = getenv("MJX_HUFFDEC_DEBUG") != nullptr;
+        static const bool debug = tuning_env("MJX_HUFFDEC_DEBUG") != nullptr;
         struct timespec   tqs, tq0, tq1, tq2;
         if(debug) {
             clock_gettime(CLOCK_MONOTONIC, &tqs);
@@ -1297,7 +1296,7 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
     // stream or on a batch leader's stream, which waits for the `staged` event recorded below.
     if(on_device && (err = arena->order_after(scan->stream)) != MJX_OK) return err;
 
-    static const bool debug = getenv("MJX_HUFFDEC_DEBUG") != nullptr;
+    static const bool debug = tuning_env("MJX_HUFFDEC_DEBUG") != nullptr;
     double            t_mark[6] = {0, 0, 0, 0, 0, 0};
     auto              mark = [&](int i) {
         if(!debug) return;

@@ -398,7 +398,7 @@ Combiner<Request, kMaxBatch> g_combiner;
 // batches that may be in flight at once (MJX_ENCODE_BATCHES)
 int max_leaders() {
     static const int n = [] {
-        const char *e = getenv("MJX_ENCODE_BATCHES");
+        const char *e = tuning_env("MJX_ENCODE_BATCHES");
         const int   v = e ? atoi(e) : 4;
         return v < 1 ? 1 : (v > 32 ? 32 : v);
     }();

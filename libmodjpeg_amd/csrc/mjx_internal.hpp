@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/mjx.h"
 
@@ -63,6 +64,17 @@ struct DevDcJob {
     int32_t  q0;
     float    rq0;
 };
+
+// Experiment and trace switches (run lengths, batches in flight, stage timings on stderr ...) exist only in the TEST build of the
+// library (libmjx_hip_faultinj.so: every source compiled with -DMJX_TEST_BUILD, __graft_entry__.build_hip); in the product build
+// tuning_env() is a constant nullptr, the tuned values are constants and the trace code is compiled out.  What the product reads
+// from the environment is documented in INTEGRATION.md: MJX_WAIT, MJX_ARENAS, MJX_SIDE_BY_SIDE, MJX_DECODE_ROUNDS,
+// MJX_COMPOSE_COPIES, MJX_EFFECT_COPIES.
+#ifdef MJX_TEST_BUILD
+inline const char *tuning_env(const char *name) { return getenv(name); }
+#else
+inline const char *tuning_env(const char *) { return nullptr; }
+#endif
 
 // host helpers (mjx_runtime.hip)
 int   check_hip(hipError_t e, const char *what, int err_code);

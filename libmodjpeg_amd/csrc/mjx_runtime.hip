@@ -446,7 +446,7 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
     };
     std::vector<Labelled> runs;
     static const int light_len = [] {
-        const char *e = getenv("MJX_LIGHT_RUN"); // experiments
+        const char *e = tuning_env("MJX_LIGHT_RUN"); // experiments
         const int   v = e ? atoi(e) : 4; // measured (scripts/r03_check6.sh): 2..8 octets within 2 %, 16 is 3-5 % slower
         return v < 1 ? 1 : (v > kMaxRunOctets ? kMaxRunOctets : v);
     }();
@@ -486,7 +486,7 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
     int64_t remaining = 0;
     for(const Labelled &l : runs) remaining += l.r.noctets;
     static const int tail_min = [] {
-        const char *e = getenv("MJX_TAIL_MIN"); // experiments; 0 = runs never shrink
+        const char *e = tuning_env("MJX_TAIL_MIN"); // experiments; 0 = runs never shrink
         const int   v = e ? atoi(e) : 4;
         return v < 0 ? 0 : v;
     }();
@@ -536,7 +536,7 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
     if(per_slot >= 8 && run_len < 8) run_len = 8;
     if(run_len < 2) run_len = 2;
     if(run_len > run_octets()) run_len = run_octets();
-    if(const char *e = getenv("MJX_RUN_OCTETS")) { // experiments only
+    if(const char *e = tuning_env("MJX_RUN_OCTETS")) { // experiments only
         const int v = atoi(e);
         if(v >= 1 && v <= run_octets()) run_len = v;
     }
@@ -681,7 +681,7 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<u
 // tiles) - a blend octet about 0.45 ns plus 0.055 ns per term of its union while the stream kernel is beside it, an octet of
 // the stream kernel (one wave per SIMD, 2-8 octets in flight) 0.55 ns without its tile, 1.5 ns with a float tile, 1.15 ns with
 // an int16 tile.  What is wrong with the estimate costs the difference once: whichever kernel finishes first leaves the other
-// to finish alone.  MJX_SIDE_BY_SIDE=0 switches the mode off, MJX_LIGHT_SPLIT=f fixes the share (measurements).
+// to finish alone.  MJX_SIDE_BY_SIDE=0 switches the mode off; the test build's MJX_LIGHT_SPLIT=f fixes the share (measurements).
 int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, int flags) {
     if(t.runs.empty() || t.light.empty() || (flags & MJX_PLAN_SERIAL)) return 0;
     static const bool off = [] { const char *e = getenv("MJX_SIDE_BY_SIDE"); return e != nullptr && e[0] == '0'; }();
@@ -698,7 +698,7 @@ int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, i
     if(!(flags & MJX_PLAN_SIDE_BY_SIDE) && (blend_octets < 8 * (int64_t)t.slots || light_octets < 8 * (int64_t)t.slots)) return 0;
     const double terms = blend_octets > 0 ? (double)t.stats.union_terms / (double)blend_octets : 0.0;
     const double blend_ns = (double)blend_octets * (0.45 + 0.055 * terms);
-    static const double fixed = [] { const char *e = getenv("MJX_LIGHT_SPLIT"); return e ? atof(e) : -1.0; }();
+    static const double fixed = [] { const char *e = tuning_env("MJX_LIGHT_SPLIT"); return e ? atof(e) : -1.0; }();
     if(fixed >= 0.0) return (int)((double)t.light.size() * (fixed > 1.0 ? 1.0 : fixed));
     double spent = 0.0;
     int    n = 0;
@@ -978,7 +978,7 @@ int Arena::prepare(size_t dev_bytes, size_t pin_bytes) {
         if(entry == nullptr) {
             if(int e = check_hip(hipEventCreateWithFlags(&entry, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH)) return e;
         }
-        static const bool arena_debug = getenv("MJX_ARENA_DEBUG") != nullptr;
+        static const bool arena_debug = tuning_env("MJX_ARENA_DEBUG") != nullptr;
         if(arena_debug && (dev_bytes > dev_cap || pin_bytes > pin_cap))
             fprintf(stderr, "mjx arena %p grows: device %zu -> %zu bytes, pinned %zu -> %zu bytes\n", (void *)this, dev_cap, dev_bytes, pin_cap, pin_bytes);
         if(dev_bytes > dev_cap) {

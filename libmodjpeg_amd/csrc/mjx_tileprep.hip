@@ -217,7 +217,7 @@ extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
 
     // MJX_TILEPREP_DEBUG=1: where the time goes (stderr)
-    static const bool dbg = getenv("MJX_TILEPREP_DEBUG") != nullptr;
+    static const bool dbg = tuning_env("MJX_TILEPREP_DEBUG") != nullptr;
     auto              now = [] {
         struct timespec t;
         clock_gettime(CLOCK_MONOTONIC, &t);

@@ -14,5 +14,5 @@ for size in "1920 1080" "3840 2160"; do
   done
 done
 BENCH_DUMP_INPUT=gpurun_out/in1080.jpg MJ_GPU_DECODE=0 $T/bench_dropin $H/libmodjpeg.so.1 1920 1080 16 16 1 > /dev/null
-MJX_HUFFDEC_DEBUG=1 $T/mjhost_probe decodecmp gpurun_out/in1080.jpg
+LD_PRELOAD=$PWD/libmodjpeg_amd/libmjx_hip_faultinj.so MJX_HUFFDEC_DEBUG=1 $T/mjhost_probe decodecmp gpurun_out/in1080.jpg
 $T/mjhost_probe decodefuzz gpurun_out/in1080.jpg 200 3

@@ -416,12 +416,12 @@ def test_gpu_entropy_decoder_matches_libjpeg(shim, tmp_path, sampling, case):
     assert res.returncode == 0 and res.stdout.strip() == "same gpu", (res.stdout, res.stderr[-500:])
 
 
-ROUND_MODES = {  # how the decoder's synchronisation rounds are walked (MJX_DECODE_WAVE_CHUNKS, MJX_DECODE_LANE_ROUNDS)
+ROUND_MODES = {  # how the decoder's synchronisation rounds are walked (MJX_DECODE_ROUNDS)
     "default": {},
-    "a-lane-per-chunk": {"MJX_DECODE_WAVE_CHUNKS": "0"},
-    "a-wavefront-per-chunk": {"MJX_DECODE_WAVE_CHUNKS": "1000000000"},
-    "one-lane-round-then-wavefronts": {"MJX_DECODE_WAVE_CHUNKS": "1", "MJX_DECODE_LANE_ROUNDS": "1"},
-    "four-lane-rounds-then-wavefronts": {"MJX_DECODE_WAVE_CHUNKS": "1", "MJX_DECODE_LANE_ROUNDS": "4"},
+    "a-lane-per-chunk": {"MJX_DECODE_ROUNDS": "lane"},
+    "a-wavefront-per-chunk": {"MJX_DECODE_ROUNDS": "wave"},
+    "one-lane-round-then-wavefronts": {"MJX_DECODE_ROUNDS": "lane:1"},
+    "four-lane-rounds-then-wavefronts": {"MJX_DECODE_ROUNDS": "lane:4"},
 }
 
 
