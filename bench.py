@@ -519,7 +519,7 @@ def bench_compose(args, rank, world):
             "parity": verdicts.pop() if len(verdicts) == 1 else "mixed: see per_rank",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "mjx::compose_kernel" if not plan_stats.get("zero_alpha_octets") and not plan_stats.get("dc_only_octets") else "one step = mjx::compose_kernel (or its lean build) + mjx::compose_light_kernel (+ mjx::compose_light_shared_kernel beside it)",
+                         "kernel": ("mjx::compose_lowl_kernel (the blend kernel's build for weights in columns 0..3: four workgroups per CU)" if plan_stats.get("runs_low_columns") == plan_stats.get("runs") else "mjx::compose_kernel") if not plan_stats.get("zero_alpha_octets") and not plan_stats.get("dc_only_octets") else "one step = mjx::compose_kernel (or its lean build) + mjx::compose_light_kernel (+ mjx::compose_light_shared_kernel beside it)",
                          "kernel_ms_mean": mean_kern_ms,
                          "kernel_ms_mean_is": "distance of two HIP events around the K timed launches on the launch stream / K",
                          "kernel_ms_pristine": pristine_ms, "kernel_ms_pristine_min": min(ms) if ms else None,

@@ -169,6 +169,8 @@ typedef struct mjx_plan_stats {
     int32_t resident_waves; /* wavefronts of the compose kernel the device holds at once: what runs are cut for */
     int32_t run_octets_max, run_octets_min;
     int32_t runs_beside; /* runs of blocks that need no blend that are streamed BESIDE the blend kernel (0: the kernels run one after the other) */
+    int64_t low_column_octets; /* blended octets none of whose weights lies in a column l >= 4 (smooth masks) ... */
+    int64_t runs_low_columns;  /* ... and the runs of them that go to the low-column build of the blend kernel (four workgroups per CU) */
 } mjx_plan_stats_t;
 int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out);
 void mjx_compose_plan_destroy(mjx_compose_plan_t *plan);

@@ -106,20 +106,23 @@ constexpr unsigned long long row_mask(int K) {
 // returns Y in row layout
 // ------------------------------------------------------------------------------------------
 // SZ0: keep M_SQRT2 * (double)z_l[0] of all eight l in registers (16 VGPRs) instead of recomputing it per term (cvt + mul)
-template <bool SZ0, class WRow>
-MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow)[8], WRow &&weight_row, float *imgZ, int b, int r) {
+// NL: columns l of weights the octet can have at all: 8, or 4 in the build for runs whose weights all lie in columns 0..3
+// (compose_lowl_kernel): half the z_l, i.e. 32 registers less.  ROT: the alpha rows of block b are stored rotated by 2b
+// (the landing layout of the full-width alpha pieces); the low-column build stores them in natural order.
+template <bool SZ0, int NL, bool ROT, class WRow>
+MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[NL], float (&yrow)[8], WRow &&weight_row, float *imgZ, int b, int r) {
     // which terms does this octet need?  bit (8b + rp) of m[l] <=> alpha_b[(rp - 2b) & 7][l] != 0
-    unsigned long long m[8];
-    static_for<8>([&](auto L) { m[L] = __ballot(al[L] != 0.0f); });
+    unsigned long long m[NL];
+    static_for<NL>([&](auto L) { m[L] = __ballot(al[L] != 0.0f); });
 
     // H stage in row layout, z_l moved to column layout through LDS, only for the columns l that
     // some block of the octet uses; z[l] of the others stays undefined and is never consumed (its
     // terms all have w == 0).  The round trips of consecutive l overlap: DS operations of one wave
     // execute in order, so the next put_row may be issued before this get_col has returned.
-    float        z[8][8];
+    float        z[NL][8];
     const double sx0 = kSqrt2 * (double)x[0];
-    double       sz0[SZ0 ? 8 : 1]; // M_SQRT2 * (double)z_l[0], used by the row v == k of every term (k >= 1, l)
-    static_for<8>([&](auto L) {
+    double       sz0[SZ0 ? NL : 1]; // M_SQRT2 * (double)z_l[0], used by the row v == k of every term (k >= 1, l)
+    static_for<NL>([&](auto L) {
         if(m[L] != 0ull) {
             float zr[8];
             hstage<L>(x, sx0, zr);
@@ -135,15 +138,15 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[8], float (&yrow
     // that are zero in every block of the octet are skipped as a whole (scalar test); inside a row
     // each term is guarded per block by `w != 0` (convolve.c:32) and the compiler's execz skip.
     unsigned long long any = 0ull;
-    static_for<8>([&](auto L) { any |= m[L]; });
+    static_for<NL>([&](auto L) { any |= m[L]; });
     float y[8];
     static_for<8>([&](auto V) { y[V] = 0.0f; });
     static_for<8>([&](auto K) {
-        constexpr unsigned long long kRowK = row_mask(K);
+        constexpr unsigned long long kRowK = ROT ? row_mask(K) : 0x0101010101010101ull << K;
         if((any & kRowK) != 0ull) {
-            float wk[8];
-            weight_row(K, wk); // alpha_b[K][0..7], broadcast inside the block
-            static_for<8>([&](auto L) {
+            float wk[NL];
+            weight_row(K, wk); // alpha_b[K][0..NL-1], broadcast inside the block
+            static_for<NL>([&](auto L) {
                 const float w = wk[L];
                 if(w != 0.0f) {
                     if constexpr(K == 0 && L == 0) {
@@ -316,7 +319,12 @@ MJX_DEV unsigned plane_block_of(const DevJob &job, int n) {
     return __umul24((unsigned)(job.row0 + trow), (unsigned)job.bpr) + (unsigned)(job.col0 + tcol);
 }
 
-template <bool I16>
+// LOWL (float tiles only): of every alpha row only the first 16 bytes (weights of columns 0..3) go to LDS, as ONE piece in natural
+// order: chunk 8b + k <- row k of block b.  The request still touches every 128-byte line of the eight alpha blocks (the HBM traffic is
+// the same); what shrinks is the LDS slot, 1 KiB instead of 2.
+MJX_DEV void dma_alpha_low(const DevJob &job, int n, int lane, unsigned dA) { dma16_so(job.alpha, (unsigned)n * 256u + (unsigned)(lane & 7) * 32u, dA); }
+
+template <bool I16, bool LOWL>
 MJX_DEV unsigned dma_octet_gather(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned a_in, unsigned dC, unsigned dT, unsigned dA) {
     const int      bq = lane >> 4;
     const int      n = G[o * kWaveBlocks + (lane >> 3)];
@@ -331,6 +339,10 @@ MJX_DEV unsigned dma_octet_gather(const DevJob &job, int o, int lane, const int 
     const int t_lo = G[o * kWaveBlocks + bq], t_hi = G[o * kWaveBlocks + 4 + bq];
     dma16_so(job.tile, (unsigned)t_lo * 256u + t_in, dT);
     dma16_so(job.tile, (unsigned)t_hi * 256u + t_in, dT + 1024);
+    if constexpr(LOWL) {
+        dma_alpha_low(job, n, lane, dA);
+        return cptr;
+    }
     dma16_so(job.alpha, (unsigned)t_lo * 256u + a_in, dA);
     dma16_so(job.alpha, (unsigned)t_hi * 256u + a_in, dA + 1024);
     return cptr;
@@ -338,7 +350,7 @@ MJX_DEV unsigned dma_octet_gather(const DevJob &job, int o, int lane, const int 
 
 // generic (slow) form: any octet, lanes past the end of the job clamp to its last block.
 // Issues the pieces and leaves `a` describing this octet.
-template <bool I16>
+template <bool I16, bool LOWL>
 MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
     const int last = job.nblocks - 1;
     int       nb = n0 + (lane >> 3);
@@ -360,7 +372,8 @@ MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
     chunk_in_block(lane, t_in, a_in);
     if(n0 + 7 <= last) {
         dma16x2(reinterpret_cast<const char *>(job.tile) + (size_t)n0 * 256, (unsigned)bq * 256u + t_in, dT);
-        dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, (unsigned)bq * 256u + a_in, dA);
+        if constexpr(LOWL) dma_alpha_low(job, nb, lane, dA);
+        else dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, (unsigned)bq * 256u + a_in, dA);
     }
     else {
         int n_lo = n0 + bq, n_hi = n0 + 4 + bq;
@@ -368,14 +381,19 @@ MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
         n_hi = n_hi < last ? n_hi : last;
         dma16(reinterpret_cast<const char *>(job.tile) + (size_t)n_lo * 256 + t_in, dT);
         dma16(reinterpret_cast<const char *>(job.tile) + (size_t)n_hi * 256 + t_in, dT + 1024);
-        dma16(reinterpret_cast<const char *>(job.alpha) + (size_t)n_lo * 256 + a_in, dA);
-        dma16(reinterpret_cast<const char *>(job.alpha) + (size_t)n_hi * 256 + a_in, dA + 1024);
+        if constexpr(LOWL) {
+            dma_alpha_low(job, nb, lane, dA);
+        }
+        else {
+            dma16(reinterpret_cast<const char *>(job.alpha) + (size_t)n_lo * 256 + a_in, dA);
+            dma16(reinterpret_cast<const char *>(job.alpha) + (size_t)n_hi * 256 + a_in, dA + 1024);
+        }
     }
     return cptr;
 }
 
 // fast form: the octet after the one described by `a`, which must be a full octet (no clamping)
-template <bool I16>
+template <bool I16, bool LOWL>
 MJX_DEV unsigned dma_octet_next(const DevJob &job, int n0, int lane, unsigned t_in, unsigned a_in, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
     a.tcol += kWaveBlocks;
     a.pblk += kWaveBlocks;
@@ -393,7 +411,8 @@ MJX_DEV unsigned dma_octet_next(const DevJob &job, int n0, int lane, unsigned t_
     }
     const unsigned bq256 = (unsigned)(lane >> 4) * 256u;
     dma16x2(reinterpret_cast<const char *>(job.tile) + (size_t)n0 * 256, bq256 + t_in, dT);
-    dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, bq256 + a_in, dA);
+    if constexpr(LOWL) dma16_so(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, (unsigned)(lane >> 3) * 256u + (unsigned)(lane & 7) * 32u, dA);
+    else dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, bq256 + a_in, dA);
     return cptr;
 }
 
@@ -406,12 +425,13 @@ struct RunCtx {
     unsigned   t_in, a_in;
 };
 // returns the plane block this lane's JCOEF row belongs to (where the octet is stored: store_ptr)
-template <bool I16>
+template <bool I16, bool LOWL = false>
 MJX_DEV unsigned dma_octet(const DevJob &job, const RunCtx &rc, int o, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
-    if(rc.gather) return dma_octet_gather<I16>(job, o, lane, rc.G, rc.t_in, rc.a_in, dC, dT, dA);
+    static_assert(!(I16 && LOWL), "the low-column build exists for float tiles");
+    if(rc.gather) return dma_octet_gather<I16, LOWL>(job, o, lane, rc.G, rc.t_in, rc.a_in, dC, dT, dA);
     const int n = rc.first + o * kWaveBlocks;
-    if(o != 0 && n + kWaveBlocks <= job.nblocks) return dma_octet_next<I16>(job, n, lane, rc.t_in, rc.a_in, a, dC, dT, dA);
-    return dma_octet_generic<I16>(job, n, lane, a, dC, dT, dA);
+    if(o != 0 && n + kWaveBlocks <= job.nblocks) return dma_octet_next<I16, LOWL>(job, n, lane, rc.t_in, rc.a_in, a, dC, dT, dA);
+    return dma_octet_generic<I16, LOWL>(job, n, lane, a, dC, dT, dA);
 }
 // the same for the lean build of the kernel, which does not keep the lane's two chunk offsets in registers
 template <bool I16>
@@ -458,14 +478,22 @@ MJX_DEV int cvt_i32_sat(float f) {
 }
 
 // wave-private LDS
-struct WaveLds {
-    float C[MJX_DEPTH][256];     // JCOEF of octet i in slot i mod DEPTH
-    float T[MJX_DEPTH][512];     // tile
-    float A[MJX_DEPTH + 1][512]; // alpha of octet i in slot i mod (DEPTH+1): live during the blend
-    float Z[kImageDwords];       // transposition image
-    float Q[256];                // quant row r at r * 12 dwords: 8 x u16 then 8 reciprocals (one LDS-DMA piece lands here: 1 KiB, 384 bytes used)
-    int   G[256];                // gather runs: tile block index of every block of the run (8 per octet; the piece lands as 1 KiB)
+// An LDS-DMA piece always lands as 1 KiB (16 bytes per lane), whatever part of it is wanted.  The two tables that are shorter are
+// therefore placed in front of storage that is written later: G (the run's gather table, at most kMaxRunOctets x 32 bytes) in
+// front of the JCOEF slot - the table piece is waited for before the first octet's pieces are issued - and Q (the quantisation rows,
+// 384 bytes) in front of the transposition image, which is first written after the first octet has landed.
+// LOWL: the build for runs whose weights all lie in columns 0..3: only the first 16 bytes of every alpha row travel into LDS.
+constexpr int kGatherInts = 192; // 24 octets x 8: kMaxRunOctets of the host's cut_runs
+template <bool LOWL> struct WaveLdsT {
+    int   G[kGatherInts];                      // gather runs: tile block index of every block of the run (8 per octet)
+    float C[MJX_DEPTH][256];                   // JCOEF of octet i in slot i mod DEPTH
+    float T[MJX_DEPTH][512];                   // tile
+    float A[MJX_DEPTH + 1][LOWL ? 256 : 512];  // alpha of octet i in slot i mod (DEPTH+1): live during the blend
+    float Q[kQuantTableBytes / 4];             // quant row r at r * 12 dwords: 8 x u16 then 8 reciprocals
+    float Z[kImageDwords];                     // transposition image
 };
+static_assert(sizeof(WaveLdsT<true>) * MJX_GROUP_WAVES <= 40 * 1024, "four workgroups of the low-column build per CU (160 KiB of LDS)");
+static_assert(offsetof(WaveLdsT<false>, C) - offsetof(WaveLdsT<false>, G) + sizeof(float) * 256 >= 1024 && sizeof(float) * (kQuantTableBytes / 4 + kImageDwords) >= 1024, "where the 1 KiB pieces of G and Q run over");
 
 // steps A and Q of compose.c:315-336 and the store, given the dequantised coefficients (packed pairs), Y in row
 // layout and the row's eight reciprocal quantisers
@@ -525,7 +553,7 @@ MJX_DEV void octet_dc_only_rq(int16_t *cptr, const uint4 q4, const float (&rq)[8
 }
 
 // one octet whose operands have landed in (pC, pT, pA): registers, blend, store to cptr
-template <bool SZ0>
+template <bool SZ0, bool LOWL>
 MJX_DEV void octet_compute(const DevJob &job, unsigned cblk, int lane, int b, int r, const float *qrow, const uint4 c4, const float4 t_lo, const float4 t_hi, const float4 a_lo,
                            const float4 a_hi, const float *pA, float *imgZ) {
     const uint4 q4 = *reinterpret_cast<const uint4 *>(qrow); // this lane's quant row, 8 x u16
@@ -545,13 +573,24 @@ MJX_DEV void octet_compute(const DevJob &job, unsigned cblk, int lane, int b, in
     (void)ph; (void)pA; (void)imgZ;
     static_for<8>([&](auto U) { y[U] = x[U] * al[U]; });
 #else
-    octet_blend<SZ0>(x, al, y,
-                [&](int K, float (&wk)[8]) {
-                    const float *wrow = pA + b * 64 + ((K + 2 * b) & 7) * 8;
-                    const float4 lo = *reinterpret_cast<const float4 *>(wrow + 4 * ph), hi = *reinterpret_cast<const float4 *>(wrow + 4 - 4 * ph);
-                    wk[0] = lo.x; wk[1] = lo.y; wk[2] = lo.z; wk[3] = lo.w; wk[4] = hi.x; wk[5] = hi.y; wk[6] = hi.z; wk[7] = hi.w;
-                },
-                imgZ, b, r); // compose.c:300-312
+    if constexpr(LOWL) { // weights in columns 0..3 only: the alpha image holds 16 bytes per row, block b row k at (8b + k) * 16
+        const float al4[4] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w};
+        octet_blend<SZ0, 4, false>(x, al4, y,
+                                   [&](int K, float (&wk)[4]) {
+                                       const float4 w4 = *reinterpret_cast<const float4 *>(pA + (b * 8 + K) * 4);
+                                       wk[0] = w4.x; wk[1] = w4.y; wk[2] = w4.z; wk[3] = w4.w;
+                                   },
+                                   imgZ, b, r);
+    }
+    else {
+        octet_blend<SZ0, 8, true>(x, al, y,
+                                  [&](int K, float (&wk)[8]) {
+                                      const float *wrow = pA + b * 64 + ((K + 2 * b) & 7) * 8;
+                                      const float4 lo = *reinterpret_cast<const float4 *>(wrow + 4 * ph), hi = *reinterpret_cast<const float4 *>(wrow + 4 - 4 * ph);
+                                      wk[0] = lo.x; wk[1] = lo.y; wk[2] = lo.z; wk[3] = lo.w; wk[4] = hi.x; wk[5] = hi.y; wk[6] = hi.z; wk[7] = hi.w;
+                                  },
+                                  imgZ, b, r); // compose.c:300-312
+    }
 #endif
 
     octet_tail(store_ptr(job, cblk, lane), qrow, cd, y);
@@ -569,8 +608,9 @@ MJX_DEV void octet_compute(const DevJob &job, unsigned cblk, int lane, int b, in
 // LEAN: the build that shares a CU with the waves of compose_light_kernel (launch_compose(shared)): at most 144 registers, so
 // that three of its waves leave 80 of a SIMD's 512 to a wave of the other kernel - M_SQRT2 * (double)z_l[0] is recomputed per
 // term (+2 of ~31 instructions per term k >= 1) and the lane's chunk offsets per octet (+8 instructions).
-template <bool I16, bool LEAN>
+template <bool I16, bool LEAN, bool LOWL = false>
 MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
+    using WaveLds = WaveLdsT<LOWL>;
     __shared__ __attribute__((aligned(16))) WaveLds lds[MJX_GROUP_WAVES];
 
     const int lane = threadIdx.x & 63;
@@ -614,11 +654,12 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
     unsigned  cp[MJX_DEPTH + 1]; // cp[d] = plane block of this lane's row of octet i + d (its store address: store_ptr)
     static_for<MJX_DEPTH>([&](auto D) {
         cp[D] = 0;
-        if(D < noct) cp[D] = (LEAN ? dma_octet_lean<I16> : dma_octet<I16>)(job, rc, D, lane, addr, lds_addr(L.C[D]), lds_addr(L.T[D]), lds_addr(L.A[D]));
+        if(D < noct) cp[D] = (LEAN ? dma_octet_lean<I16> : dma_octet<I16, LOWL>)(job, rc, D, lane, addr, lds_addr(L.C[D]), lds_addr(L.T[D]), lds_addr(L.A[D]));
     });
 
     const int     ph = (b >> 1) & 1;
-    constexpr int kPieces = I16 ? 3 : 5; // VMEM operations per octet before its store
+    static_assert(!(LOWL && (I16 || LEAN)), "the low-column build: float tiles, not lean");
+    constexpr int kPieces = I16 ? 3 : (LOWL ? 4 : 5); // VMEM operations per octet before its store
     // I16: this lane converts the alpha row stored at position r of its block = source row (r - 2b) & 7
     const int    k_src = (r - 2 * b) & 7;
     const double kc0 = 0.3535534, kc1 = 0.5; // the reference's literals (dropon.c:548-566)
@@ -641,10 +682,16 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
         else {
             t_lo = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4 * ph);
             t_hi = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4 - 4 * ph);
-            // the alpha row stored at row position r of this block = source row (r - 2b) & 7: only the
-            // skip ballots of octet_blend look at it (row_mask)
-            a_lo = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 * ph);
-            a_hi = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 - 4 * ph);
+            if constexpr(LOWL) { // this lane's own row, weights of columns 0..3 (natural order): the skip ballots look at it
+                a_lo = *reinterpret_cast<const float4 *>(pA + lane * 4);
+                a_hi = a_lo;
+            }
+            else {
+                // the alpha row stored at row position r of this block = source row (r - 2b) & 7: only the
+                // skip ballots of octet_blend look at it (row_mask)
+                a_lo = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 * ph);
+                a_hi = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 - 4 * ph);
+            }
         }
         // the JCOEF and tile slots are about to be overwritten by the DMA of octet i + DEPTH
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -652,7 +699,7 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
         int sn = sa + MJX_DEPTH; // alpha slot of octet i + DEPTH
         sn = sn > MJX_DEPTH ? sn - (MJX_DEPTH + 1) : sn;
         cp[MJX_DEPTH] = cp[0];
-        if(i + MJX_DEPTH < noct) cp[MJX_DEPTH] = (LEAN ? dma_octet_lean<I16> : dma_octet<I16>)(job, rc, i + MJX_DEPTH, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(L.A[sn]));
+        if(i + MJX_DEPTH < noct) cp[MJX_DEPTH] = (LEAN ? dma_octet_lean<I16> : dma_octet<I16, LOWL>)(job, rc, i + MJX_DEPTH, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(L.A[sn]));
 
         if constexpr(I16) {
             const unsigned tw[4] = {ti4.x, ti4.y, ti4.z, ti4.w}, aw[4] = {ai4.x, ai4.y, ai4.z, ai4.w};
@@ -673,7 +720,7 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
             *reinterpret_cast<float4 *>(pA + lane * 8 + 4 - 4 * ph) = a_hi;
             wave_sync();
         }
-        octet_compute<!LEAN && MJX_SZ0_CACHE>(job, cp[0], lane, b, r, qrow, c4, t_lo, t_hi, a_lo, a_hi, pA, L.Z);
+        octet_compute<!LEAN && !LOWL && MJX_SZ0_CACHE, LOWL>(job, cp[0], lane, b, r, qrow, c4, t_lo, t_hi, a_lo, a_hi, pA, L.Z);
 
         static_for<MJX_DEPTH>([&](auto D) { cp[D] = cp[D + 1]; });
         sc = sc + 1 == MJX_DEPTH ? 0 : sc + 1;
@@ -684,6 +731,13 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
 template <bool I16>
 __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void compose_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
     compose_body<I16, false>(runs, nruns, qrq);
+}
+// The build for runs whose weights all lie in columns 0..3 (smooth masks: regime A2 is all of this kind): four z_l instead of
+// eight and 1 KiB of alpha per octet in LDS instead of 2 bring the kernel under 128 registers and 40 KiB of LDS per workgroup, i.e.
+// FOUR workgroups per CU instead of three - a third more of the stream in flight, which is what bounds these runs
+// (profiles/r04/README.md: the VALU is 68 % busy at A2).
+__global__ __launch_bounds__(64 * MJX_GROUP_WAVES, 4) void compose_lowl_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
+    compose_body<false, false, true>(runs, nruns, qrq);
 }
 // (amdgpu_num_vgpr counts the architected half of the unified register file: 72 = 144 registers per lane)
 template <bool I16>
@@ -1009,6 +1063,13 @@ int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, 
     else if(tiles_i16) hipLaunchKernelGGL(compose_kernel<true>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
     else hipLaunchKernelGGL(compose_kernel<false>, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
     return check_hip(hipGetLastError(), "compose_kernel launch", MJX_ERR_LAUNCH);
+}
+
+int launch_compose_lowl(const Run *runs, int nruns, const void *qrq, hipStream_t s) {
+    if(nruns <= 0) return MJX_OK;
+    const int groups = (nruns + MJX_GROUP_WAVES - 1) / MJX_GROUP_WAVES;
+    hipLaunchKernelGGL(compose_lowl_kernel, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
+    return check_hip(hipGetLastError(), "compose_lowl_kernel launch", MJX_ERR_LAUNCH);
 }
 
 // wavefronts of compose_kernel resident on the current device at once: what the run table is cut for

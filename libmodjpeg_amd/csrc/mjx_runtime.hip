@@ -98,12 +98,15 @@ struct Segment {
     int32_t cls;     // cost class of its octets: 2 = several times the memory-bound octet, 1, 0 = memory-bound, -1 = zero alpha
     int32_t first;   // kRunConsecutive: first tile block; gather kinds: first octet in the gather table
     int32_t noctets;
+    int32_t low = 0; // every weight of every octet lies in columns 0..3: the octets may go to the low-column build of the blend kernel
 };
 
 struct SchedStats {
     int64_t blocks = 0, octets = 0, gather_octets = 0, zero_octets = 0, dc_octets = 0, block_terms = 0, union_terms = 0, union_consecutive = 0;
+    int64_t low_octets = 0; // blended octets whose weights all lie in columns 0..3
     void add(const SchedStats &o) {
         union_consecutive += o.union_consecutive;
+        low_octets += o.low_octets;
         blocks += o.blocks; octets += o.octets; gather_octets += o.gather_octets; zero_octets += o.zero_octets; dc_octets += o.dc_octets;
         block_terms += o.block_terms; union_terms += o.union_terms;
     }
@@ -120,8 +123,8 @@ struct mjx_tile_schedule {
 };
 
 struct mjx_compose_plan {
-    Run        *d_runs = nullptr;    // compose_kernel's runs, then compose_light_kernel's (zero-alpha, DC-only)
-    int         nruns = 0, nlight = 0;
+    Run        *d_runs = nullptr;    // compose_kernel's runs, then compose_lowl_kernel's, then compose_light_kernel's (zero-alpha, DC-only)
+    int         nruns = 0, nlowl = 0, nlight = 0;
     void       *d_qrq = nullptr;     // kQuantTableBytes per quantisation table
     int32_t    *d_gather = nullptr;  // plans grouped by pattern: the blocks of every gather octet
     int         njobs = 0;
@@ -243,6 +246,7 @@ struct Tables {
     int                  run_len = 0; // octets per run in the body of the launch
     int                  run_min = 0, run_max = 0;
     bool                 tiles_i16 = false;
+    std::vector<RunRef>  lowl;   // compose_lowl_kernel's: blended runs whose weights all lie in columns 0..3 (float tiles)
     SchedStats           stats;
 };
 
@@ -288,6 +292,7 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     int      nzero = 0, ndc = 0;
     float    cost_cons = 0.0f;
     int64_t  terms = 0, union_cons = 0;
+    uint64_t union_all = 0;
     for(int o = 0; o < noct_all; ++o) {
         uint64_t u = 0;
         for(int k = 0; k < kWaveBlocks && o * kWaveBlocks + k < nblocks; ++k) {
@@ -300,6 +305,7 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
         }
         cost_cons += octet_cost(u);
         union_cons += __builtin_popcountll(u);
+        union_all |= u;
     }
     st.block_terms += terms;
     st.union_consecutive += union_cons;
@@ -307,9 +313,11 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     // only weight is (0,0) with the head of their alpha block only
     const bool split_zero = skip_zero && nzero >= kWaveBlocks, split_dc = skip_zero && ndc >= kWaveBlocks;
     auto consecutive = [&]() {
-        segs.push_back(Segment{kRunConsecutive, cost_class(cost_cons / (float)noct_all), 0, noct_all});
+        const int low = (pattern_columns(union_all) & 0xF0u) == 0 ? 1 : 0;
+        segs.push_back(Segment{kRunConsecutive, cost_class(cost_cons / (float)noct_all), 0, noct_all, low});
         st.octets += noct_all;
         st.union_terms += union_cons;
+        st.low_octets += low ? noct_all : 0;
     };
     if(all_same && !(split_zero && pattern[0] == 0) && !(split_dc && pattern[0] == 1)) return consecutive();
 
@@ -377,11 +385,13 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     if(cost_sorted > 0.93f * cost_cons) return consecutive();
 
     int base = (int)(gather.size() / kWaveBlocks);
-    for(int o = 0; o < noct_sorted;) { // stretches of octets of one cost class
+    for(int o = 0; o < noct_sorted;) { // stretches of octets of one cost class (and all with, or not all with, their weights in columns 0..3)
         const int cls = cost_class(octet_cost(unions[(size_t)o]));
+        const int low = (pattern_columns(unions[(size_t)o]) & 0xF0u) == 0 ? 1 : 0;
         int       e = o;
-        while(e < noct_sorted && cost_class(octet_cost(unions[(size_t)e])) == cls) ++e;
-        segs.push_back(Segment{kRunGather, cls, base + o, e - o});
+        while(e < noct_sorted && cost_class(octet_cost(unions[(size_t)e])) == cls && ((pattern_columns(unions[(size_t)e]) & 0xF0u) == 0 ? 1 : 0) == low) ++e;
+        segs.push_back(Segment{kRunGather, cls, base + o, e - o, low});
+        st.low_octets += low ? e - o : 0;
         o = e;
     }
     for(int o = 0; o < noct_sorted; ++o) {
@@ -442,8 +452,11 @@ constexpr int kMaxRunOctets = 24; // a gather table piece holds 32 octets; conse
 void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
     struct Labelled {
         RunRef  r;
-        int32_t cls;
+        int32_t cls, low;
     };
+    // the low-column build of the blend kernel exists for float tiles (test build: MJX_LOWL=0 sends everything to the general one)
+    static const bool lowl_off = [] { const char *e = tuning_env("MJX_LOWL"); return e != nullptr && e[0] == '0'; }();
+    const bool        use_low = !t.tiles_i16 && !lowl_off;
     std::vector<Labelled> runs;
     static const int light_len = [] {
         const char *e = tuning_env("MJX_LIGHT_RUN"); // experiments
@@ -455,7 +468,7 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
         // the stretch [i, e): same job, same kind, same table, each segment starting where the one before ends
         size_t e = i + 1;
         while(e < all.size() && all[e].job == all[i].job && all[e].sched == all[i].sched && all[e].seg.kind == all[i].seg.kind && all[i].seg.kind != kRunConsecutive &&
-              all[e].seg.first == all[e - 1].seg.first + all[e - 1].seg.noctets)
+              all[e].seg.first == all[e - 1].seg.first + all[e - 1].seg.noctets && (!use_low || all[e].seg.low == all[i].seg.low))
             ++e;
         int total = 0;
         for(size_t k = i; k < e; ++k) total += all[k].seg.noctets;
@@ -476,43 +489,49 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
             if(rest > 0 && rest * 2 < t.run_len && len + rest <= kMaxRunOctets) len += rest;
             while(f >= seg_end) seg_end += all[++seg].seg.noctets;
             const int first = kind == kRunConsecutive ? base + f * kWaveBlocks : base + f;
-            runs.push_back(Labelled{RunRef{all[i].job, first, len, kind, all[i].sched}, all[seg].seg.cls});
+            runs.push_back(Labelled{RunRef{all[i].job, first, len, kind, all[i].sched}, all[seg].seg.cls, use_low ? all[i].seg.low : 0});
             f += len;
         }
         i = e;
     }
     std::stable_sort(runs.begin(), runs.end(), [](const Labelled &a, const Labelled &b) { return a.cls > b.cls; });
 
-    int64_t remaining = 0;
-    for(const Labelled &l : runs) remaining += l.r.noctets;
     static const int tail_min = [] {
         const char *e = tuning_env("MJX_TAIL_MIN"); // experiments; 0 = runs never shrink
         const int   v = e ? atoi(e) : 4;
         return v < 0 ? 0 : v;
     }();
-    const bool one_round = remaining <= (int64_t)t.slots * 8; // every wave gets its share at once: nothing is replaced, nothing to balance
     t.runs.clear();
+    t.lowl.clear();
     t.run_min = 1 << 30;
     t.run_max = 0;
-    for(const Labelled &l : runs) {
-        for(int f = 0; f < l.r.noctets;) {
-            int len = l.r.noctets - f;
-            if(!one_round && tail_min > 0) {
-                int64_t guided = remaining / (2 * (int64_t)t.slots);
-                if(guided < tail_min) guided = tail_min;
-                if(guided < len && len - guided >= (guided + 1) / 2) len = (int)guided; // never leave a crumb behind
+    for(int low = 0; low < 2; ++low) { // the two launches of blended runs, each with its own tail
+        std::vector<RunRef> &out = low ? t.lowl : t.runs;
+        const int64_t        slots = low ? (int64_t)t.slots * 4 / 3 : (int64_t)t.slots; // (four workgroups of the low-column build per CU against three)
+        int64_t              remaining = 0;
+        for(const Labelled &l : runs) remaining += l.low == low ? l.r.noctets : 0;
+        const bool one_round = remaining <= slots * 8; // every wave gets its share at once: nothing is replaced, nothing to balance
+        for(const Labelled &l : runs) {
+            if(l.low != low) continue;
+            for(int f = 0; f < l.r.noctets;) {
+                int len = l.r.noctets - f;
+                if(!one_round && tail_min > 0) {
+                    int64_t guided = remaining / (2 * slots);
+                    if(guided < tail_min) guided = tail_min;
+                    if(guided < len && len - guided >= (guided + 1) / 2) len = (int)guided; // never leave a crumb behind
+                }
+                RunRef r = l.r;
+                r.first = l.r.kind == kRunConsecutive ? l.r.first + f * kWaveBlocks : l.r.first + f;
+                r.noctets = len;
+                out.push_back(r);
+                t.run_min = len < t.run_min ? len : t.run_min;
+                t.run_max = len > t.run_max ? len : t.run_max;
+                f += len;
+                remaining -= len;
             }
-            RunRef r = l.r;
-            r.first = l.r.kind == kRunConsecutive ? l.r.first + f * kWaveBlocks : l.r.first + f;
-            r.noctets = len;
-            t.runs.push_back(r);
-            t.run_min = len < t.run_min ? len : t.run_min;
-            t.run_max = len > t.run_max ? len : t.run_max;
-            f += len;
-            remaining -= len;
         }
     }
-    if(t.runs.empty()) t.run_min = 0;
+    if(t.runs.empty() && t.lowl.empty()) t.run_min = 0;
 }
 
 int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, bool tiles_i16, Tables &t) {
@@ -683,7 +702,7 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<u
 // an int16 tile.  What is wrong with the estimate costs the difference once: whichever kernel finishes first leaves the other
 // to finish alone.  MJX_SIDE_BY_SIDE=0 switches the mode off; the test build's MJX_LIGHT_SPLIT=f fixes the share (measurements).
 int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, int flags) {
-    if(t.runs.empty() || t.light.empty() || (flags & MJX_PLAN_SERIAL)) return 0;
+    if((t.runs.empty() && t.lowl.empty()) || t.light.empty() || (flags & MJX_PLAN_SERIAL)) return 0;
     static const bool off = [] { const char *e = getenv("MJX_SIDE_BY_SIDE"); return e != nullptr && e[0] == '0'; }();
     if(off) return 0;
     // the stream kernel addresses planes and tiles with 32-bit byte offsets
@@ -693,6 +712,7 @@ int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, i
     }
     int64_t blend_octets = 0, light_octets = 0;
     for(const RunRef &r : t.runs) blend_octets += r.noctets;
+    for(const RunRef &r : t.lowl) blend_octets += r.noctets;
     for(const RunRef &r : t.light) light_octets += r.noctets;
     // worth two more launches and two events per step only when both kernels fill the device for a while
     if(!(flags & MJX_PLAN_SIDE_BY_SIDE) && (blend_octets < 8 * (int64_t)t.slots || light_octets < 8 * (int64_t)t.slots)) return 0;
@@ -724,6 +744,7 @@ void fill_stats(mjx_plan_stats_t *out, const SchedStats &st, int64_t runs, int s
     out->resident_waves = slots;
     out->run_octets_max = run_max;
     out->run_octets_min = run_min;
+    out->low_column_octets = st.low_octets;
 }
 } // namespace
 
@@ -782,7 +803,15 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
         else {
             plain_runs(t);
         }
+        // side by side, the lean build of the blend kernel takes every blended run (the low-column build would fill the registers
+        // the stream kernel needs)
+        p->nbeside = side_by_side_share(t, jobs, njobs, flags);
+        if(p->nbeside > 0) {
+            t.runs.insert(t.runs.end(), t.lowl.begin(), t.lowl.end());
+            t.lowl.clear();
+        }
         p->nruns = (int)t.runs.size();
+        p->nlowl = (int)t.lowl.size();
         p->nlight = (int)t.light.size();
         p->stats = t.stats;
         p->slots = t.slots;
@@ -794,12 +823,12 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
             if((err = check_hip(hipMalloc((void **)&p->d_gather, t.gather.size() * sizeof(int32_t)), "hipMalloc(gather)", MJX_ERR_MEMORY))) break;
             if((err = check_hip(hipMemcpy(p->d_gather, t.gather.data(), t.gather.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(gather)", MJX_ERR_LAUNCH))) break;
         }
-        std::vector<Run> runs(t.runs.size() + t.light.size());
+        std::vector<Run> runs(t.runs.size() + t.lowl.size() + t.light.size());
         expand_runs(t, t.runs, runs.data(), p->d_gather, nullptr);
-        expand_runs(t, t.light, runs.data() + t.runs.size(), p->d_gather, nullptr);
+        expand_runs(t, t.lowl, runs.data() + t.runs.size(), p->d_gather, nullptr);
+        expand_runs(t, t.light, runs.data() + t.runs.size() + t.lowl.size(), p->d_gather, nullptr);
         if((err = check_hip(hipMalloc((void **)&p->d_runs, runs.size() * sizeof(Run)), "hipMalloc(runs)", MJX_ERR_MEMORY))) break;
         if((err = check_hip(hipMemcpy(p->d_runs, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(runs)", MJX_ERR_LAUNCH))) break;
-        p->nbeside = side_by_side_share(t, jobs, njobs, flags);
         if(p->nbeside > 0) { // the two kernels of a step run side by side (mjx_compose_run)
             // lowest priority: where a workgroup of either kernel fits, the blend kernel's goes first (its waves are the long-lived ones)
             int prio_low = 0, prio_high = 0;
@@ -838,8 +867,9 @@ int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan) { return plan ? 
 
 int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out) {
     if(plan == nullptr || out == nullptr) return MJX_ERR_NULL_DATA;
-    fill_stats(out, plan->stats, (int64_t)plan->nruns + plan->nlight, plan->slots, plan->run_max, plan->run_min);
+    fill_stats(out, plan->stats, (int64_t)plan->nruns + plan->nlowl + plan->nlight, plan->slots, plan->run_max, plan->run_min);
     out->runs_beside = plan->nbeside;
+    out->runs_low_columns = plan->nlowl;
     return MJX_OK;
 }
 
@@ -857,13 +887,14 @@ int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
         MJX_HIP(hipEventRecord(plan->fork, s), MJX_ERR_LAUNCH);
         MJX_HIP(hipStreamWaitEvent(plan->side, plan->fork, 0), MJX_ERR_LAUNCH);
         int err = launch_compose(plan->d_runs, plan->nruns, plan->d_qrq, plan->tiles_i16, s, true);
-        if(err == MJX_OK) err = launch_compose_light_pair(plan->d_runs + plan->nruns, plan->nlight, plan->nbeside, plan->d_qrq, plan->tiles_i16, plan->side, s);
+        if(err == MJX_OK) err = launch_compose_light_pair(plan->d_runs + plan->nruns + plan->nlowl, plan->nlight, plan->nbeside, plan->d_qrq, plan->tiles_i16, plan->side, s);
         MJX_HIP(hipEventRecord(plan->join, plan->side), MJX_ERR_LAUNCH);
         MJX_HIP(hipStreamWaitEvent(s, plan->join, 0), MJX_ERR_LAUNCH);
         return err;
     }
     int err = launch_compose(plan->d_runs, plan->nruns, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
-    if(err == MJX_OK) err = launch_compose_light(plan->d_runs + plan->nruns, plan->nlight, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
+    if(err == MJX_OK) err = launch_compose_lowl(plan->d_runs + plan->nruns, plan->nlowl, plan->d_qrq, (hipStream_t)stream);
+    if(err == MJX_OK) err = launch_compose_light(plan->d_runs + plan->nruns + plan->nlowl, plan->nlight, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
     return err;
 }
 
@@ -1269,6 +1300,9 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
             }
         }
         cut_runs(t, all);
+        // (per-image launches are a fraction of one round of waves: everything blended goes through the general build)
+        t.runs.insert(t.runs.end(), t.lowl.begin(), t.lowl.end());
+        t.lowl.clear();
     }
 
     // descriptor packet in pinned memory: [Run[] | quantisation tables], one copy
