@@ -87,15 +87,25 @@ def test_batch_cli_shards_its_workers_over_two_devices(stubbed, tmp_path):
     assert set(per_dev) == {"0", "1"} and max(per_dev.values()) <= 4, per_dev  # 8 workers: t mod 2
     composes = [kv for what, kv in rows if what == "compose"]
     assert len(composes) == 32 * 3
-    # one overlay, one target format, two devices: its tiles are prepared once per device (or once more when
-    # two workers of a device miss at the same moment) and scheduled when they are used the second time.  How many
-    # composes run before their schedule is there depends on how the eight workers interleave (a worker's second image
-    # can arrive while another worker is still making the schedule), so only what every interleaving guarantees is
-    # asserted: the first use is never scheduled, most uses are, every device makes its own schedules, one per component at least
-    with_sched = sum(kv["schedule"] == "1" for kv in composes)
-    assert 32 * 3 // 2 <= with_sched < 32 * 3, with_sched
+    # One overlay, one target format, two devices.  Only what holds for EVERY interleaving of the eight workers is asserted
+    # (a lower bound on the scheduled composes is a matter of timing - a worker's next image can arrive while another
+    # worker is still making the schedule):
+    #  - an entry's tiles are scheduled when they are used the second time, so on each device the first use of every component
+    #    has no schedule;
+    #  - exactly one caller makes an entry's schedules (sched_state 0 -> 1 under the lock), one per component; a device has one
+    #    entry for this overlay, or one more per worker that missed at the same moment as another (4 workers per device): a
+    #    schedule that was rebuilt on every use would show as dozens of rows here;
+    #  - each device has at least 16 uses of the entry, so the second use happens and the schedules ARE made, and whatever is
+    #    composed after they are published uses them: at least the very last compose of the run does.
+    first_seen = set()
+    for kv in composes:
+        key = (kv["device"], kv["rect"])
+        if key not in first_seen:
+            first_seen.add(key)
+            assert kv["schedule"] == "0", ("the first use of an entry is never scheduled", kv)
     scheds = collections.Counter(kv["device"] for what, kv in rows if what == "schedule")
-    assert set(scheds) == {"0", "1"} and all(3 <= n <= 4 * 3 * 2 for n in scheds.values()), scheds
+    assert set(scheds) == {"0", "1"} and all(3 <= n <= 4 * 3 for n in scheds.values()), scheds
+    assert sum(kv["schedule"] == "1" for kv in composes) >= 1
     # the same command on ONE device must write the same files (nothing depends on the sharding)
     out1 = tmp_path / "out1"
     out1.mkdir()
