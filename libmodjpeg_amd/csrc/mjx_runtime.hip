@@ -806,7 +806,14 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
         // side by side, the lean build of the blend kernel takes every blended run (the low-column build would fill the registers
         // the stream kernel needs)
         p->nbeside = side_by_side_share(t, jobs, njobs, flags);
-        if(p->nbeside > 0) {
+        // The low-column build (four workgroups per CU) is worth 3-11 % on launches of a few rounds of waves - one 4K image, the
+        // 512-image shard of the 8-GPU split - where ramp and tail count, nothing on the 4096-image batch and -1..-4 % on launches
+        // of a hundred rounds (256 x 4K: profiles/r04/lowl_kernel_4k_workloads.txt): above a million octets the general build
+        // takes these runs.
+        int64_t low_octets = 0;
+        for(const RunRef &r : t.lowl) low_octets += r.noctets;
+        constexpr int64_t kLowlMaxOctets = 1 << 20;
+        if(p->nbeside > 0 || low_octets > kLowlMaxOctets) {
             t.runs.insert(t.runs.end(), t.lowl.begin(), t.lowl.end());
             t.lowl.clear();
         }
