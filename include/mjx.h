@@ -141,7 +141,9 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
  * Blocks whose ONLY weight is (0,0) - every block an opaque or evenly translucent part of an overlay
  * covers - travel without their alpha block (the schedule reads the weight once and keeps it in the run table),
  * and their one term runs without the two transpositions the general product needs.  Both kinds are streamed
- * by a lean kernel of their own (8 waves per SIMD, short runs) next to the blend kernel.
+ * by a lean kernel of their own (8 waves per SIMD, short runs) next to the blend kernel.  Runs of blocks none of whose weights
+ * lies in a column l >= 4 (smooth masks) may go to a build of the blend kernel that keeps four z_l and the first 16 bytes of
+ * every alpha row only (four workgroups per CU): also under this promise only.
  * MJX_PLAN_TILES_I16: every job's tiles are int16 coefficients (the same as MJX_JOB_TILES_I16 on every job). */
 #define MJX_PLAN_GROUP_BY_DENSITY 1
 #define MJX_PLAN_ALPHA_IS_FINAL   2
@@ -151,7 +153,8 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
  * BY SIDE - a lean build of the blend kernel, a long-lived stream kernel in the registers it leaves on every CU, forked from
  * and joined to the caller's stream by events inside mjx_compose_run (legal in a stream capture) - and a small one runs them
  * one after the other.  MJX_PLAN_SERIAL: always one after the other; MJX_PLAN_SIDE_BY_SIDE: side by side whatever the size
- * (tests).  Purely a schedule: the results are identical. */
+ * (tests; plans with a plane or a tile array of 4 GiB or more always run them one after the other).  Purely a schedule: the
+ * results are identical. */
 #define MJX_PLAN_SERIAL           8
 #define MJX_PLAN_SIDE_BY_SIDE     16
 int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs,

@@ -313,7 +313,9 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     // only weight is (0,0) with the head of their alpha block only
     const bool split_zero = skip_zero && nzero >= kWaveBlocks, split_dc = skip_zero && ndc >= kWaveBlocks;
     auto consecutive = [&]() {
-        const int low = (pattern_columns(union_all) & 0xF0u) == 0 ? 1 : 0;
+        // (like the zero-alpha and DC-only kinds, the low-column build relies on the alpha tiles keeping the zeros they have now:
+        // only with the caller's promise, MJX_PLAN_ALPHA_IS_FINAL / a tile schedule)
+        const int low = skip_zero && (pattern_columns(union_all) & 0xF0u) == 0 ? 1 : 0;
         segs.push_back(Segment{kRunConsecutive, cost_class(cost_cons / (float)noct_all), 0, noct_all, low});
         st.octets += noct_all;
         st.union_terms += union_cons;
@@ -387,9 +389,10 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     int base = (int)(gather.size() / kWaveBlocks);
     for(int o = 0; o < noct_sorted;) { // stretches of octets of one cost class (and all with, or not all with, their weights in columns 0..3)
         const int cls = cost_class(octet_cost(unions[(size_t)o]));
-        const int low = (pattern_columns(unions[(size_t)o]) & 0xF0u) == 0 ? 1 : 0;
+        auto      is_low = [&](int q) { return skip_zero && (pattern_columns(unions[(size_t)q]) & 0xF0u) == 0 ? 1 : 0; };
+        const int low = is_low(o);
         int       e = o;
-        while(e < noct_sorted && cost_class(octet_cost(unions[(size_t)e])) == cls && ((pattern_columns(unions[(size_t)e]) & 0xF0u) == 0 ? 1 : 0) == low) ++e;
+        while(e < noct_sorted && cost_class(octet_cost(unions[(size_t)e])) == cls && is_low(e) == low) ++e;
         segs.push_back(Segment{kRunGather, cls, base + o, e - o, low});
         st.low_octets += low ? e - o : 0;
         o = e;

@@ -602,3 +602,40 @@ def test_host_paths_in_place_and_staged_give_the_same_bytes(mj):
         assert last[:3] == ["host", "paths", "ok"] and last[3] == ("1" if copies else "-")
         digests.append(last[-1])
     assert digests[0] == digests[1]
+
+
+def test_grouped_plan_without_the_promise_follows_later_changes_of_alpha(mj):
+    """MJX_PLAN_GROUP_BY_DENSITY alone is "purely a schedule: the results are identical, whatever alpha holds later" (mjx.h): the
+    alpha tiles are scanned when the plan is made - here every weight lies in columns 0..3 and half of the blocks have none or
+    only (0,0) - then REPLACED by dense weights.  Nothing the scan saw may have been baked in: no low-column build of the
+    blend kernel, no zero-alpha or DC-only streams (those need MJX_PLAN_ALPHA_IS_FINAL)."""
+    import torch
+    from libmodjpeg_amd._lib import MJX_PLAN_GROUP_BY_DENSITY, PlanStats, RectJob, check, lib
+    rng = np.random.default_rng(77)
+    prow, bpr, row0, col0, rows, cols = 40, 64, 2, 7, 24, 40
+    n = rows * cols
+    q = rng.integers(1, 200, 64).astype(np.uint16)
+    coef = rng.integers(-1024, 1024, (prow, bpr, 64)).astype(np.int16)
+    tile = np.round(rng.standard_normal((n, 64)) * 200).astype(np.float32)
+    smooth = np.zeros((n, 8, 8), np.float32)
+    smooth[:, :, :4] = (rng.standard_normal((n, 8, 4)) * 0.05).astype(np.float32)
+    kind = rng.integers(0, 3, n)
+    smooth[kind == 0] = 0
+    smooth[kind == 1] = 0
+    smooth[kind == 1, 0, 0] = 0.25
+    dense = (rng.standard_normal((n, 64)) * 0.05).astype(np.float32)
+    d_c, d_t, d_a = _t(coef), _t(tile), _t(smooth.reshape(n, 64))
+    jobs = (RectJob * 1)()
+    jobs[0] = RectJob(d_c.data_ptr(), d_t.data_ptr(), d_a.data_ptr(), bpr, prow, row0, col0, rows, cols, 0)
+    plan = ctypes.c_void_p()
+    check(lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, 1, q.ctypes.data_as(ctypes.c_void_p), 1, MJX_PLAN_GROUP_BY_DENSITY), "plan")
+    st = PlanStats()
+    check(lib().mjx_compose_plan_stats(plan, ctypes.byref(st)), "stats")
+    assert st.zero_alpha_octets == 0 and st.dc_only_octets == 0 and st.runs_low_columns == 0 and st.low_column_octets == 0
+    d_a.copy_(torch.from_numpy(dense))  # same stream as the run below
+    check(lib().mjx_compose_run(plan, None), "run")
+    torch.cuda.synchronize()
+    lib().mjx_compose_plan_destroy(plan)
+    want = coef.reshape(-1).copy()
+    O.compose_rect(want, bpr, row0, col0, rows, cols, q, tile.reshape(-1), dense.reshape(-1))
+    assert np.array_equal(d_c.cpu().numpy().reshape(-1), want)
