@@ -717,8 +717,10 @@ int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, i
     for(const RunRef &r : t.runs) blend_octets += r.noctets;
     for(const RunRef &r : t.lowl) blend_octets += r.noctets;
     for(const RunRef &r : t.light) light_octets += r.noctets;
-    // worth two more launches and two events per step only when both kernels fill the device for a while
-    if(!(flags & MJX_PLAN_SIDE_BY_SIDE) && (blend_octets < 8 * (int64_t)t.slots || light_octets < 8 * (int64_t)t.slots)) return 0;
+    // worth two more launches and two events per step only when both kernels fill the device for a while: measured
+    // (profiles/r04/side_by_side_small_launches.txt) the step gains from 256 images of regime A5 (2.6 blended octets per resident
+    // wave) and from 64 of A4 upwards and loses below 128 of A5 (1.3)
+    if(!(flags & MJX_PLAN_SIDE_BY_SIDE) && (blend_octets < 2 * (int64_t)t.slots || light_octets < 4 * (int64_t)t.slots)) return 0;
     const double terms = blend_octets > 0 ? (double)t.stats.union_terms / (double)blend_octets : 0.0;
     const double blend_ns = (double)blend_octets * (0.45 + 0.055 * terms);
     static const double fixed = [] { const char *e = tuning_env("MJX_LIGHT_SPLIT"); return e ? atof(e) : -1.0; }();
