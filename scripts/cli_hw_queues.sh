@@ -1,0 +1,12 @@
+cd /root/repo 2>/dev/null || cd $GRAFT_REPO_ROOT
+n=1024
+work=$(mktemp -d /tmp/mjq.XXXX); mkdir -p $work/in $work/out
+H=libmodjpeg_amd/host; T=tests/tools
+for i in $(seq 1 16); do BENCH_DUMP_INPUT=$work/in/img$i.jpg MJ_GPU_DECODE=0 MJ_GPU_ENCODE=0 $T/bench_dropin $H/libmodjpeg.so.1 1920 1080 16 16 1 > /dev/null; done
+for i in $(seq 1 $n); do echo $work/in/img$(( (i % 16) + 1 )).jpg >> $work/list.txt; done
+cp tests/golden/images/dropon.png $work/logo.png
+for rep in 1 2; do for q in 2 4 8 16; do for jobs in 16 32; do
+  echo -n "hw_queues=$q jobs=$jobs : "
+  GPU_MAX_HW_QUEUES=$q $H/modjpeg --batch $work/list.txt --outdir $work/out --jobs $jobs -p br -m -10,-10 -d $work/logo.png -y 10 2>&1 | tail -1
+done; done; done
+rm -rf $work
