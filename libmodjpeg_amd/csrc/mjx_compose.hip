@@ -229,7 +229,9 @@ typedef __attribute__((address_space(3))) void       lvoid_t;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short          s16x2 __attribute__((ext_vector_type(2)));
 
-#if MJX_NT
+#ifdef MJX_LOAD_POLICY /* experiments: cache-policy bits of the LDS-DMA loads, e.g. -DMJX_LOAD_POLICY='" sc1 nt"' */
+#define MJX_NT_SFX MJX_LOAD_POLICY
+#elif MJX_NT
 #define MJX_NT_SFX " nt"
 #else
 #define MJX_NT_SFX ""
