@@ -68,7 +68,7 @@ typedef void *mjx_stream_t; /* a hipStream_t, or NULL for the default stream */
  *                  queued, when the call was made, on the caller's stream: the `stream` member of the call's
  *                  struct, or its `after` argument.  NULL is the legacy default stream (which in turn waits for
  *                  every blocking stream of the device); a struct that was zero-initialised therefore waits for
- *                  the default stream.  MJX_STREAM_IDLE says that nothing is pending on the memory handed over
+ *                  the default stream.  (A stream with nothing queued costs a query, no event.)  MJX_STREAM_IDLE says that nothing is pending on the memory handed over
  *                  (the caller has synchronised, or the library itself produced it in an earlier call of this
  *                  kind): no event, no wait.
  *        at exit   the call returns only after its own device work has completed, so whatever the caller
