@@ -180,7 +180,9 @@ void mjx_compose_plan_destroy(mjx_compose_plan_t *plan);
 /* total 8x8 blocks the plan composes per run */
 int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan);
 /* Enqueue one pass over all rectangles on `stream` (asynchronous; no host sync, no allocation:
- * safe inside hipGraph capture). */
+ * safe inside hipGraph capture).  Host threads may run one plan at the same time (a side-by-side plan serialises its fork and
+ * join internally; its side stream then runs the passes' stream kernels one after the other); the passes touch the same
+ * planes, so ordering them against each other stays the callers' business. */
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream);
 
 /* Per-image callers (the libmodjpeg.h shim) hold everything in HOST memory.  One call = one

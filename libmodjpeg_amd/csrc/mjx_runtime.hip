@@ -136,6 +136,7 @@ struct mjx_compose_plan {
     // of the plan's, forked from and joined to the caller's stream by events
     hipStream_t side = nullptr;
     hipEvent_t  fork = nullptr, join = nullptr;
+    mutable pthread_mutex_t side_lock = PTHREAD_MUTEX_INITIALIZER; // the five calls that fork and join are one unit: two host threads may run one plan
     int         nbeside = 0; // leading light runs that go to the kernel running beside the blend kernel (0: the two kernels run one after the other)
 };
 
@@ -895,7 +896,14 @@ int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
         // registers) leaves every SIMD room for ONE wave of the stream kernel (80 registers): one long-lived workgroup of it per CU
         // works through the first nbeside runs on the plan's side stream, forked from and joined to the caller's stream by events
         // (legal inside a stream capture); what is left of the runs follows the blend kernel on the caller's stream.
+        // The plan owns ONE side stream and ONE pair of events: a second host thread that runs the same plan (on another stream)
+        // must not record the fork event between this thread's record and its wait.
         hipStream_t s = (hipStream_t)stream;
+        struct Held {
+            pthread_mutex_t *m;
+            explicit Held(pthread_mutex_t *mm) : m(mm) { pthread_mutex_lock(m); }
+            ~Held() { pthread_mutex_unlock(m); }
+        } held(&plan->side_lock);
         MJX_HIP(hipEventRecord(plan->fork, s), MJX_ERR_LAUNCH);
         MJX_HIP(hipStreamWaitEvent(plan->side, plan->fork, 0), MJX_ERR_LAUNCH);
         int err = launch_compose(plan->d_runs, plan->nruns, plan->d_qrq, plan->tiles_i16, s, true);
