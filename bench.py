@@ -494,6 +494,13 @@ def bench_compose(args, rank, world):
         launch_bytes = max(min(launch_bytes, blocks_per_step * bytes_per_block), 0)
         achieved = launch_bytes / (mean_kern_ms * 1e-3) / 1e9
         achieved_nominal = blocks_per_step * bytes_per_block / (mean_kern_ms * 1e-3) / 1e9
+        # What the launch asks the memory system for.  Octets none of whose weights lies in a row or column >= 4 (smooth masks: all of
+        # regime A2) go to the low-column build of the blend kernel, which leaves the second 128-byte line of their alpha blocks - zeros,
+        # the schedule has seen them - where it is: eight first lines and one second line per octet instead of sixteen lines.
+        # `achieved` stays SURVEY 8d's algorithmic figure; `achieved_on_bytes_moved` says how hard the memory system works.
+        skipped = 8 * plan_stats.get("low_row_octets", 0) * 112 if plan_stats.get("runs_low_columns") and args.tiles != "i16" else 0
+        moved_bytes = launch_bytes - skipped
+        achieved_moved = moved_bytes / (mean_kern_ms * 1e-3) / 1e9
         # every rank's own launch against the peak of its own GPU: the figures above describe rank 0's shard
         rank_gbs = [r["blocks_per_step"] * (launch_bytes / blocks_per_step) / (r["kernel_ms_mean"] * 1e-3) / 1e9 for r in per_rank]
         key = f"{args.workload}:{args.regime}:"
@@ -519,13 +526,15 @@ def bench_compose(args, rank, world):
             "parity": verdicts.pop() if len(verdicts) == 1 else "mixed: see per_rank",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("mjx::compose_lowl_kernel (the blend kernel's build for weights in columns 0..3: four workgroups per CU)" if plan_stats.get("runs_low_columns") == plan_stats.get("runs") else "mjx::compose_kernel") if not plan_stats.get("zero_alpha_octets") and not plan_stats.get("dc_only_octets") else "one step = mjx::compose_kernel (or its lean build) + mjx::compose_light_kernel (+ mjx::compose_light_shared_kernel beside it)",
+                         "kernel": ("mjx::compose_lowl_kernel (the blend kernel's build for weights in columns 0..3: four workgroups per CU; weights in rows 0..3 as well: the second line of the alpha blocks is not fetched)" if plan_stats.get("runs_low_columns") == plan_stats.get("runs") else "mjx::compose_kernel") if not plan_stats.get("zero_alpha_octets") and not plan_stats.get("dc_only_octets") else "one step = mjx::compose_kernel (or its lean build) + mjx::compose_light_kernel (+ mjx::compose_light_shared_kernel beside it)",
                          "kernel_ms_mean": mean_kern_ms,
                          "kernel_ms_mean_is": "distance of two HIP events around the K timed launches on the launch stream / K",
                          "kernel_ms_pristine": pristine_ms, "kernel_ms_pristine_min": min(ms) if ms else None,
                          "kernel_ms_pristine_median": sorted(ms)[len(ms) // 2] if ms else None,
                          "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_block": bytes_per_block,
                          "bytes_per_block_of_this_plan": launch_bytes / blocks_per_step,
+                         "bytes_moved_per_launch": moved_bytes, "bytes_moved_per_block": moved_bytes / blocks_per_step,
+                         "achieved_on_bytes_moved": achieved_moved, "frac_on_bytes_moved": achieved_moved / HBM_PEAK_GBS,
                          "achieved_at_nominal_bytes_per_block": achieved_nominal, "frac_at_nominal_bytes_per_block": achieved_nominal / HBM_PEAK_GBS,
                          "scope": "rank 0" if world > 1 else "the one rank", "rank": 0,
                          "achieved_min_over_ranks": min(rank_gbs), "achieved_max_over_ranks": max(rank_gbs),

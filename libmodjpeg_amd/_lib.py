@@ -53,7 +53,7 @@ class PlanStats(ctypes.Structure):
     _fields_ = [("blocks", ctypes.c_int64), ("octets", ctypes.c_int64), ("gather_octets", ctypes.c_int64), ("zero_alpha_octets", ctypes.c_int64),
                 ("runs", ctypes.c_int64), ("block_terms", ctypes.c_int64), ("union_terms", ctypes.c_int64), ("dc_only_octets", ctypes.c_int64), ("union_terms_consecutive", ctypes.c_int64),
                 ("resident_waves", ctypes.c_int32), ("run_octets_max", ctypes.c_int32), ("run_octets_min", ctypes.c_int32), ("runs_beside", ctypes.c_int32),
-                ("low_column_octets", ctypes.c_int64), ("runs_low_columns", ctypes.c_int64)]
+                ("low_column_octets", ctypes.c_int64), ("runs_low_columns", ctypes.c_int64), ("low_row_octets", ctypes.c_int64)]
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}

@@ -324,10 +324,17 @@ MJX_DEV unsigned plane_block_of(const DevJob &job, int n) {
 // LOWL (float tiles only): of every alpha row only the first 16 bytes (weights of columns 0..3) go to LDS, as ONE piece in natural
 // order: chunk 8b + k <- row k of block b.  The request still touches every 128-byte line of the eight alpha blocks (the HBM traffic is
 // the same); what shrinks is the LDS slot, 1 KiB instead of 2.
-MJX_DEV void dma_alpha_low(const DevJob &job, int n, int lane, unsigned dA) { dma16_so(job.alpha, (unsigned)n * 256u + (unsigned)(lane & 7) * 32u, dA); }
+// low_rows (a promise of the schedule's: no weight of the run lies in a row k >= 4 either): rows 4..7 of the eight blocks are not
+// fetched; their lanes all ask for the same 16 bytes, row 4 of the octet's first block (n_first) - zeros, like what they stand for
+// - so that per octet eight first lines and ONE second line travel instead of sixteen lines.
+MJX_DEV void dma_alpha_low(const DevJob &job, int n, int lane, unsigned dA, bool low_rows, int n_first) {
+    const unsigned k = (unsigned)(lane & 7);
+    const unsigned off = low_rows && k >= 4 ? (unsigned)n_first * 256u + 128u : (unsigned)n * 256u + k * 32u;
+    dma16_so(job.alpha, off, dA);
+}
 
 template <bool I16, bool LOWL>
-MJX_DEV unsigned dma_octet_gather(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned a_in, unsigned dC, unsigned dT, unsigned dA) {
+MJX_DEV unsigned dma_octet_gather(const DevJob &job, int o, int lane, const int *G, unsigned t_in, unsigned a_in, unsigned dC, unsigned dT, unsigned dA, bool low_rows) {
     const int      bq = lane >> 4;
     const int      n = G[o * kWaveBlocks + (lane >> 3)];
     const unsigned cptr = plane_block_of(job, n);
@@ -342,7 +349,7 @@ MJX_DEV unsigned dma_octet_gather(const DevJob &job, int o, int lane, const int 
     dma16_so(job.tile, (unsigned)t_lo * 256u + t_in, dT);
     dma16_so(job.tile, (unsigned)t_hi * 256u + t_in, dT + 1024);
     if constexpr(LOWL) {
-        dma_alpha_low(job, n, lane, dA);
+        dma_alpha_low(job, n, lane, dA, low_rows, G[o * kWaveBlocks]);
         return cptr;
     }
     dma16_so(job.alpha, (unsigned)t_lo * 256u + a_in, dA);
@@ -353,7 +360,7 @@ MJX_DEV unsigned dma_octet_gather(const DevJob &job, int o, int lane, const int 
 // generic (slow) form: any octet, lanes past the end of the job clamp to its last block.
 // Issues the pieces and leaves `a` describing this octet.
 template <bool I16, bool LOWL>
-MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
+MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA, bool low_rows) {
     const int last = job.nblocks - 1;
     int       nb = n0 + (lane >> 3);
     nb = nb < last ? nb : last;
@@ -374,7 +381,7 @@ MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
     chunk_in_block(lane, t_in, a_in);
     if(n0 + 7 <= last) {
         dma16x2(reinterpret_cast<const char *>(job.tile) + (size_t)n0 * 256, (unsigned)bq * 256u + t_in, dT);
-        if constexpr(LOWL) dma_alpha_low(job, nb, lane, dA);
+        if constexpr(LOWL) dma_alpha_low(job, nb, lane, dA, low_rows, n0 < last ? n0 : last);
         else dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, (unsigned)bq * 256u + a_in, dA);
     }
     else {
@@ -384,7 +391,7 @@ MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
         dma16(reinterpret_cast<const char *>(job.tile) + (size_t)n_lo * 256 + t_in, dT);
         dma16(reinterpret_cast<const char *>(job.tile) + (size_t)n_hi * 256 + t_in, dT + 1024);
         if constexpr(LOWL) {
-            dma_alpha_low(job, nb, lane, dA);
+            dma_alpha_low(job, nb, lane, dA, low_rows, n0 < last ? n0 : last);
         }
         else {
             dma16(reinterpret_cast<const char *>(job.alpha) + (size_t)n_lo * 256 + a_in, dA);
@@ -396,7 +403,7 @@ MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
 
 // fast form: the octet after the one described by `a`, which must be a full octet (no clamping)
 template <bool I16, bool LOWL>
-MJX_DEV unsigned dma_octet_next(const DevJob &job, int n0, int lane, unsigned t_in, unsigned a_in, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
+MJX_DEV unsigned dma_octet_next(const DevJob &job, int n0, int lane, unsigned t_in, unsigned a_in, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA, bool low_rows) {
     a.tcol += kWaveBlocks;
     a.pblk += kWaveBlocks;
     const unsigned row_skip = (unsigned)(job.bpr - job.cols);
@@ -413,7 +420,10 @@ MJX_DEV unsigned dma_octet_next(const DevJob &job, int n0, int lane, unsigned t_
     }
     const unsigned bq256 = (unsigned)(lane >> 4) * 256u;
     dma16x2(reinterpret_cast<const char *>(job.tile) + (size_t)n0 * 256, bq256 + t_in, dT);
-    if constexpr(LOWL) dma16_so(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, (unsigned)(lane >> 3) * 256u + (unsigned)(lane & 7) * 32u, dA);
+    if constexpr(LOWL) {
+        const unsigned k = (unsigned)(lane & 7);
+        dma16_so(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, low_rows && k >= 4 ? 128u : (unsigned)(lane >> 3) * 256u + k * 32u, dA); // (dma_alpha_low)
+    }
     else dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, bq256 + a_in, dA);
     return cptr;
 }
@@ -423,6 +433,7 @@ MJX_DEV unsigned dma_octet_next(const DevJob &job, int n0, int lane, unsigned t_
 struct RunCtx {
     int        first;   // consecutive: first tile block of the run
     bool       gather;  // wave-uniform
+    bool       low_rows; // wave-uniform; low-column build: Run.pad (dma_alpha_low)
     const int *G;       // gather: the run's table in LDS
     unsigned   t_in, a_in;
 };
@@ -430,10 +441,10 @@ struct RunCtx {
 template <bool I16, bool LOWL = false>
 MJX_DEV unsigned dma_octet(const DevJob &job, const RunCtx &rc, int o, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
     static_assert(!(I16 && LOWL), "the low-column build exists for float tiles");
-    if(rc.gather) return dma_octet_gather<I16, LOWL>(job, o, lane, rc.G, rc.t_in, rc.a_in, dC, dT, dA);
+    if(rc.gather) return dma_octet_gather<I16, LOWL>(job, o, lane, rc.G, rc.t_in, rc.a_in, dC, dT, dA, rc.low_rows);
     const int n = rc.first + o * kWaveBlocks;
-    if(o != 0 && n + kWaveBlocks <= job.nblocks) return dma_octet_next<I16, LOWL>(job, n, lane, rc.t_in, rc.a_in, a, dC, dT, dA);
-    return dma_octet_generic<I16, LOWL>(job, n, lane, a, dC, dT, dA);
+    if(o != 0 && n + kWaveBlocks <= job.nblocks) return dma_octet_next<I16, LOWL>(job, n, lane, rc.t_in, rc.a_in, a, dC, dT, dA, rc.low_rows);
+    return dma_octet_generic<I16, LOWL>(job, n, lane, a, dC, dT, dA, rc.low_rows);
 }
 // the same for the lean build of the kernel, which does not keep the lane's two chunk offsets in registers
 template <bool I16>
@@ -633,6 +644,7 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
     RunCtx rc;
     rc.first = first;
     rc.gather = kind != kRunConsecutive;
+    rc.low_rows = LOWL && __builtin_amdgcn_readfirstlane(run.pad) != 0;
     rc.G = L.G;
     rc.t_in = rc.a_in = 0;
     if constexpr(!LEAN) chunk_in_block(lane, rc.t_in, rc.a_in);

@@ -98,15 +98,18 @@ struct Segment {
     int32_t cls;     // cost class of its octets: 2 = several times the memory-bound octet, 1, 0 = memory-bound, -1 = zero alpha
     int32_t first;   // kRunConsecutive: first tile block; gather kinds: first octet in the gather table
     int32_t noctets;
-    int32_t low = 0; // every weight of every octet lies in columns 0..3: the octets may go to the low-column build of the blend kernel
+    int32_t low = 0; // 1: every weight of every octet lies in columns 0..3: the octets may go to the low-column build of the blend kernel;
+                     // 2: and in rows 0..3, i.e. in the first 128-byte line of its alpha block
 };
 
 struct SchedStats {
     int64_t blocks = 0, octets = 0, gather_octets = 0, zero_octets = 0, dc_octets = 0, block_terms = 0, union_terms = 0, union_consecutive = 0;
     int64_t low_octets = 0; // blended octets whose weights all lie in columns 0..3
+    int64_t low_row_octets = 0; // ... and in rows 0..3
     void add(const SchedStats &o) {
         union_consecutive += o.union_consecutive;
         low_octets += o.low_octets;
+        low_row_octets += o.low_row_octets;
         blocks += o.blocks; octets += o.octets; gather_octets += o.gather_octets; zero_octets += o.zero_octets; dc_octets += o.dc_octets;
         block_terms += o.block_terms; union_terms += o.union_terms;
     }
@@ -234,6 +237,7 @@ namespace {
 struct RunRef {
     int32_t job, first, noctets, kind;
     int32_t sched; // gather kinds: which gather table `first` counts in (-1: the plan's own)
+    int32_t low_rows = 0; // low-column runs: no weight lies in a row k >= 4 either (Run.pad: the second line of the alpha blocks stays where it is)
 };
 
 struct Tables {
@@ -269,6 +273,9 @@ inline unsigned pattern_rows(uint64_t p) { // bit k: some weight (k, l) is used
     for(int k = 0; k < 8; ++k) m |= ((p >> (8 * k)) & 0xFFu) ? 1u << k : 0u;
     return m;
 }
+// Segment.low of an octet (or stretch) whose blocks' patterns have the union u: 0 = some weight in a column l >= 4; 1 = none, but
+// some in a row k >= 4; 2 = every weight in rows and columns 0..3 (the first 128-byte line of the alpha block holds them all)
+inline int low_class(uint64_t u) { return (pattern_columns(u) & 0xF0u) != 0 ? 0 : ((u >> 32) != 0 ? 1 : 2); }
 inline float octet_cost(uint64_t u) {
     const float c = kCostFixed + kCostColumn * (float)__builtin_popcount(pattern_columns(u)) + kCostTerm * (float)__builtin_popcountll(u);
     return c > kCostMemory ? c : kCostMemory;
@@ -316,11 +323,12 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     auto consecutive = [&]() {
         // (like the zero-alpha and DC-only kinds, the low-column build relies on the alpha tiles keeping the zeros they have now:
         // only with the caller's promise, MJX_PLAN_ALPHA_IS_FINAL / a tile schedule)
-        const int low = skip_zero && (pattern_columns(union_all) & 0xF0u) == 0 ? 1 : 0;
+        const int low = skip_zero ? low_class(union_all) : 0;
         segs.push_back(Segment{kRunConsecutive, cost_class(cost_cons / (float)noct_all), 0, noct_all, low});
         st.octets += noct_all;
         st.union_terms += union_cons;
         st.low_octets += low ? noct_all : 0;
+        st.low_row_octets += low == 2 ? noct_all : 0;
     };
     if(all_same && !(split_zero && pattern[0] == 0) && !(split_dc && pattern[0] == 1)) return consecutive();
 
@@ -390,12 +398,13 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     int base = (int)(gather.size() / kWaveBlocks);
     for(int o = 0; o < noct_sorted;) { // stretches of octets of one cost class (and all with, or not all with, their weights in columns 0..3)
         const int cls = cost_class(octet_cost(unions[(size_t)o]));
-        auto      is_low = [&](int q) { return skip_zero && (pattern_columns(unions[(size_t)q]) & 0xF0u) == 0 ? 1 : 0; };
+        auto      is_low = [&](int q) { return skip_zero ? low_class(unions[(size_t)q]) : 0; };
         const int low = is_low(o);
         int       e = o;
         while(e < noct_sorted && cost_class(octet_cost(unions[(size_t)e])) == cls && is_low(e) == low) ++e;
         segs.push_back(Segment{kRunGather, cls, base + o, e - o, low});
         st.low_octets += low ? e - o : 0;
+        st.low_row_octets += low == 2 ? e - o : 0;
         o = e;
     }
     for(int o = 0; o < noct_sorted; ++o) {
@@ -493,7 +502,7 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
             if(rest > 0 && rest * 2 < t.run_len && len + rest <= kMaxRunOctets) len += rest;
             while(f >= seg_end) seg_end += all[++seg].seg.noctets;
             const int first = kind == kRunConsecutive ? base + f * kWaveBlocks : base + f;
-            runs.push_back(Labelled{RunRef{all[i].job, first, len, kind, all[i].sched}, all[seg].seg.cls, use_low ? all[i].seg.low : 0});
+            runs.push_back(Labelled{RunRef{all[i].job, first, len, kind, all[i].sched, use_low && all[i].seg.low == 2 ? 1 : 0}, all[seg].seg.cls, use_low && all[i].seg.low != 0 ? 1 : 0});
             f += len;
         }
         i = e;
@@ -635,7 +644,7 @@ void expand_runs(const Tables &t, const std::vector<RunRef> &refs, Run *out, con
         d.first = r.first;
         d.noctets = r.noctets;
         d.kind = r.kind;
-        d.pad = 0;
+        d.pad = r.low_rows;
         d.gather = r.kind == kRunConsecutive ? nullptr : (r.sched < 0 ? own : scheds[r.sched]->d_gather);
     }
 }
@@ -751,6 +760,7 @@ void fill_stats(mjx_plan_stats_t *out, const SchedStats &st, int64_t runs, int s
     out->run_octets_max = run_max;
     out->run_octets_min = run_min;
     out->low_column_octets = st.low_octets;
+    out->low_row_octets = st.low_row_octets;
 }
 } // namespace
 
@@ -816,10 +826,18 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
         // 512-image shard of the 8-GPU split - where ramp and tail count, nothing on the 4096-image batch and -1..-4 % on launches
         // of a hundred rounds (256 x 4K: profiles/r04/lowl_kernel_4k_workloads.txt): above a million octets the general build
         // takes these runs.
-        int64_t low_octets = 0;
-        for(const RunRef &r : t.lowl) low_octets += r.noctets;
-        constexpr int64_t kLowlMaxOctets = 1 << 20;
-        if(p->nbeside > 0 || low_octets > kLowlMaxOctets) {
+        // Runs whose weights also keep to rows 0..3 (smooth masks: all of regime A2) leave the second line of every alpha block
+        // where it is in that build - 656 instead of 768 bytes per block - and stay with it at any size.
+        int64_t low_octets = 0, low_row_octets = 0;
+        for(const RunRef &r : t.lowl) {
+            low_octets += r.noctets;
+            low_row_octets += r.low_rows ? r.noctets : 0;
+        }
+#ifndef MJX_LOWL_MAX_OCTETS
+#define MJX_LOWL_MAX_OCTETS (1 << 20)
+#endif
+        constexpr int64_t kLowlMaxOctets = MJX_LOWL_MAX_OCTETS;
+        if(p->nbeside > 0 || (low_octets > kLowlMaxOctets && low_row_octets * 2 < low_octets)) {
             t.runs.insert(t.runs.end(), t.lowl.begin(), t.lowl.end());
             t.lowl.clear();
         }

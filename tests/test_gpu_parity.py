@@ -400,6 +400,77 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
     assert lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 2, final | MJX_PLAN_SERIAL | MJX_PLAN_SIDE_BY_SIDE) == mj._lib.MJX_ERR_BAD_ARG
 
 
+@pytest.mark.parametrize("seed", [77, 78])
+def test_low_column_and_low_row_runs_vs_oracle(mj, seed):
+    """The low-column build of the blend kernel (compose_lowl_kernel: runs none of whose weights lies in a column l >= 4) and its
+    low-row form (none in a row k >= 4 either: rows 4..7 of the alpha blocks are not fetched, their lanes read row 4 of the octet's
+    first block instead).  Jobs made of: smooth blocks (k + l <= 3), blocks with weights anywhere in columns 0..3, blocks with
+    weights anywhere in rows 0..3 (not low), mixtures of them with empty and single-weight blocks, a smooth job with ONE block that
+    has a weight in row 5 (its octet must fetch the second line, its neighbours need not), negative zeros where the schedule sees
+    no weight, ragged block counts; consecutive and grouped plans under the promise that alpha is final == the same without it
+    == oracle."""
+    import torch
+    from libmodjpeg_amd._lib import MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_SERIAL, PlanStats, RectJob, check, lib
+    rng = np.random.default_rng(seed)
+    kk8, ll8 = np.mgrid[0:8, 0:8]
+    smooth, low_cols, low_rows_only = (kk8 + ll8) <= 3, ll8 < 4, kk8 < 4
+    # prow, bpr, row0, col0, rows, cols, kind
+    shapes = [(20, 40, 1, 2, 16, 32, "smooth"), (12, 30, 0, 3, 9, 21, "cols"), (10, 26, 2, 1, 7, 23, "rows"), (40, 40, 3, 3, 33, 29, "mix"), (16, 24, 0, 0, 16, 24, "one"),
+              (6, 9, 1, 1, 3, 5, "smooth")]
+    quants = np.stack([rng.integers(1, 256, 64), rng.integers(1, 4000, 64)]).astype(np.uint16)
+    host = []
+    for prow, bpr, row0, col0, rows, cols, kind in shapes:
+        n = rows * cols
+        coef = rng.integers(-1024, 1024, (prow, bpr, 64)).astype(np.int16)
+        tile = np.round(rng.standard_normal((n, 64)) * 200).astype(np.float32)
+        w = (rng.random((n, 8, 8)) * 0.2 + 0.001).astype(np.float32) * rng.choice(np.array([-1, 1], np.float32), (n, 8, 8))
+        if kind == "smooth":
+            mask = np.broadcast_to(smooth, (n, 8, 8)).copy()
+        elif kind == "cols":
+            mask = np.broadcast_to(low_cols, (n, 8, 8)) & (rng.random((n, 8, 8)) < 0.5)
+        elif kind == "rows":
+            mask = np.broadcast_to(low_rows_only, (n, 8, 8)) & (rng.random((n, 8, 8)) < 0.5)
+        elif kind == "one":
+            mask = np.broadcast_to(smooth, (n, 8, 8)).copy()
+            mask[n // 2 + 3, 5, 0] = True
+        else:
+            which = rng.integers(0, 6, n)
+            mask = np.zeros((n, 8, 8), bool)
+            mask[which == 1, 0, 0] = True
+            mask[which == 2] = smooth
+            mask[which == 3] = low_cols & (rng.random((8, 8)) < 0.6)
+            mask[which == 4] = low_rows_only
+            mask[which == 5] = rng.random((int((which == 5).sum()), 8, 8)) < 0.7
+        alpha = np.where(mask, w, np.float32(0))
+        alpha[(~mask) & (rng.random((n, 8, 8)) < 0.1)] = np.float32(-0.0)  # not a weight (convolve.c:32): the schedule must not count it, the kernel may fetch it
+        host.append((coef, tile, np.ascontiguousarray(alpha.reshape(n, 64), np.float32)))
+    jobs = (RectJob * len(shapes))()
+    results, stats = [], []
+    for flags in (MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_SERIAL, MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_SERIAL, MJX_PLAN_GROUP_BY_DENSITY, 0):
+        dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
+        for j, (prow, bpr, row0, col0, rows, cols, _) in enumerate(shapes):
+            jobs[j] = RectJob(dev[j][0].data_ptr(), dev[j][1].data_ptr(), dev[j][2].data_ptr(), bpr, prow, row0, col0, rows, cols, j % 2)
+        plan = ctypes.c_void_p()
+        check(lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 2, flags), "plan")
+        st = PlanStats()
+        check(lib().mjx_compose_plan_stats(plan, ctypes.byref(st)), "stats")
+        stats.append((st.low_column_octets, st.runs_low_columns))
+        if flags & MJX_PLAN_GROUP_BY_DENSITY and flags & MJX_PLAN_ALPHA_IS_FINAL:
+            # both smooth jobs whole (64 + 2 octets) at least, none of the "cols" job (rows 0..7)
+            assert 64 + 2 <= st.low_row_octets < st.low_column_octets
+        check(lib().mjx_compose_run(plan, None), "run")
+        torch.cuda.synchronize()
+        lib().mjx_compose_plan_destroy(plan)
+        results.append([d[0].cpu().numpy() for d in dev])
+    assert stats[1][0] > 0 and stats[1][1] > 0, "the low-column build took the smooth runs (the alpha tiles are scanned for MJX_PLAN_GROUP_BY_DENSITY)"
+    assert stats[0] == (0, 0) and stats[2] == (0, 0) and stats[3] == (0, 0), "without the scan, or without the promise that alpha is final, nothing is relied on"
+    for j, (prow, bpr, row0, col0, rows, cols, kind) in enumerate(shapes):
+        want = host[j][0].reshape(-1).copy()
+        O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 2]), host[j][1].reshape(-1), host[j][2].reshape(-1))
+        for which, name in enumerate(("plain, alpha final", "grouped, alpha final", "grouped", "plain")):
+            assert np.array_equal(results[which][j].reshape(-1), want), (name, j, kind)
+
+
 @pytest.mark.parametrize("seed", [2027] + _EXTRA_SEEDS)
 def test_int16_tile_plans_vs_oracle_on_full_range_values(mj, seed):
     """MJX_JOB_TILES_I16 on arbitrary int16 contents (tile and alpha coefficients over the whole
