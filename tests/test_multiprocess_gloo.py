@@ -165,15 +165,17 @@ def test_a_dead_rank_takes_the_group_down_instead_of_hanging_it():
 
 def test_traffic_figures_exist_for_every_shard_of_the_strong_split():
     """roofline.traffic of an N > 1 line (it printed null): profiles/traffic.json holds a
-    measured rocprofv3 figure for 4096 / 2048 / 1024 / 512 images per GPU, and any other shard size gets the
+    measured rocprofv3 figure for the full batch and for the 512-image shard of the 8-GPU split (round 4: 656 bytes
+    per block, the second line of the smooth regime's alpha blocks is not fetched), and any other shard size gets the
     nearest one scaled by its block count, labelled as scaled"""
     import os
 
     import bench
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
-    for images in (4096, 2048, 1024, 512):
+    for images in (4096, 512):
         got, src = bench.traffic_from_profiles(path, f"compose_1080p_batch:A2:{images}")
-        assert got is not None and 0.99 < got / (images * 1536 * 768) < 1.02, (images, got)
+        assert got is not None and 0.99 < got / (images * 1536 * 656) < 1.02, (images, got)
         assert "rocprofv3" in src
-    got, src = bench.traffic_scaled(path, "compose_1080p_batch:A2:", 683 * 1536)  # the 6-rank shard
-    assert got is not None and 0.99 < got / (683 * 1536 * 768) < 1.02 and src.startswith("scaled by block count")
+    for images in (2048, 1024, 683):  # the 2- and 4-GPU shards, the 6-rank rehearsal's
+        got, src = bench.traffic_scaled(path, "compose_1080p_batch:A2:", images * 1536)
+        assert got is not None and 0.99 < got / (images * 1536 * 656) < 1.02 and src.startswith("scaled by block count"), (images, got, src)
