@@ -498,7 +498,9 @@ def bench_compose(args, rank, world):
         # regime A2) go to the low-column build of the blend kernel, which leaves the second 128-byte line of their alpha blocks - zeros,
         # the schedule has seen them - where it is: eight first lines and one second line per octet instead of sixteen lines.
         # `achieved` stays SURVEY 8d's algorithmic figure; `achieved_on_bytes_moved` says how hard the memory system works.
-        skipped = 8 * plan_stats.get("low_row_octets", 0) * 112 if plan_stats.get("runs_low_columns") and args.tiles != "i16" else 0
+        # (the low-column build asks for one second line per octet, the general and lean builds for two: 112 / 96 bytes per block saved)
+        lowl_only = plan_stats.get("runs_low_columns") and plan_stats.get("low_column_octets") == plan_stats.get("low_row_octets") and not plan_stats.get("runs_beside")
+        skipped = 8 * plan_stats.get("low_row_octets", 0) * (112 if lowl_only else 96) if args.tiles != "i16" else 0
         moved_bytes = launch_bytes - skipped
         achieved_moved = moved_bytes / (mean_kern_ms * 1e-3) / 1e9
         # every rank's own launch against the peak of its own GPU: the figures above describe rank 0's shard

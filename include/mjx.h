@@ -174,8 +174,8 @@ typedef struct mjx_plan_stats {
     int32_t runs_beside; /* runs of blocks that need no blend that are streamed BESIDE the blend kernel (0: the kernels run one after the other) */
     int64_t low_column_octets; /* blended octets none of whose weights lies in a column l >= 4 (smooth masks) ... */
     int64_t runs_low_columns;  /* ... and the runs of them that go to the low-column build of the blend kernel (four workgroups per CU) */
-    int64_t low_row_octets;    /* low-column octets none of whose weights lies in a row k >= 4 either: in the low-column build the second
-                                  128-byte line of their alpha blocks is not fetched (656 instead of 768 bytes per block with float tiles) */
+    int64_t low_row_octets;    /* blended octets none of whose weights lies in a row k >= 4: with float tiles the second 128-byte line of
+                                  their alpha blocks is not fetched (656 - 672 instead of 768 bytes per block) */
 } mjx_plan_stats_t;
 int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out);
 void mjx_compose_plan_destroy(mjx_compose_plan_t *plan);

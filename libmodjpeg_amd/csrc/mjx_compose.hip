@@ -324,6 +324,10 @@ MJX_DEV unsigned plane_block_of(const DevJob &job, int n) {
 // LOWL (float tiles only): of every alpha row only the first 16 bytes (weights of columns 0..3) go to LDS, as ONE piece in natural
 // order: chunk 8b + k <- row k of block b.  The request still touches every 128-byte line of the eight alpha blocks (the HBM traffic is
 // the same); what shrinks is the LDS slot, 1 KiB instead of 2.
+// The general alpha image (two pieces: blocks 0..3 and 4..7 of the octet; this lane's chunk is half a row, a_in = 32 * row + 16 * half
+// inside its block) under the same promise: the lanes of rows 4..7 (a_in >= 128) ask for row 4 of the piece's first block instead.
+MJX_DEV unsigned alpha_chunk(unsigned own, unsigned a_in, bool low_rows, unsigned first_block_off) { return low_rows && a_in >= 128u ? first_block_off + 128u + (a_in & 16u) : own; }
+
 // low_rows (a promise of the schedule's: no weight of the run lies in a row k >= 4 either): rows 4..7 of the eight blocks are not
 // fetched; their lanes all ask for the same 16 bytes, row 4 of the octet's first block (n_first) - zeros, like what they stand for
 // - so that per octet eight first lines and ONE second line travel instead of sixteen lines.
@@ -352,8 +356,9 @@ MJX_DEV unsigned dma_octet_gather(const DevJob &job, int o, int lane, const int 
         dma_alpha_low(job, n, lane, dA, low_rows, G[o * kWaveBlocks]);
         return cptr;
     }
-    dma16_so(job.alpha, (unsigned)t_lo * 256u + a_in, dA);
-    dma16_so(job.alpha, (unsigned)t_hi * 256u + a_in, dA + 1024);
+    const unsigned first_off = low_rows ? (unsigned)G[o * kWaveBlocks] * 256u : 0u;
+    dma16_so(job.alpha, alpha_chunk((unsigned)t_lo * 256u + a_in, a_in, low_rows, first_off), dA);
+    dma16_so(job.alpha, alpha_chunk((unsigned)t_hi * 256u + a_in, a_in, low_rows, first_off), dA + 1024);
     return cptr;
 }
 
@@ -382,7 +387,7 @@ MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
     if(n0 + 7 <= last) {
         dma16x2(reinterpret_cast<const char *>(job.tile) + (size_t)n0 * 256, (unsigned)bq * 256u + t_in, dT);
         if constexpr(LOWL) dma_alpha_low(job, nb, lane, dA, low_rows, n0 < last ? n0 : last);
-        else dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, (unsigned)bq * 256u + a_in, dA);
+        else dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, alpha_chunk((unsigned)bq * 256u + a_in, a_in, low_rows, 0u), dA); // (the second piece: row 4 of block 4)
     }
     else {
         int n_lo = n0 + bq, n_hi = n0 + 4 + bq;
@@ -394,8 +399,10 @@ MJX_DEV unsigned dma_octet_generic(const DevJob &job, int n0, int lane, OctetAdd
             dma_alpha_low(job, nb, lane, dA, low_rows, n0 < last ? n0 : last);
         }
         else {
-            dma16(reinterpret_cast<const char *>(job.alpha) + (size_t)n_lo * 256 + a_in, dA);
-            dma16(reinterpret_cast<const char *>(job.alpha) + (size_t)n_hi * 256 + a_in, dA + 1024);
+            const int nf = n0 < last ? n0 : last;
+            const bool redirect = low_rows && a_in >= 128u;
+            dma16(reinterpret_cast<const char *>(job.alpha) + (redirect ? (size_t)nf * 256 + 128 + (a_in & 16u) : (size_t)n_lo * 256 + a_in), dA);
+            dma16(reinterpret_cast<const char *>(job.alpha) + (redirect ? (size_t)nf * 256 + 128 + (a_in & 16u) : (size_t)n_hi * 256 + a_in), dA + 1024);
         }
     }
     return cptr;
@@ -424,7 +431,7 @@ MJX_DEV unsigned dma_octet_next(const DevJob &job, int n0, int lane, unsigned t_
         const unsigned k = (unsigned)(lane & 7);
         dma16_so(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, low_rows && k >= 4 ? 128u : (unsigned)(lane >> 3) * 256u + k * 32u, dA); // (dma_alpha_low)
     }
-    else dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, bq256 + a_in, dA);
+    else dma16x2(reinterpret_cast<const char *>(job.alpha) + (size_t)n0 * 256, alpha_chunk(bq256 + a_in, a_in, low_rows, 0u), dA); // (the second piece: row 4 of block 4)
     return cptr;
 }
 
@@ -433,7 +440,7 @@ MJX_DEV unsigned dma_octet_next(const DevJob &job, int n0, int lane, unsigned t_
 struct RunCtx {
     int        first;   // consecutive: first tile block of the run
     bool       gather;  // wave-uniform
-    bool       low_rows; // wave-uniform; low-column build: Run.pad (dma_alpha_low)
+    bool       low_rows; // wave-uniform; float tiles: Run.pad (alpha_chunk, dma_alpha_low)
     const int *G;       // gather: the run's table in LDS
     unsigned   t_in, a_in;
 };
@@ -644,7 +651,7 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
     RunCtx rc;
     rc.first = first;
     rc.gather = kind != kRunConsecutive;
-    rc.low_rows = LOWL && __builtin_amdgcn_readfirstlane(run.pad) != 0;
+    rc.low_rows = !I16 && __builtin_amdgcn_readfirstlane(run.pad) != 0;
     rc.G = L.G;
     rc.t_in = rc.a_in = 0;
     if constexpr(!LEAN) chunk_in_block(lane, rc.t_in, rc.a_in);

@@ -98,8 +98,8 @@ struct Segment {
     int32_t cls;     // cost class of its octets: 2 = several times the memory-bound octet, 1, 0 = memory-bound, -1 = zero alpha
     int32_t first;   // kRunConsecutive: first tile block; gather kinds: first octet in the gather table
     int32_t noctets;
-    int32_t low = 0; // 1: every weight of every octet lies in columns 0..3: the octets may go to the low-column build of the blend kernel;
-                     // 2: and in rows 0..3, i.e. in the first 128-byte line of its alpha block
+    int32_t low = 0; // bit 0: every weight of every octet lies in columns 0..3: the octets may go to the low-column build of the blend kernel;
+                     // bit 1: every weight lies in rows 0..3, i.e. in the first 128-byte line of its alpha block: the second stays unfetched
 };
 
 struct SchedStats {
@@ -237,7 +237,7 @@ namespace {
 struct RunRef {
     int32_t job, first, noctets, kind;
     int32_t sched; // gather kinds: which gather table `first` counts in (-1: the plan's own)
-    int32_t low_rows = 0; // low-column runs: no weight lies in a row k >= 4 either (Run.pad: the second line of the alpha blocks stays where it is)
+    int32_t low_rows = 0; // float tiles: no weight of the run lies in a row k >= 4 (Run.pad: the second 128-byte line of its alpha blocks stays where it is)
 };
 
 struct Tables {
@@ -273,9 +273,9 @@ inline unsigned pattern_rows(uint64_t p) { // bit k: some weight (k, l) is used
     for(int k = 0; k < 8; ++k) m |= ((p >> (8 * k)) & 0xFFu) ? 1u << k : 0u;
     return m;
 }
-// Segment.low of an octet (or stretch) whose blocks' patterns have the union u: 0 = some weight in a column l >= 4; 1 = none, but
-// some in a row k >= 4; 2 = every weight in rows and columns 0..3 (the first 128-byte line of the alpha block holds them all)
-inline int low_class(uint64_t u) { return (pattern_columns(u) & 0xF0u) != 0 ? 0 : ((u >> 32) != 0 ? 1 : 2); }
+// Segment.low of an octet (or stretch) whose blocks' patterns have the union u: bit 0 = no weight in a column l >= 4,
+// bit 1 = no weight in a row k >= 4 (bit 8k + l of a pattern is weight (k, l): rows 4..7 are the upper half)
+inline int low_class(uint64_t u) { return ((pattern_columns(u) & 0xF0u) == 0 ? 1 : 0) | ((u >> 32) == 0 ? 2 : 0); }
 inline float octet_cost(uint64_t u) {
     const float c = kCostFixed + kCostColumn * (float)__builtin_popcount(pattern_columns(u)) + kCostTerm * (float)__builtin_popcountll(u);
     return c > kCostMemory ? c : kCostMemory;
@@ -327,8 +327,8 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
         segs.push_back(Segment{kRunConsecutive, cost_class(cost_cons / (float)noct_all), 0, noct_all, low});
         st.octets += noct_all;
         st.union_terms += union_cons;
-        st.low_octets += low ? noct_all : 0;
-        st.low_row_octets += low == 2 ? noct_all : 0;
+        st.low_octets += (low & 1) ? noct_all : 0;
+        st.low_row_octets += (low & 2) ? noct_all : 0;
     };
     if(all_same && !(split_zero && pattern[0] == 0) && !(split_dc && pattern[0] == 1)) return consecutive();
 
@@ -403,8 +403,8 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
         int       e = o;
         while(e < noct_sorted && cost_class(octet_cost(unions[(size_t)e])) == cls && is_low(e) == low) ++e;
         segs.push_back(Segment{kRunGather, cls, base + o, e - o, low});
-        st.low_octets += low ? e - o : 0;
-        st.low_row_octets += low == 2 ? e - o : 0;
+        st.low_octets += (low & 1) ? e - o : 0;
+        st.low_row_octets += (low & 2) ? e - o : 0;
         o = e;
     }
     for(int o = 0; o < noct_sorted; ++o) {
@@ -470,6 +470,8 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
     // the low-column build of the blend kernel exists for float tiles (test build: MJX_LOWL=0 sends everything to the general one)
     static const bool lowl_off = [] { const char *e = tuning_env("MJX_LOWL"); return e != nullptr && e[0] == '0'; }();
     const bool        use_low = !t.tiles_i16 && !lowl_off;
+    // what of Segment.low counts here: the low-column build and the skipping of the alpha blocks' second line both exist for float tiles
+    const int         low_mask = (use_low ? 1 : 0) | (t.tiles_i16 ? 0 : 2);
     std::vector<Labelled> runs;
     static const int light_len = [] {
         const char *e = tuning_env("MJX_LIGHT_RUN"); // experiments
@@ -481,7 +483,7 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
         // the stretch [i, e): same job, same kind, same table, each segment starting where the one before ends
         size_t e = i + 1;
         while(e < all.size() && all[e].job == all[i].job && all[e].sched == all[i].sched && all[e].seg.kind == all[i].seg.kind && all[i].seg.kind != kRunConsecutive &&
-              all[e].seg.first == all[e - 1].seg.first + all[e - 1].seg.noctets && (!use_low || all[e].seg.low == all[i].seg.low))
+              all[e].seg.first == all[e - 1].seg.first + all[e - 1].seg.noctets && (all[e].seg.low & low_mask) == (all[i].seg.low & low_mask))
             ++e;
         int total = 0;
         for(size_t k = i; k < e; ++k) total += all[k].seg.noctets;
@@ -502,7 +504,7 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
             if(rest > 0 && rest * 2 < t.run_len && len + rest <= kMaxRunOctets) len += rest;
             while(f >= seg_end) seg_end += all[++seg].seg.noctets;
             const int first = kind == kRunConsecutive ? base + f * kWaveBlocks : base + f;
-            runs.push_back(Labelled{RunRef{all[i].job, first, len, kind, all[i].sched, use_low && all[i].seg.low == 2 ? 1 : 0}, all[seg].seg.cls, use_low && all[i].seg.low != 0 ? 1 : 0});
+            runs.push_back(Labelled{RunRef{all[i].job, first, len, kind, all[i].sched, (all[i].seg.low & low_mask & 2) ? 1 : 0}, all[seg].seg.cls, (all[i].seg.low & low_mask & 1) ? 1 : 0});
             f += len;
         }
         i = e;
@@ -826,8 +828,9 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
         // 512-image shard of the 8-GPU split - where ramp and tail count, nothing on the 4096-image batch and -1..-4 % on launches
         // of a hundred rounds (256 x 4K: profiles/r04/lowl_kernel_4k_workloads.txt): above a million octets the general build
         // takes these runs.
-        // Runs whose weights also keep to rows 0..3 (smooth masks: all of regime A2) leave the second line of every alpha block
-        // where it is in that build - 656 instead of 768 bytes per block - and stay with it at any size.
+        // Smooth masks (all of regime A2: weights in rows 0..3 as well, 656 instead of 768 bytes per block in either build) stay
+        // with the low-column build at any size: with a seventh fewer bytes per octet its fourth workgroup per CU pays
+        // (256 x 4K: 6.1 against 7.1 ms, profiles/r04/lowrows/).
         int64_t low_octets = 0, low_row_octets = 0;
         for(const RunRef &r : t.lowl) {
             low_octets += r.noctets;
