@@ -501,7 +501,9 @@ def bench_compose(args, rank, world):
         # (the low-column build asks for one second line per octet, the general and lean builds for two: 112 / 96 bytes per block saved)
         lowl_only = plan_stats.get("runs_low_columns") and plan_stats.get("low_column_octets") == plan_stats.get("low_row_octets") and not plan_stats.get("runs_beside")
         skipped = 8 * plan_stats.get("low_row_octets", 0) * (112 if lowl_only else 96) if args.tiles != "i16" else 0
-        moved_bytes = launch_bytes - skipped
+        # (blocks outside the mask come out as they went in unless coef * q leaves int16 - never with the synthetic planes - and are then
+        # not written back: compose_light_stream)
+        moved_bytes = launch_bytes - skipped - special_zero * 128
         achieved_moved = moved_bytes / (mean_kern_ms * 1e-3) / 1e9
         # every rank's own launch against the peak of its own GPU: the figures above describe rank 0's shard
         rank_gbs = [r["blocks_per_step"] * (launch_bytes / blocks_per_step) / (r["kernel_ms_mean"] * 1e-3) / 1e9 for r in per_rank]
