@@ -725,22 +725,32 @@ int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, i
         if(jobs[i].rows <= 0 || jobs[i].cols <= 0) continue;
         if((int64_t)jobs[i].blocks_per_row * jobs[i].plane_rows * 128 >= (1ll << 32) || (int64_t)jobs[i].rows * jobs[i].cols * 256 >= (1ll << 32)) return 0;
     }
-    int64_t blend_octets = 0, light_octets = 0;
-    for(const RunRef &r : t.runs) blend_octets += r.noctets;
-    for(const RunRef &r : t.lowl) blend_octets += r.noctets;
+    int64_t blend_octets = 0, light_octets = 0, smooth_octets = 0; // smooth: weights in rows and columns 0..3 (at most 16 terms, usually 10)
+    for(const RunRef &r : t.runs) {
+        blend_octets += r.noctets; // (a run of this list may be a low-row one without being a low-column one: priced by its terms)
+    }
+    for(const RunRef &r : t.lowl) {
+        blend_octets += r.noctets;
+        smooth_octets += r.low_rows ? r.noctets : 0;
+    }
     for(const RunRef &r : t.light) light_octets += r.noctets;
     // worth two more launches and two events per step only when both kernels fill the device for a while: measured
     // (profiles/r04/side_by_side_small_launches.txt) the step gains from 256 images of regime A5 (2.6 blended octets per resident
     // wave) and from 64 of A4 upwards and loses below 128 of A5 (1.3)
     if(!(flags & MJX_PLAN_SIDE_BY_SIDE) && (blend_octets < 2 * (int64_t)t.slots || light_octets < 4 * (int64_t)t.slots)) return 0;
-    const double terms = blend_octets > 0 ? (double)t.stats.union_terms / (double)blend_octets : 0.0;
-    const double blend_ns = (double)blend_octets * (0.45 + 0.055 * terms);
+    // Blended octets cost 0.45 ns + 0.055 ns per term of their union (the vector ALU), but a smooth octet (ten terms) no less than what
+    // its bytes take beside the stream kernel: 1.5 ns (A4, where 62 % of the blended octets are smooth: best share 0.65 of the runs,
+    // the average over all blended octets alone gave 0.58).
+    const int64_t dense_octets = blend_octets - smooth_octets;
+    double        dense_terms = dense_octets > 0 ? ((double)t.stats.union_terms - 10.0 * (double)smooth_octets) / (double)dense_octets : 0.0;
+    dense_terms = dense_terms < 1.0 ? 1.0 : (dense_terms > 64.0 ? 64.0 : dense_terms);
+    const double blend_ns = (double)dense_octets * (0.45 + 0.055 * dense_terms) + (double)smooth_octets * 1.5;
     static const double fixed = [] { const char *e = tuning_env("MJX_LIGHT_SPLIT"); return e ? atof(e) : -1.0; }();
     if(fixed >= 0.0) return (int)((double)t.light.size() * (fixed > 1.0 ? 1.0 : fixed));
     double spent = 0.0;
     int    n = 0;
     for(const RunRef &r : t.light) {
-        spent += (double)r.noctets * (r.kind == kRunDcOnly ? (t.tiles_i16 ? 1.15 : 1.5) : 0.55);
+        spent += (double)r.noctets * (r.kind == kRunDcOnly ? (t.tiles_i16 ? 1.15 : 1.5) : 0.5); // (a block outside the mask is read, and written only if it changed)
         if(spent > blend_ns) break;
         ++n;
     }
