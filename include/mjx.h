@@ -143,7 +143,8 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
  * and their one term runs without the two transpositions the general product needs.  Both kinds are streamed
  * by a lean kernel of their own (8 waves per SIMD, short runs) next to the blend kernel.  Runs of blocks none of whose weights
  * lies in a column l >= 4 (smooth masks) may go to a build of the blend kernel that keeps four z_l and the first 16 bytes of
- * every alpha row only (four workgroups per CU): also under this promise only.
+ * every alpha row only (four workgroups per CU), runs none of whose weights lies in a row k >= 4 leave the second 128-byte line of
+ * their alpha blocks unfetched, and a block without weights that comes out as it went in is not written back: also under this promise only.
  * MJX_PLAN_TILES_I16: every job's tiles are int16 coefficients (the same as MJX_JOB_TILES_I16 on every job). */
 #define MJX_PLAN_GROUP_BY_DENSITY 1
 #define MJX_PLAN_ALPHA_IS_FINAL   2
