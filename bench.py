@@ -486,25 +486,23 @@ def bench_compose(args, rank, world):
     if rank == 0:
         # Algorithmic bytes of THIS launch.  SURVEY 8d prices a composed block at 768 B (512 with int16 tiles); a plan made
         # with the promise that alpha is final moves less for two kinds of block: no weight at all -> the
-        # JCOEF block in and out + its table entry (260 B); the single weight (0,0) -> JCOEF in and out, the tile block and
+        # JCOEF block in + its table entry; the single weight (0,0) -> JCOEF in and out, the tile block and
         # a table entry with the weight (520 B, 392 with int16 tiles).  The headline regime A2 has neither kind.
         special_dc, special_zero = 8 * plan_stats["dc_only_octets"], 8 * plan_stats["zero_alpha_octets"]
         dc_bytes = 128 + (128 if args.tiles == "i16" else 256) + 8 + 128
-        launch_bytes = (blocks_per_step - special_dc - special_zero) * bytes_per_block + special_dc * dc_bytes + special_zero * 260
+        # Round 4 added two more: octets none of whose weights lies in a row k >= 4 (smooth masks: all of the headline regime A2) leave the
+        # second 128-byte line of their alpha blocks - zeros, the schedule has seen them - where it is: eight first lines and one second
+        # line per octet in the low-column build (656 B per block), two in the general and lean builds (672); and a block
+        # without weights that comes out as it went in - always, unless coef * q leaves int16, which the synthetic planes never do - is
+        # not written back (132 B).  `achieved` prices the launch by these bytes, the ones its plan asks the memory system for (the
+        # counters agree: profiles/traffic.json); `achieved_at_nominal_bytes_per_block` is the same launch at SURVEY 8d's 768 B per block.
+        lowl_only = plan_stats.get("runs_low_columns") and plan_stats.get("low_column_octets") == plan_stats.get("low_row_octets") and not plan_stats.get("runs_beside")
+        skipped = 8 * plan_stats.get("low_row_octets", 0) * (112 if lowl_only else 96) if args.tiles != "i16" else 0
+        launch_bytes = (blocks_per_step - special_dc - special_zero) * bytes_per_block - skipped + special_dc * dc_bytes + special_zero * 132
         launch_bytes = max(min(launch_bytes, blocks_per_step * bytes_per_block), 0)
         achieved = launch_bytes / (mean_kern_ms * 1e-3) / 1e9
         achieved_nominal = blocks_per_step * bytes_per_block / (mean_kern_ms * 1e-3) / 1e9
-        # What the launch asks the memory system for.  Octets none of whose weights lies in a row or column >= 4 (smooth masks: all of
-        # regime A2) go to the low-column build of the blend kernel, which leaves the second 128-byte line of their alpha blocks - zeros,
-        # the schedule has seen them - where it is: eight first lines and one second line per octet instead of sixteen lines.
-        # `achieved` stays SURVEY 8d's algorithmic figure; `achieved_on_bytes_moved` says how hard the memory system works.
-        # (the low-column build asks for one second line per octet, the general and lean builds for two: 112 / 96 bytes per block saved)
-        lowl_only = plan_stats.get("runs_low_columns") and plan_stats.get("low_column_octets") == plan_stats.get("low_row_octets") and not plan_stats.get("runs_beside")
-        skipped = 8 * plan_stats.get("low_row_octets", 0) * (112 if lowl_only else 96) if args.tiles != "i16" else 0
-        # (blocks outside the mask come out as they went in unless coef * q leaves int16 - never with the synthetic planes - and are then
-        # not written back: compose_light_stream)
-        moved_bytes = launch_bytes - skipped - special_zero * 128
-        achieved_moved = moved_bytes / (mean_kern_ms * 1e-3) / 1e9
+        moved_bytes, achieved_moved = launch_bytes, achieved  # (the same figures under the names the round-4 profiles use)
         # every rank's own launch against the peak of its own GPU: the figures above describe rank 0's shard
         rank_gbs = [r["blocks_per_step"] * (launch_bytes / blocks_per_step) / (r["kernel_ms_mean"] * 1e-3) / 1e9 for r in per_rank]
         key = f"{args.workload}:{args.regime}:"
