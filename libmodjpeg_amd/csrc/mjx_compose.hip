@@ -447,7 +447,6 @@ struct RunCtx {
 // returns the plane block this lane's JCOEF row belongs to (where the octet is stored: store_ptr)
 template <bool I16, bool LOWL = false>
 MJX_DEV unsigned dma_octet(const DevJob &job, const RunCtx &rc, int o, int lane, OctetAddr &a, unsigned dC, unsigned dT, unsigned dA) {
-    static_assert(!(I16 && LOWL), "the low-column build exists for float tiles");
     if(rc.gather) return dma_octet_gather<I16, LOWL>(job, o, lane, rc.G, rc.t_in, rc.a_in, dC, dT, dA, rc.low_rows);
     const int n = rc.first + o * kWaveBlocks;
     if(o != 0 && n + kWaveBlocks <= job.nblocks) return dma_octet_next<I16, LOWL>(job, n, lane, rc.t_in, rc.a_in, a, dC, dT, dA, rc.low_rows);
@@ -679,10 +678,10 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
     });
 
     const int     ph = (b >> 1) & 1;
-    static_assert(!(LOWL && (I16 || LEAN)), "the low-column build: float tiles, not lean");
+    static_assert(!(LOWL && LEAN), "the low-column build is not a lean one");
     constexpr int kPieces = I16 ? 3 : (LOWL ? 4 : 5); // VMEM operations per octet before its store
-    // I16: this lane converts the alpha row stored at position r of its block = source row (r - 2b) & 7
-    const int    k_src = (r - 2 * b) & 7;
+    // I16: this lane converts the alpha row stored at position r of its block = source row (r - 2b) & 7 (LOWL: the natural image, row r)
+    const int    k_src = LOWL ? r : (r - 2 * b) & 7;
     const double kc0 = 0.3535534, kc1 = 0.5; // the reference's literals (dropon.c:548-566)
     const double k_first = (k_src == 0 ? kc0 : kc1) * kc0 / 1020.0, k_rest = (k_src == 0 ? kc0 : kc1) * kc1 / 1020.0;
     int          sc = 0, sa = 0; // LDS slots of octet i: i mod DEPTH, i mod (DEPTH + 1)
@@ -735,10 +734,16 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
             t_lo = make_float4(t[0], t[1], t[2], t[3]);
             t_hi = make_float4(t[4], t[5], t[6], t[7]);
             a_lo = make_float4(a[0], a[1], a[2], a[3]);
-            a_hi = make_float4(a[4], a[5], a[6], a[7]);
-            // the float image the broadcast weight reads expect: this row at position r, halves swapped per block
-            *reinterpret_cast<float4 *>(pA + lane * 8 + 4 * ph) = a_lo;
-            *reinterpret_cast<float4 *>(pA + lane * 8 + 4 - 4 * ph) = a_hi;
+            if constexpr(LOWL) { // the natural image of the low-column build: block b row k at (8b + k) * 16 bytes, columns 0..3 (the others hold no weight)
+                a_hi = a_lo;
+                *reinterpret_cast<float4 *>(pA + lane * 4) = a_lo;
+            }
+            else {
+                a_hi = make_float4(a[4], a[5], a[6], a[7]);
+                // the float image the broadcast weight reads expect: this row at position r, halves swapped per block
+                *reinterpret_cast<float4 *>(pA + lane * 8 + 4 * ph) = a_lo;
+                *reinterpret_cast<float4 *>(pA + lane * 8 + 4 - 4 * ph) = a_hi;
+            }
             wave_sync();
         }
         octet_compute<!LEAN && !LOWL && MJX_SZ0_CACHE, LOWL>(job, cp[0], lane, b, r, qrow, c4, t_lo, t_hi, a_lo, a_hi, pA, L.Z);
@@ -759,6 +764,11 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) void c
 // (profiles/r04/README.md: the VALU is 68 % busy at A2).
 __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, 4) void compose_lowl_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
     compose_body<false, false, true>(runs, nruns, qrq);
+}
+// the same for int16 tiles: the lane that holds row r of its block's alpha coefficients converts the four weights of columns 0..3
+// (half the double-precision conversions of the general build, which is bound by them: DESIGN.md 4b)
+__global__ __launch_bounds__(64 * MJX_GROUP_WAVES, 4) void compose_lowl_i16_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
+    compose_body<true, false, true>(runs, nruns, qrq);
 }
 // (amdgpu_num_vgpr counts the architected half of the unified register file: 72 = 144 registers per lane)
 template <bool I16>
@@ -1095,10 +1105,11 @@ int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, 
     return check_hip(hipGetLastError(), "compose_kernel launch", MJX_ERR_LAUNCH);
 }
 
-int launch_compose_lowl(const Run *runs, int nruns, const void *qrq, hipStream_t s) {
+int launch_compose_lowl(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
     const int groups = (nruns + MJX_GROUP_WAVES - 1) / MJX_GROUP_WAVES;
-    hipLaunchKernelGGL(compose_lowl_kernel, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
+    if(tiles_i16) hipLaunchKernelGGL(compose_lowl_i16_kernel, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
+    else hipLaunchKernelGGL(compose_lowl_kernel, dim3((unsigned)groups), dim3(64 * MJX_GROUP_WAVES), 0, s, runs, nruns, qrq);
     return check_hip(hipGetLastError(), "compose_lowl_kernel launch", MJX_ERR_LAUNCH);
 }
 

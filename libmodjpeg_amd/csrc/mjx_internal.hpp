@@ -123,7 +123,7 @@ struct ArenaLease {
 int launch_compose(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s, bool shared = false);
 // runs of kind kRunZeroAlpha / kRunDcOnly only: the blocks that need no blend stream through a lean kernel of their own
 // blended runs whose weights all lie in columns 0..3, float tiles: the build that fits four workgroups on a CU
-int launch_compose_lowl(const Run *runs, int nruns, const void *qrq, hipStream_t s);
+int launch_compose_lowl(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s);
 int launch_compose_light(const Run *runs, int nruns, const void *qrq, bool tiles_i16, hipStream_t s);
 // the first nbeside runs on `beside`, by few long-lived workgroups that run next to the (lean) blend kernel; the rest on `after`,
 // the blend kernel's own stream, when it has finished

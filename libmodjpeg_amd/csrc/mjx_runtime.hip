@@ -467,10 +467,10 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
         RunRef  r;
         int32_t cls, low;
     };
-    // the low-column build of the blend kernel exists for float tiles (test build: MJX_LOWL=0 sends everything to the general one)
+    // (test build: MJX_LOWL=0 sends everything to the general build of the blend kernel)
     static const bool lowl_off = [] { const char *e = tuning_env("MJX_LOWL"); return e != nullptr && e[0] == '0'; }();
-    const bool        use_low = !t.tiles_i16 && !lowl_off;
-    // what of Segment.low counts here: the low-column build and the skipping of the alpha blocks' second line both exist for float tiles
+    const bool        use_low = !lowl_off;
+    // what of Segment.low counts here: the skipping of the alpha blocks' second line exists for float tiles (an int16 alpha block is one line)
     const int         low_mask = (use_low ? 1 : 0) | (t.tiles_i16 ? 0 : 2);
     std::vector<Labelled> runs;
     static const int light_len = [] {
@@ -944,7 +944,7 @@ int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
         return err;
     }
     int err = launch_compose(plan->d_runs, plan->nruns, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
-    if(err == MJX_OK) err = launch_compose_lowl(plan->d_runs + plan->nruns, plan->nlowl, plan->d_qrq, (hipStream_t)stream);
+    if(err == MJX_OK) err = launch_compose_lowl(plan->d_runs + plan->nruns, plan->nlowl, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
     if(err == MJX_OK) err = launch_compose_light(plan->d_runs + plan->nruns + plan->nlowl, plan->nlight, plan->d_qrq, plan->tiles_i16, (hipStream_t)stream);
     return err;
 }

@@ -400,18 +400,22 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
     assert lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 2, final | MJX_PLAN_SERIAL | MJX_PLAN_SIDE_BY_SIDE) == mj._lib.MJX_ERR_BAD_ARG
 
 
+@pytest.mark.parametrize("i16", [False, True])
 @pytest.mark.parametrize("seed", [77, 78])
-def test_low_column_and_low_row_runs_vs_oracle(mj, seed):
+def test_low_column_and_low_row_runs_vs_oracle(mj, seed, i16):
     """The low-column build of the blend kernel (compose_lowl_kernel: runs none of whose weights lies in a column l >= 4) and its
     low-row form (none in a row k >= 4 either: rows 4..7 of the alpha blocks are not fetched, their lanes read row 4 of the octet's
     first block instead).  Jobs made of: smooth blocks (k + l <= 3), blocks with weights anywhere in columns 0..3, blocks with
     weights anywhere in rows 0..3 (not low), mixtures of them with empty and single-weight blocks, a smooth job with ONE block that
     has a weight in row 5 (its octet must fetch the second line, its neighbours need not), negative zeros where the schedule sees
     no weight, ragged block counts; consecutive and grouped plans under the promise that alpha is final == the same without it
-    == oracle."""
+    == oracle.  With int16 tiles (compose_lowl_i16_kernel: the lane that holds a row of alpha coefficients converts the weights
+    of columns 0..3): the same jobs, oracle fed with the converted floats."""
     import torch
-    from libmodjpeg_amd._lib import MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_SERIAL, PlanStats, RectJob, check, lib
-    rng = np.random.default_rng(seed)
+    from libmodjpeg_amd._lib import MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_SERIAL, MJX_PLAN_TILES_I16, PlanStats, RectJob, check, lib
+    rng = np.random.default_rng(seed + 100 * i16)
+    c0, c1 = 0.3535534, 0.5
+    kscale = np.array([(c0 if j // 8 == 0 else c1) * (c0 if j % 8 == 0 else c1) / 1020.0 for j in range(64)], np.float64)
     kk8, ll8 = np.mgrid[0:8, 0:8]
     smooth, low_cols, low_rows_only = (kk8 + ll8) <= 3, ll8 < 4, kk8 < 4
     # prow, bpr, row0, col0, rows, cols, kind
@@ -441,13 +445,20 @@ def test_low_column_and_low_row_runs_vs_oracle(mj, seed):
             mask[which == 3] = low_cols & (rng.random((8, 8)) < 0.6)
             mask[which == 4] = low_rows_only
             mask[which == 5] = rng.random((int((which == 5).sum()), 8, 8)) < 0.7
+        if i16:  # int16 coefficients; what the oracle sees: tile = (float)coef, weight = (float)((double)(float)coef * K) (dropon.c:476-485, :548-566)
+            ti = rng.integers(-2000, 2000, (n, 64)).astype(np.int16)
+            ai = np.where(mask.reshape(n, 64), rng.integers(1, 2040, (n, 64)) * rng.choice(np.array([-1, 1]), (n, 64)), 0).astype(np.int16)
+            host.append((coef, ti, ai, ti.astype(np.float32), (ai.astype(np.float32).astype(np.float64) * kscale).astype(np.float32)))
+            continue
         alpha = np.where(mask, w, np.float32(0))
         alpha[(~mask) & (rng.random((n, 8, 8)) < 0.1)] = np.float32(-0.0)  # not a weight (convolve.c:32): the schedule must not count it, the kernel may fetch it
-        host.append((coef, tile, np.ascontiguousarray(alpha.reshape(n, 64), np.float32)))
+        alpha = np.ascontiguousarray(alpha.reshape(n, 64), np.float32)
+        host.append((coef, tile, alpha, tile, alpha))
     jobs = (RectJob * len(shapes))()
     results, stats = [], []
     for flags in (MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_SERIAL, MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_SERIAL, MJX_PLAN_GROUP_BY_DENSITY, 0):
-        dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
+        flags |= MJX_PLAN_TILES_I16 if i16 else 0
+        dev = [(_t(c), _t(t), _t(a)) for c, t, a, _, _ in host]
         for j, (prow, bpr, row0, col0, rows, cols, _) in enumerate(shapes):
             jobs[j] = RectJob(dev[j][0].data_ptr(), dev[j][1].data_ptr(), dev[j][2].data_ptr(), bpr, prow, row0, col0, rows, cols, j % 2)
         plan = ctypes.c_void_p()
@@ -466,7 +477,7 @@ def test_low_column_and_low_row_runs_vs_oracle(mj, seed):
     assert stats[0] == (0, 0) and stats[2] == (0, 0) and stats[3] == (0, 0), "without the scan, or without the promise that alpha is final, nothing is relied on"
     for j, (prow, bpr, row0, col0, rows, cols, kind) in enumerate(shapes):
         want = host[j][0].reshape(-1).copy()
-        O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 2]), host[j][1].reshape(-1), host[j][2].reshape(-1))
+        O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 2]), host[j][3].reshape(-1), host[j][4].reshape(-1))
         for which, name in enumerate(("plain, alpha final", "grouped, alpha final", "grouped", "plain")):
             assert np.array_equal(results[which][j].reshape(-1), want), (name, j, kind)
 
