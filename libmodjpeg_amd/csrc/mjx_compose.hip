@@ -321,7 +321,7 @@ MJX_DEV unsigned plane_block_of(const DevJob &job, int n) {
     return __umul24((unsigned)(job.row0 + trow), (unsigned)job.bpr) + (unsigned)(job.col0 + tcol);
 }
 
-// LOWL (float tiles only): of every alpha row only the first 16 bytes (weights of columns 0..3) go to LDS, as ONE piece in natural
+// LOWL with float tiles (int16 alpha pieces travel whole and are converted by the lanes, compose_body): of every alpha row only the first 16 bytes (weights of columns 0..3) go to LDS, as ONE piece in natural
 // order: chunk 8b + k <- row k of block b.  The request still touches every 128-byte line of the eight alpha blocks (the HBM traffic is
 // the same); what shrinks is the LDS slot, 1 KiB instead of 2.
 // The general alpha image (two pieces: blocks 0..3 and 4..7 of the octet; this lane's chunk is half a row, a_in = 32 * row + 16 * half

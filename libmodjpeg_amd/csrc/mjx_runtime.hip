@@ -251,7 +251,7 @@ struct Tables {
     int                  run_len = 0; // octets per run in the body of the launch
     int                  run_min = 0, run_max = 0;
     bool                 tiles_i16 = false;
-    std::vector<RunRef>  lowl;   // compose_lowl_kernel's: blended runs whose weights all lie in columns 0..3 (float tiles)
+    std::vector<RunRef>  lowl;   // compose_lowl_kernel's / compose_lowl_i16_kernel's: blended runs whose weights all lie in columns 0..3
     SchedStats           stats;
 };
 
