@@ -401,7 +401,7 @@ def test_plans_grouped_by_density_vs_oracle_on_random_patterns(mj, seed):
 
 
 @pytest.mark.parametrize("i16", [False, True])
-@pytest.mark.parametrize("seed", [77, 78])
+@pytest.mark.parametrize("seed", [77, 78] + _EXTRA_SEEDS)
 def test_low_column_and_low_row_runs_vs_oracle(mj, seed, i16):
     """The low-column build of the blend kernel (compose_lowl_kernel: runs none of whose weights lies in a column l >= 4) and its
     low-row form (none in a row k >= 4 either: rows 4..7 of the alpha blocks are not fetched, their lanes read row 4 of the octet's
