@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 BYTES_PER_BLOCK = 768  # 128 JCOEF read + 256 tile + 256 alpha + 128 JCOEF write
+EFFECT_SECTOR_BYTES = 96  # what the counters show per DC of the effects pass: a 64-byte fetch and a 32-byte write-back (profiles/r04/effects_4k_rocprof_summary.txt)
 
 WORKLOADS = {
     # name: (width, height, dropon_w, dropon_h, mcu_x, mcu_y, images of the whole job)
@@ -77,6 +78,12 @@ def parse(argv=None):
                          "the other, side by side, or as the library decides (default; side by side when both fill the device)")
     ap.add_argument("--keep-zero-alpha", action="store_true",
                     help="compose: blocks without any weight still stream their tile and alpha blocks (no MJX_PLAN_ALPHA_IS_FINAL)")
+    ap.add_argument("--also", default="auto", choices=["auto", "none"],
+                    help="auto (default): the headline run (default workload, regime, tiles and launch on one GPU) also measures, inside the same JSON line, what "
+                         "making its plan costs (`plan_ms`), the same launch planned WITHOUT the promise that alpha is final (`roofline.frac_without_promise`) and, "
+                         "under `also`, the other regimes of the same batch (A5 real mask, A4 mixed, A3 dense), the 4K full-frame config and the effects batch, each "
+                         "with its step time, its parity verdict and its fraction of the HBM peak on the bytes its plan moves; none: the headline only")
+    ap.add_argument("--also-steps", type=int, default=20, help="timed steps of every `also` measurement (effects: a quarter of it)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     return ap.parse_args(argv)
 
@@ -378,6 +385,96 @@ def traffic_scaled(path, key_prefix, blocks):
     return None, None
 
 
+def plan_launch_bytes(plan_stats, blocks, tiles_i16):
+    """Bytes one launch of a plan asks the memory system for (the counters agree: profiles/traffic.json).
+    SURVEY 8d prices a composed block at 768 B (512 with int16 tiles); a plan made with the promise that alpha is final moves
+    less for four kinds of block: no weight at all -> the JCOEF block in + its table entry, written back only if it changed
+    (132 B); the single weight (0,0) -> JCOEF in and out, the tile block and a table entry with the weight (520 B, 392 with
+    int16 tiles); float tiles, no weight in a row k >= 4 -> the second 128-byte line of the alpha block stays where it is
+    (eight first lines and one second line per octet in the low-column build: 656 B per block; two in the general and lean
+    builds: 672 B)."""
+    per_block = 512 if tiles_i16 else BYTES_PER_BLOCK
+    special_dc, special_zero = 8 * plan_stats["dc_only_octets"], 8 * plan_stats["zero_alpha_octets"]
+    dc_bytes = 128 + (128 if tiles_i16 else 256) + 8 + 128
+    lowl_only = plan_stats.get("runs_low_columns") and plan_stats.get("low_column_octets") == plan_stats.get("low_row_octets") and not plan_stats.get("runs_beside")
+    skipped = 8 * plan_stats.get("low_row_octets", 0) * (112 if lowl_only else 96) if not tiles_i16 else 0
+    launch_bytes = (blocks - special_dc - special_zero) * per_block - skipped + special_dc * dc_bytes + special_zero * 132
+    return max(min(launch_bytes, blocks * per_block), 0)
+
+
+def also_compose(batch, batch_cfg, regime_name, steps, nsample, alpha_is_final=True, spinup_ms=150.0):
+    """One more measurement on an existing batch (same images, same rectangles): tiles and alpha of `regime_name` and the planes
+    are generated afresh (deterministic: the planes are pristine again), a plan is made, the first pass is compared with the CPU
+    oracle on `nsample` images, then `steps` launches are timed between two HIP events.  Returns the entry of the JSON line's
+    `also` block."""
+    import numpy as np
+    import torch
+    t_wall = time.perf_counter()
+    regime = REGIMES[regime_name]
+    batch.regime = regime
+    batch.fill_synthetic()
+    batch.build_plan(alpha_is_final=alpha_is_final)
+    st = batch.plan_stats()
+    tiles = [batch.tiles_as_float(0, c) for c in range(3)] if regime == 5 else None
+    _, expected = cpu_baseline_and_expected(batch_cfg, regime, nsample, batch.image0, timing=False, tiles=tiles)
+    batch.run()
+    torch.cuda.synchronize()
+    bad = sum(not np.array_equal(batch.rect_numpy(i, c).reshape(-1), expected[3 * i + c]) for i in range(nsample) for c in range(3))
+    spin_up(batch.run, torch.cuda.synchronize, spinup_ms)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        batch.run()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    blocks = batch.total_blocks()
+    moved = plan_launch_bytes(st, blocks, False)
+    return {"alpha_regime": regime_name, "images": batch.n, "blocks_per_step": blocks, "steps": steps, "ms_per_step": ms, "blocks_per_s": blocks / (ms * 1e-3),
+            "parity": "bit-exact" if bad == 0 else f"MISMATCH in {bad} of {3 * nsample} rectangles", "parity_sample_images": nsample,
+            "alpha_is_final": alpha_is_final, "bytes_moved_per_block": moved / blocks, "achieved_on_bytes_moved": moved / (ms * 1e-3) / 1e9,
+            "frac_on_bytes_moved": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_at_nominal_bytes_per_block": blocks * BYTES_PER_BLOCK / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "launch": "side by side (%d stream runs beside the lean blend kernel)" % st["runs_beside"] if st.get("runs_beside") else "one kernel after the other",
+            "mean_terms_per_block": st.get("mean_terms_per_block"), "mean_union_terms_per_octet": st.get("mean_union_terms_per_octet"),
+            "plan_ms": st["build_ms"], "wall_s": time.perf_counter() - t_wall}
+
+
+def also_effects(steps, image0=0, images=4096):
+    """BASELINE configs[4] at its size on this GPU (4096 x 4K resident = 102 GB; luminance(+7) then tint(+5,-3), two launches per step):
+    first pass compared with the oracle on two whole images, then `steps` steps between two HIP events."""
+    import numpy as np
+    import torch
+    from libmodjpeg_amd.batch import EffectBatch
+    t_wall = time.perf_counter()
+    lum, cb, cr = 7, 5, -3
+    eb = EffectBatch(images, 3840, 2160, image0=image0)
+    eb.fill_synthetic()
+    eb.build_plans(lum, cb, cr, fused=False)
+    dcs = eb.dc_blocks_per_image() * images
+    _, expected = effects_cpu_baseline_and_expected(eb.geo, eb.quant, image0, 2, lum, cb, cr, timing=False)
+    eb.run()
+    torch.cuda.synchronize()
+    bad = sum(not np.array_equal(eb.coef[c][i].cpu().numpy().reshape(-1), expected[3 * i + c]) for i in range(2) for c in range(3))
+    spin_up(eb.run, torch.cuda.synchronize, 150.0)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        eb.run()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    out = {"workload": "effects_4k_batch", "images": images, "dc_blocks_per_step": dcs, "steps": steps, "ms_per_step": ms, "blocks_per_s": dcs / (ms * 1e-3),
+           "parity": "bit-exact" if bad == 0 else f"MISMATCH in {bad} of 6 planes", "parity_sample_images": 2,
+           "frac_at_4_bytes_per_dc": dcs * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "frac_at_sector_bytes_per_dc": dcs * EFFECT_SECTOR_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "sector_bytes_per_dc": EFFECT_SECTOR_BYTES,
+           "wall_s": None}
+    eb.destroy_plans()
+    del eb
+    torch.cuda.empty_cache()
+    out["wall_s"] = time.perf_counter() - t_wall
+    return out
+
+
 # ---- masked compose -------------------------------------------------------------------------------
 
 def main():
@@ -488,18 +585,7 @@ def bench_compose(args, rank, world):
         # with the promise that alpha is final moves less for two kinds of block: no weight at all -> the
         # JCOEF block in + its table entry; the single weight (0,0) -> JCOEF in and out, the tile block and
         # a table entry with the weight (520 B, 392 with int16 tiles).  The headline regime A2 has neither kind.
-        special_dc, special_zero = 8 * plan_stats["dc_only_octets"], 8 * plan_stats["zero_alpha_octets"]
-        dc_bytes = 128 + (128 if args.tiles == "i16" else 256) + 8 + 128
-        # Round 4 added two more: octets none of whose weights lies in a row k >= 4 (smooth masks: all of the headline regime A2) leave the
-        # second 128-byte line of their alpha blocks - zeros, the schedule has seen them - where it is: eight first lines and one second
-        # line per octet in the low-column build (656 B per block), two in the general and lean builds (672); and a block
-        # without weights that comes out as it went in - always, unless coef * q leaves int16, which the synthetic planes never do - is
-        # not written back (132 B).  `achieved` prices the launch by these bytes, the ones its plan asks the memory system for (the
-        # counters agree: profiles/traffic.json); `achieved_at_nominal_bytes_per_block` is the same launch at SURVEY 8d's 768 B per block.
-        lowl_only = plan_stats.get("runs_low_columns") and plan_stats.get("low_column_octets") == plan_stats.get("low_row_octets") and not plan_stats.get("runs_beside")
-        skipped = 8 * plan_stats.get("low_row_octets", 0) * (112 if lowl_only else 96) if args.tiles != "i16" else 0
-        launch_bytes = (blocks_per_step - special_dc - special_zero) * bytes_per_block - skipped + special_dc * dc_bytes + special_zero * 132
-        launch_bytes = max(min(launch_bytes, blocks_per_step * bytes_per_block), 0)
+        launch_bytes = plan_launch_bytes(plan_stats, blocks_per_step, args.tiles == "i16")
         achieved = launch_bytes / (mean_kern_ms * 1e-3) / 1e9
         achieved_nominal = blocks_per_step * bytes_per_block / (mean_kern_ms * 1e-3) / 1e9
         moved_bytes, achieved_moved = launch_bytes, achieved  # (the same figures under the names the round-4 profiles use)
@@ -544,6 +630,41 @@ def bench_compose(args, rank, world):
             "per_rank": per_rank,
             "cpu_baseline": cpu_info,
         }
+        # what making the plan cost (the reference pays tile compilation and its zero tests inside every call, compose.c:155-157, convolve.c:32;
+        # a plan pays once, outside the timed region): mjx_plan_stats_t.build_us
+        out["plan_ms"] = dict(plan_stats["build_ms"], note="mjx_compose_plan_create_opts of the headline batch, host wall clock: scan of the alpha tiles on the device, "
+                              "its results coming down, the host's schedule (patterns -> octets -> runs), tables going up; once per plan, not inside the timed region; "
+                              "in steps of the headline launch: %.1f" % (plan_stats["build_ms"]["total"] / mean_kern_ms))
+        headline = (args.workload == "compose_1080p_batch" and args.regime == "A2" and args.tiles == "f32" and args.launch == "auto" and not args.no_group
+                    and not args.keep_zero_alpha and not args.images and world == 1)
+        if args.also == "auto" and headline:
+            cfg = (width, height, dw, dh, mcu_x, mcu_y)
+            t_also = time.perf_counter()
+            # the same launch planned WITHOUT the promise that alpha is final: whole alpha blocks travel (768 B per block), general or low-column build
+            wp = also_compose(batch, cfg, "A2", args.also_steps, 8, alpha_is_final=False)
+            out["roofline"]["frac_without_promise"] = wp["frac_on_bytes_moved"]
+            out["roofline"]["kernel_ms_without_promise"] = wp["ms_per_step"]
+            out["roofline"]["without_promise"] = wp
+            also = {"compose_1080p_batch:" + r: also_compose(batch, cfg, r, args.also_steps, 8) for r in ("A5", "A4", "A3")}
+            del batch
+            if pristine is not None:
+                del pristine
+            torch.cuda.empty_cache()
+            w4, h4 = WORKLOADS["compose_4k_fullframe"][0:2]
+            one = ComposeBatch(1, w4, h4, w4, h4, 0, 0, REGIMES["A2"])
+            also["compose_4k_fullframe:A2"] = also_compose(one, (w4, h4, w4, h4, 0, 0), "A2", 10 * args.also_steps, 1, spinup_ms=50.0)
+            del one
+            torch.cuda.empty_cache()
+            also["effects_4k_batch"] = also_effects(max(2, args.also_steps // 4))
+            also["wall_s"] = time.perf_counter() - t_also
+            also["note"] = ("secondary measurements of the same run, each from pristine synthetic inputs, first pass checked against the CPU oracle; "
+                            "frac_on_bytes_moved = the bytes the plan asks the memory system for / step time / 8 TB/s")
+            out["also"] = also
+            mism = [k for k, v in also.items() if isinstance(v, dict) and v.get("parity") not in (None, "bit-exact")] + ([] if wp["parity"] == "bit-exact" else ["without_promise"])
+            if mism:
+                print(json.dumps(out))
+                print(f"bench.py: GPU output differs from the oracle in {mism}", file=sys.stderr)
+                sys.exit(1)
         print(json.dumps(out))
         sys.stdout.flush()
 
@@ -647,8 +768,11 @@ def bench_effects(args, rank, world):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "mjx::effect_dc_kernel (two launches per step)", "kernel_ms_mean": mean_ms,
                          "algorithmic_bytes_per_launch": dcs * 4,
+                         # "also report the sector-realistic figure": what the counters show travelling per DC (FETCH_SIZE 64 B, WRITE_SIZE 32 B)
+                         "sector_granular": {"achieved": dcs * EFFECT_SECTOR_BYTES / (mean_ms * 1e-3) / 1e9, "frac": dcs * EFFECT_SECTOR_BYTES / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "bytes_per_dc": EFFECT_SECTOR_BYTES, "note": "64 bytes fetched + 32 bytes written back per 2-byte DC by the rocprofv3 counters"},
                          "line_granular": {"achieved": line_gbs, "frac": line_gbs / HBM_PEAK_GBS, "bytes_per_dc": 256,
-                                           "note": "the 2-byte DC is the only field used of each 128-byte block: a line is read and written back per DC"}},
+                                           "note": "one 128-byte line touched for reading and one for writing per DC: the unit the pass's time scales with (DESIGN.md 5), not bytes the counters show"}},
             "per_rank": per_rank,
             "cpu_baseline": cpu_info}))
         sys.stdout.flush()

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MJX_VERSION 104
+#define MJX_VERSION 105
 
 /* error codes (0 = success).  The libmodjpeg.h shim maps them onto MJ_ERR_* (INTEGRATION.md). */
 #define MJX_OK             0
@@ -68,7 +68,7 @@ typedef void *mjx_stream_t; /* a hipStream_t, or NULL for the default stream */
  *                  queued, when the call was made, on the caller's stream: the `stream` member of the call's
  *                  struct, or its `after` argument.  NULL is the legacy default stream (which in turn waits for
  *                  every blocking stream of the device); a struct that was zero-initialised therefore waits for
- *                  the default stream.  (A stream with nothing queued costs a query, no event.)  MJX_STREAM_IDLE says that nothing is pending on the memory handed over
+ *                  the default stream.  (A stream of the caller's own with nothing queued costs a query, no event; for NULL the event is always recorded, since only that makes the default stream wait for the blocking streams.)  MJX_STREAM_IDLE says that nothing is pending on the memory handed over
  *                  (the caller has synchronised, or the library itself produced it in an earlier call of this
  *                  kind): no event, no wait.
  *        at exit   the call returns only after its own device work has completed, so whatever the caller
@@ -79,6 +79,10 @@ typedef void *mjx_stream_t; /* a hipStream_t, or NULL for the default stream */
 #define MJX_STREAM_IDLE ((mjx_stream_t)(intptr_t)-1)
 
 /* ---- device plumbing (so that C callers need no HIP headers) -------------------------- */
+/* MJX_VERSION of the header the library was built from.  Structs grow and arguments are added between versions (104: the `stream`
+ * members; 105: mjx_plan_stats_t), so a caller built against another header must not go on: the Python mirror and the
+ * libmodjpeg.h shim compare this with their own MJX_VERSION when they load the library. */
+int         mjx_version(void);
 int         mjx_device_count(void);                 /* number of HIP devices, 0 if none */
 int         mjx_set_device(int ordinal);            /* hipSetDevice for the calling thread */
 int         mjx_get_device(int *ordinal);           /* the calling thread's current device */
@@ -158,8 +162,29 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
  * results are identical. */
 #define MJX_PLAN_SERIAL           8
 #define MJX_PLAN_SIDE_BY_SIDE     16
+/* MJX_PLAN_NO_LOW_COLUMN_BUILD: blended runs whose weights all lie in columns 0..3 go to the general build of the blend kernel
+ * like the others (three workgroups per CU instead of four; measurements, and the parity tests' way of sending smooth masks
+ * through the general build).  Purely a schedule. */
+#define MJX_PLAN_NO_LOW_COLUMN_BUILD 32
 int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs,
                                const uint16_t *qtables, int nq, int flags);
+/* The same with every choice of the schedule that is the caller's to make.  Zero-initialise the struct (memset / = {0}): a zero
+ * field leaves the choice to the library, and the reserved fields must be zero.  None of them changes a result
+ * (tests/test_gpu_fullsize.py::test_full_batch_schedule_independence_and_oracle_samples composes the 4096-image batch with runs
+ * of 16, 1 and 5 octets and compares every block). */
+typedef struct mjx_plan_options {
+    int32_t flags;             /* MJX_PLAN_* */
+    int32_t run_octets;        /* octets (8 blocks) one wavefront of the blend kernel works through in the body of a launch, 1..16.
+                                  0: by the size of the launch (2..16: long runs amortise a wave's start, short ones fill the device
+                                  when the launch is small).  A caller with many tiny rectangles may know better. */
+    int32_t stream_run_octets; /* the same for the runs of blocks that need no blend (MJX_PLAN_ALPHA_IS_FINAL), 1..24; 0: 4 */
+    int32_t tail_min_octets;   /* towards the end of a launch runs shrink with the work that is left, not below this; 0: 4; -1: never */
+    float   beside_share;      /* side-by-side launches: this share (0 < s <= 1) of the stream runs goes to the kernel beside the blend
+                                  kernel; 0: the library's estimate */
+    int32_t reserved[11];
+} mjx_plan_options_t;
+int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs,
+                                 const uint16_t *qtables, int nq, const mjx_plan_options_t *opts);
 /* octets (8 blocks) of the plan that were formed by pattern rather than by position */
 int64_t mjx_compose_plan_gather_octets(const mjx_compose_plan_t *plan);
 /* what a plan looks like: `block_terms` = non-zero weights summed over the blocks, `union_terms` = terms
@@ -177,6 +202,12 @@ typedef struct mjx_plan_stats {
     int64_t runs_low_columns;  /* ... and the runs of them that go to the low-column build of the blend kernel (four workgroups per CU) */
     int64_t low_row_octets;    /* blended octets none of whose weights lies in a row k >= 4: with float tiles the second 128-byte line of
                                   their alpha blocks is not fetched (656 - 672 instead of 768 bytes per block) */
+    /* (105) what making the plan cost, host wall clock in microseconds: the reference pays its tile compilation and its zero tests
+     * inside every call (compose.c:155-157, convolve.c:32); a plan pays this once.  [0] the scan of the alpha tiles on the device
+     * (MJX_PLAN_GROUP_BY_DENSITY; 0 without), [1] its results coming down, [2] the host's schedule (patterns -> octets -> runs),
+     * [3] tables going up (runs, gather table, quantisation rows), [4] the whole call. */
+    int32_t build_us[5];
+    int32_t reserved;
 } mjx_plan_stats_t;
 int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out);
 void mjx_compose_plan_destroy(mjx_compose_plan_t *plan);
@@ -185,7 +216,10 @@ int64_t mjx_compose_plan_blocks(const mjx_compose_plan_t *plan);
 /* Enqueue one pass over all rectangles on `stream` (asynchronous; no host sync, no allocation:
  * safe inside hipGraph capture).  Host threads may run one plan at the same time (a side-by-side plan serialises its fork and
  * join internally; its side stream then runs the passes' stream kernels one after the other); the passes touch the same
- * planes, so ordering them against each other stays the callers' business. */
+ * planes, so ordering them against each other stays the callers' business.  Two restrictions: a plan runs on the device it was made
+ * on (the calling thread's current device must be that one: MJX_ERR_BAD_ARG otherwise), and while a stream capture that contains
+ * a side-by-side plan's launches is open (its side stream is part of the capture until the join), no other thread may run the same
+ * plan - capture it, end the capture, then share it. */
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream);
 
 /* Per-image callers (the libmodjpeg.h shim) hold everything in HOST memory.  One call = one

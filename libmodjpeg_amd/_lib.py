@@ -20,6 +20,8 @@ MJX_PLAN_ALPHA_IS_FINAL = 2
 MJX_PLAN_TILES_I16 = 4
 MJX_PLAN_SERIAL = 8         # the two kernels of a step always one after the other
 MJX_PLAN_SIDE_BY_SIDE = 16  # ... always side by side (the default decides by the size of the launch)
+MJX_PLAN_NO_LOW_COLUMN_BUILD = 32  # smooth runs take the general build of the blend kernel like the others
+MJX_VERSION = 105  # include/mjx.h; compared with mjx_version() of the library that is loaded
 MJX_JOB_TILES_I16 = 1
 MJX_RECT_TILES_ON_DEVICE = 1
 MJX_RECT_ROWS_ON_DEVICE = 2
@@ -53,15 +55,23 @@ class PlanStats(ctypes.Structure):
     _fields_ = [("blocks", ctypes.c_int64), ("octets", ctypes.c_int64), ("gather_octets", ctypes.c_int64), ("zero_alpha_octets", ctypes.c_int64),
                 ("runs", ctypes.c_int64), ("block_terms", ctypes.c_int64), ("union_terms", ctypes.c_int64), ("dc_only_octets", ctypes.c_int64), ("union_terms_consecutive", ctypes.c_int64),
                 ("resident_waves", ctypes.c_int32), ("run_octets_max", ctypes.c_int32), ("run_octets_min", ctypes.c_int32), ("runs_beside", ctypes.c_int32),
-                ("low_column_octets", ctypes.c_int64), ("runs_low_columns", ctypes.c_int64), ("low_row_octets", ctypes.c_int64)]
+                ("low_column_octets", ctypes.c_int64), ("runs_low_columns", ctypes.c_int64), ("low_row_octets", ctypes.c_int64),
+                ("build_us", ctypes.c_int32 * 5), ("reserved", ctypes.c_int32)]
 
     def as_dict(self):
-        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k not in ("reserved", "build_us")}
+        d["build_ms"] = dict(zip(("scan", "download", "host_schedule", "upload", "total"), (u / 1e3 for u in self.build_us)))
         real = d["octets"] - d["zero_alpha_octets"]  # (DC-only octets count with a union of one term)
         d["mean_union_terms_per_octet"] = d["union_terms"] / real if real and d["union_terms"] else None
         d["mean_terms_per_block"] = d["block_terms"] / d["blocks"] if d["blocks"] and d["block_terms"] else None
         d["mean_union_terms_per_octet_consecutive"] = d["union_terms_consecutive"] / ((d["blocks"] + 7) // 8) if d["union_terms_consecutive"] else None
         return d
+
+
+class PlanOptions(ctypes.Structure):
+    """struct mjx_plan_options (include/mjx.h): zero = the library's choice"""
+    _fields_ = [("flags", ctypes.c_int32), ("run_octets", ctypes.c_int32), ("stream_run_octets", ctypes.c_int32), ("tail_min_octets", ctypes.c_int32),
+                ("beside_share", ctypes.c_float), ("reserved", ctypes.c_int32 * 11)]
 
 
 class DcJob(ctypes.Structure):
@@ -94,6 +104,7 @@ MJX_PREP_SOURCE_RGB, MJX_PREP_SOURCE_YCC, MJX_PREP_TARGET_RGB, MJX_PREP_TARGET_Y
 # every symbol include/mjx.h declares: (name, restype, argtypes)
 _vp, _i, _sz, _u64, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint32
 SYMBOLS = [
+    ("mjx_version", _i, []),
     ("mjx_device_count", _i, []),
     ("mjx_set_device", _i, [_i]),
     ("mjx_get_device", _i, [ctypes.POINTER(_i)]),
@@ -105,6 +116,7 @@ SYMBOLS = [
     ("mjx_stream_synchronize", _i, [_vp]),
     ("mjx_compose_plan_create", _i, [ctypes.POINTER(_vp), ctypes.POINTER(RectJob), _i, _vp, _i]),
     ("mjx_compose_plan_create_ex", _i, [ctypes.POINTER(_vp), ctypes.POINTER(RectJob), _i, _vp, _i, _i]),
+    ("mjx_compose_plan_create_opts", _i, [ctypes.POINTER(_vp), ctypes.POINTER(RectJob), _i, _vp, _i, ctypes.POINTER(PlanOptions)]),
     ("mjx_compose_plan_gather_octets", ctypes.c_int64, [_vp]),
     ("mjx_compose_plan_stats", _i, [_vp, ctypes.POINTER(PlanStats)]),
     ("mjx_tile_schedule_create", _i, [ctypes.POINTER(_vp), _vp, _i, _i, _i, _vp]),
@@ -161,6 +173,8 @@ def lib():
             f = getattr(L, name)  # AttributeError if the ABI lost a symbol
             f.restype = res
             f.argtypes = args
+        if L.mjx_version() != MJX_VERSION:  # structs grow between versions: a stale library would read garbage (MJX_HIP_LIB overrides)
+            raise RuntimeError(f"{LIB_PATH} implements mjx.h version {L.mjx_version()}, this package was written for {MJX_VERSION}: rebuild it")
         _lib = L
     return _lib
 

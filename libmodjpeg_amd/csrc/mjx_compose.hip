@@ -882,7 +882,11 @@ MJX_DEV void compose_light_body(const Run *__restrict__ runs, int ridx, const vo
 // SGPRs and every lane picks its block's.
 // one run of the stream kernel.  DC: a DC-only run (JCOEF row, tile row and the block's weight travel) or a zero-alpha run (the
 // JCOEF row alone: 5 registers per octet in flight, so many more of them)
-template <bool I16, bool DC, int DEPTH>
+// WIDE: the plane is addressed with 64-bit byte offsets (the launch that has the device to itself: any plane libjpeg can hold, a
+// 65 535 x 65 535 pixel component is 8 GiB); !WIDE: scalar base + 32-bit byte offset, for the kernel that lives in 80 registers -
+// side_by_side_share() sends a plan there only when every rectangle ends below 4 GiB of its plane.  (A tile array of one job is
+// always below 4 GiB: build_tables cuts rectangles of 2^24 blocks or more.)
+template <bool I16, bool DC, int DEPTH, bool WIDE>
 MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
     const int    b = lane >> 3, r = lane & 7;
     const int    noct = __builtin_amdgcn_readfirstlane(run.noctets);
@@ -914,11 +918,10 @@ MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
     auto fetch = [&](const Tab &t) {
         int n = t.n[0];
         static_for<kWaveBlocks - 1>([&](auto K) { n = b == K + 1 ? t.n[K + 1] : n; });
-        // scalar base + 32-bit byte offset (launch_compose_light_pair is only used for planes and tile arrays below 4 GiB): a
-        // 64-bit address per load would cost two registers each, and this kernel has 80
         Octet o;
         o.pblk = plane_block_of(job, n);
-        o.c4 = global_load16_nt(reinterpret_cast<const char *>(job.coef) + (o.pblk * 128u + (unsigned)r * 16u));
+        if constexpr(WIDE) o.c4 = global_load16_nt(reinterpret_cast<const char *>(job.coef) + ((size_t)o.pblk * 128 + (size_t)r * 16));
+        else o.c4 = global_load16_nt(reinterpret_cast<const char *>(job.coef) + (o.pblk * 128u + (unsigned)r * 16u));
         if constexpr(DC) {
             unsigned w = t.w[0];
             static_for<kWaveBlocks - 1>([&](auto K) { w = b == K + 1 ? t.w[K + 1] : w; });
@@ -934,7 +937,8 @@ MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
         return o;
     };
     auto finish = [&](const Octet &o) {
-        int16_t       *cptr = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(job.coef) + (o.pblk * 128u + (unsigned)r * 16u));
+        int16_t       *cptr = WIDE ? reinterpret_cast<int16_t *>(reinterpret_cast<char *>(job.coef) + ((size_t)o.pblk * 128 + (size_t)r * 16))
+                                   : reinterpret_cast<int16_t *>(reinterpret_cast<char *>(job.coef) + (o.pblk * 128u + (unsigned)r * 16u));
         // this lane's quantisation row from the wave's LDS copy: 8 x u16 now, the 8 reciprocals when the tail needs them
         const uint4    q4 = *reinterpret_cast<const uint4 *>(qrow);
         const unsigned cd[4] = {pk_mul_lo_u16(o.c4.x, q4.x), pk_mul_lo_u16(o.c4.y, q4.y), pk_mul_lo_u16(o.c4.z, q4.z), pk_mul_lo_u16(o.c4.w, q4.w)};
@@ -1040,8 +1044,8 @@ MJX_DEV void compose_light_stream(const Run *__restrict__ runs, int nruns, const
         const float *qrow = mine + (lane & 7) * kQuantRowDwords;
         constexpr int kDepthDc = SHARED ? (I16 ? MJX_STREAM_DEPTH_DC_I16 : MJX_STREAM_DEPTH_DC_F32) : MJX_LIGHT_DEPTH_DC;
         constexpr int kDepthZa = SHARED ? MJX_STREAM_DEPTH_ZA : MJX_LIGHT_DEPTH_ZA;
-        if(__builtin_amdgcn_readfirstlane(run.kind) == kRunDcOnly) light_stream_run<I16, true, kDepthDc>(run, qrow, lane);
-        else light_stream_run<I16, false, kDepthZa>(run, qrow, lane);
+        if(__builtin_amdgcn_readfirstlane(run.kind) == kRunDcOnly) light_stream_run<I16, true, kDepthDc, !SHARED>(run, qrow, lane);
+        else light_stream_run<I16, false, kDepthZa, !SHARED>(run, qrow, lane);
     }
 }
 

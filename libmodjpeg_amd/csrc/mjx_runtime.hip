@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <new>
 #include <vector>
 
@@ -141,6 +142,8 @@ struct mjx_compose_plan {
     hipEvent_t  fork = nullptr, join = nullptr;
     mutable pthread_mutex_t side_lock = PTHREAD_MUTEX_INITIALIZER; // the five calls that fork and join are one unit: two host threads may run one plan
     int         nbeside = 0; // leading light runs that go to the kernel running beside the blend kernel (0: the two kernels run one after the other)
+    int         device = -1; // the device the plan's tables, side stream and events live on
+    int32_t     build_us[5] = {0, 0, 0, 0, 0}; // mjx_plan_stats_t.build_us
 };
 
 struct mjx_dc_plan {
@@ -241,6 +244,7 @@ struct RunRef {
 };
 
 struct Tables {
+    mjx_plan_options_t   opt{};  // zero: every choice is the library's
     std::vector<DevJob>  jobs;
     std::vector<RunRef>  runs;   // compose_kernel's
     std::vector<RunRef>  light;  // compose_light_kernel's: zero-alpha and DC-only runs
@@ -467,17 +471,12 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
         RunRef  r;
         int32_t cls, low;
     };
-    // (test build: MJX_LOWL=0 sends everything to the general build of the blend kernel)
-    static const bool lowl_off = [] { const char *e = tuning_env("MJX_LOWL"); return e != nullptr && e[0] == '0'; }();
-    const bool        use_low = !lowl_off;
+    const bool        use_low = !(t.opt.flags & MJX_PLAN_NO_LOW_COLUMN_BUILD);
     // what of Segment.low counts here: the skipping of the alpha blocks' second line exists for float tiles (an int16 alpha block is one line)
     const int         low_mask = (use_low ? 1 : 0) | (t.tiles_i16 ? 0 : 2);
     std::vector<Labelled> runs;
-    static const int light_len = [] {
-        const char *e = tuning_env("MJX_LIGHT_RUN"); // experiments
-        const int   v = e ? atoi(e) : 4; // measured (scripts/r03_check6.sh): 2..8 octets within 2 %, 16 is 3-5 % slower
-        return v < 1 ? 1 : (v > kMaxRunOctets ? kMaxRunOctets : v);
-    }();
+    // measured (round 3): 2..8 octets within 2 %, 16 is 3-5 % slower
+    const int light_len = t.opt.stream_run_octets > 0 ? (t.opt.stream_run_octets > kMaxRunOctets ? kMaxRunOctets : t.opt.stream_run_octets) : 4;
     t.light.clear();
     for(size_t i = 0; i < all.size();) {
         // the stretch [i, e): same job, same kind, same table, each segment starting where the one before ends
@@ -511,11 +510,7 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
     }
     std::stable_sort(runs.begin(), runs.end(), [](const Labelled &a, const Labelled &b) { return a.cls > b.cls; });
 
-    static const int tail_min = [] {
-        const char *e = tuning_env("MJX_TAIL_MIN"); // experiments; 0 = runs never shrink
-        const int   v = e ? atoi(e) : 4;
-        return v < 0 ? 0 : v;
-    }();
+    const int tail_min = t.opt.tail_min_octets > 0 ? t.opt.tail_min_octets : (t.opt.tail_min_octets < 0 ? 0 : 4); // 0 = runs never shrink
     t.runs.clear();
     t.lowl.clear();
     t.run_min = 1 << 30;
@@ -570,10 +565,7 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
     if(per_slot >= 8 && run_len < 8) run_len = 8;
     if(run_len < 2) run_len = 2;
     if(run_len > run_octets()) run_len = run_octets();
-    if(const char *e = tuning_env("MJX_RUN_OCTETS")) { // experiments only
-        const int v = atoi(e);
-        if(v >= 1 && v <= run_octets()) run_len = v;
-    }
+    if(t.opt.run_octets > 0) run_len = t.opt.run_octets < run_octets() ? t.opt.run_octets : run_octets(); // the caller's choice (mjx_plan_options_t)
     t.run_len = run_len;
     // rectangles of >= 2^24 blocks are split by rows so that the kernel's float row/column split
     // of the linear tile index stays exact
@@ -589,6 +581,9 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
         if(j.row0 < 0 || j.col0 < 0 || j.blocks_per_row <= 0 || j.col0 + (int64_t)j.cols > j.blocks_per_row) return MJX_ERR_BAD_ARG;
         if(j.plane_rows > 0 && j.row0 + (int64_t)j.rows > j.plane_rows) return MJX_ERR_BAD_ARG;
         if(j.cols > kMaxJobBlocks) return MJX_ERR_BAD_ARG;
+        // the kernels keep a plane block as a 32-bit index made by a 24-bit multiply (row x pitch): far beyond any JPEG (8 192 x 8 192
+        // blocks), but a caller's pitch is arbitrary
+        if(j.blocks_per_row >= (1 << 24) || (int64_t)j.row0 + j.rows >= (1 << 24) || ((int64_t)j.row0 + j.rows) * j.blocks_per_row >= (1ll << 31)) return MJX_ERR_BAD_ARG;
 
         const int max_rows = (int)(kMaxJobBlocks / j.cols);
         for(int r0 = 0; r0 < j.rows; r0 += max_rows) {
@@ -653,7 +648,15 @@ void expand_runs(const Tables &t, const std::vector<RunRef> &refs, Run *out, con
 
 // zero patterns of the alpha tiles of every job in t (one launch over temporary consecutive runs)
 // `after`: the stream the alpha tiles were written on (ordering contract of mjx.h)
-int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<uint32_t> &w00, mjx_stream_t after) {
+static int32_t us_since(std::chrono::steady_clock::time_point t0) {
+    const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    return us > 0x7FFFFFFFll ? 0x7FFFFFFF : (int32_t)us;
+}
+
+// us (optional): [0] the scan on the device, [1] the patterns coming down (large scans only: the small ones are one queue of
+// upload, kernel and download whose parts the host cannot tell apart, counted under [0])
+int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<uint32_t> &w00, mjx_stream_t after, int32_t *us = nullptr) {
+    const auto t_start = std::chrono::steady_clock::now();
     std::vector<Run> tmp;
     for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
         const DevJob &d = t.jobs[(size_t)jid];
@@ -689,6 +692,7 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<u
             memcpy(pattern.data(), arena->pin + run_bytes, (size_t)t.blocks * sizeof(uint64_t));
             memcpy(w00.data(), arena->pin + run_bytes + pat_bytes, w_bytes);
         }
+        if(us) us[0] = us_since(t_start);
         return err != MJX_OK ? err : serr;
     }
     // (large scans run on the legacy default stream, which a non-blocking stream of the caller's is not ordered against)
@@ -701,8 +705,14 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<u
     if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_w, w_bytes), "hipMalloc(weights)", MJX_ERR_MEMORY);
     if(err == MJX_OK) err = check_hip(hipMemcpy(d_tmp, tmp.data(), tmp.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(scan runs)", MJX_ERR_LAUNCH);
     if(err == MJX_OK) err = launch_alpha_pattern(d_tmp, (int)tmp.size(), d_pat, d_w, t.tiles_i16, nullptr);
+    if(err == MJX_OK && us) { // (only to tell the kernel from the copies in build_us)
+        err = check_hip(hipStreamSynchronize(nullptr), "hipStreamSynchronize(scan)", MJX_ERR_LAUNCH);
+        us[0] = us_since(t_start);
+    }
+    const auto t_down = std::chrono::steady_clock::now();
     if(err == MJX_OK) err = check_hip(hipMemcpy(pattern.data(), d_pat, (size_t)t.blocks * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(patterns)", MJX_ERR_LAUNCH);
     if(err == MJX_OK) err = check_hip(hipMemcpy(w00.data(), d_w, w_bytes, hipMemcpyDeviceToHost), "hipMemcpy(weights)", MJX_ERR_LAUNCH);
+    if(us) us[1] = us_since(t_down);
     if(d_tmp) (void)hipFree(d_tmp);
     if(d_pat) (void)hipFree(d_pat);
     if(d_w) (void)hipFree(d_w);
@@ -715,15 +725,15 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<u
 // tiles) - a blend octet about 0.45 ns plus 0.055 ns per term of its union while the stream kernel is beside it, an octet of
 // the stream kernel (one wave per SIMD, 2-8 octets in flight) 0.55 ns without its tile, 1.5 ns with a float tile, 1.15 ns with
 // an int16 tile.  What is wrong with the estimate costs the difference once: whichever kernel finishes first leaves the other
-// to finish alone.  MJX_SIDE_BY_SIDE=0 switches the mode off; the test build's MJX_LIGHT_SPLIT=f fixes the share (measurements).
+// to finish alone.  MJX_PLAN_SERIAL switches the mode off; mjx_plan_options_t.beside_share fixes the share (measurements).
 int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, int flags) {
     if((t.runs.empty() && t.lowl.empty()) || t.light.empty() || (flags & MJX_PLAN_SERIAL)) return 0;
-    static const bool off = [] { const char *e = getenv("MJX_SIDE_BY_SIDE"); return e != nullptr && e[0] == '0'; }();
-    if(off) return 0;
-    // the stream kernel addresses planes and tiles with 32-bit byte offsets
+    // the stream kernel that runs beside the blend kernel addresses the plane with 32-bit byte offsets from job.coef (80 registers):
+    // every rectangle has to END below 4 GiB of its plane (the serial launch's kernel uses 64-bit offsets).  What counts is the last
+    // block a rectangle touches, not plane_rows, which is optional.
     for(int i = 0; i < njobs; ++i) {
         if(jobs[i].rows <= 0 || jobs[i].cols <= 0) continue;
-        if((int64_t)jobs[i].blocks_per_row * jobs[i].plane_rows * 128 >= (1ll << 32) || (int64_t)jobs[i].rows * jobs[i].cols * 256 >= (1ll << 32)) return 0;
+        if(((int64_t)jobs[i].row0 + jobs[i].rows) * jobs[i].blocks_per_row * 128 >= (1ll << 32)) return 0;
     }
     int64_t blend_octets = 0, light_octets = 0, smooth_octets = 0; // smooth: weights in rows and columns 0..3 (at most 16 terms, usually 10)
     for(const RunRef &r : t.runs) {
@@ -745,8 +755,7 @@ int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, i
     double        dense_terms = dense_octets > 0 ? ((double)t.stats.union_terms - 10.0 * (double)smooth_octets) / (double)dense_octets : 0.0;
     dense_terms = dense_terms < 1.0 ? 1.0 : (dense_terms > 64.0 ? 64.0 : dense_terms);
     const double blend_ns = (double)dense_octets * (0.45 + 0.055 * dense_terms) + (double)smooth_octets * 1.5;
-    static const double fixed = [] { const char *e = tuning_env("MJX_LIGHT_SPLIT"); return e ? atof(e) : -1.0; }();
-    if(fixed >= 0.0) return (int)((double)t.light.size() * (fixed > 1.0 ? 1.0 : fixed));
+    if(t.opt.beside_share > 0.0f) return (int)((double)t.light.size() * (t.opt.beside_share > 1.0f ? 1.0 : (double)t.opt.beside_share)); // the caller's choice
     double spent = 0.0;
     int    n = 0;
     for(const RunRef &r : t.light) {
@@ -776,13 +785,30 @@ void fill_stats(mjx_plan_stats_t *out, const SchedStats &st, int64_t runs, int s
 }
 } // namespace
 
+int mjx_version(void) { return MJX_VERSION; }
+
 int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, int flags) {
+    mjx_plan_options_t opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.flags = flags;
+    return mjx_compose_plan_create_opts(plan, jobs, njobs, qtables, nq, &opt);
+}
+
+int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, const mjx_plan_options_t *opts) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
     *plan = nullptr;
+    if(opts == nullptr) return MJX_ERR_NULL_DATA;
+    const int flags = opts->flags;
     if(njobs < 0 || nq < 0) return MJX_ERR_BAD_ARG;
     if(njobs > 0 && (jobs == nullptr || qtables == nullptr || nq == 0)) return MJX_ERR_NULL_DATA;
-    if(flags & ~(MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_TILES_I16 | MJX_PLAN_SERIAL | MJX_PLAN_SIDE_BY_SIDE)) return MJX_ERR_BAD_ARG;
+    if(flags & ~(MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_TILES_I16 | MJX_PLAN_SERIAL | MJX_PLAN_SIDE_BY_SIDE | MJX_PLAN_NO_LOW_COLUMN_BUILD)) return MJX_ERR_BAD_ARG;
     if((flags & MJX_PLAN_SERIAL) && (flags & MJX_PLAN_SIDE_BY_SIDE)) return MJX_ERR_BAD_ARG;
+    if(opts->run_octets < 0 || opts->run_octets > run_octets() || opts->stream_run_octets < 0 || opts->stream_run_octets > 24 || opts->tail_min_octets < -1 ||
+       !(opts->beside_share >= 0.0f && opts->beside_share <= 1.0f))
+        return MJX_ERR_BAD_ARG;
+    for(int32_t r : opts->reserved) {
+        if(r != 0) return MJX_ERR_BAD_ARG; // zero-initialise the struct: later versions give these fields a meaning
+    }
     if(!ensure_device()) return MJX_ERR_NO_DEVICE;
 
     // one tile format per plan: the plan flag, or MJX_JOB_TILES_I16 on every job
@@ -799,12 +825,15 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
         tiles_i16 = tiles_i16 || (live > 0 && with == live);
     }
 
+    const auto t_call = std::chrono::steady_clock::now();
     Tables t;
+    t.opt = *opts;
     int    err = build_tables(jobs, njobs, qtables, nq, tiles_i16, t);
     if(err != MJX_OK) return err;
 
     mjx_compose_plan *p = new(std::nothrow) mjx_compose_plan;
     if(p == nullptr) return MJX_ERR_MEMORY;
+    (void)hipGetDevice(&p->device);
     p->njobs = (int)t.jobs.size();
     p->blocks = t.blocks;
     p->tiles_i16 = t.tiles_i16;
@@ -817,7 +846,7 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
             // without weights leave their tiles behind, which is why that needs the caller's promise
             std::vector<uint64_t> pattern;
             std::vector<uint32_t> w00;
-            if((err = scan_patterns(t, pattern, w00, nullptr)) != MJX_OK) break; // after the legacy default stream (mjx.h)
+            if((err = scan_patterns(t, pattern, w00, nullptr, p->build_us)) != MJX_OK) break; // after the legacy default stream (mjx.h)
             std::vector<JobSegment> all;
             std::vector<Segment>    one;
             for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
@@ -854,6 +883,8 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
             t.runs.insert(t.runs.end(), t.lowl.begin(), t.lowl.end());
             t.lowl.clear();
         }
+        p->build_us[2] = us_since(t_call) - p->build_us[0] - p->build_us[1]; // (build_tables included)
+        const auto t_up = std::chrono::steady_clock::now();
         p->nruns = (int)t.runs.size();
         p->nlowl = (int)t.lowl.size();
         p->nlight = (int)t.light.size();
@@ -881,7 +912,9 @@ int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *
             if((err = check_hip(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH))) break;
             if((err = check_hip(hipEventCreateWithFlags(&p->join, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH))) break;
         }
+        p->build_us[3] = us_since(t_up);
     } while(0);
+    p->build_us[4] = us_since(t_call);
     if(err != MJX_OK) {
         mjx_compose_plan_destroy(p);
         return err;
@@ -914,11 +947,16 @@ int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out
     fill_stats(out, plan->stats, (int64_t)plan->nruns + plan->nlowl + plan->nlight, plan->slots, plan->run_max, plan->run_min);
     out->runs_beside = plan->nbeside;
     out->runs_low_columns = plan->nlowl;
+    memcpy(out->build_us, plan->build_us, sizeof(out->build_us));
     return MJX_OK;
 }
 
 int mjx_compose_run(const mjx_compose_plan_t *plan, mjx_stream_t stream) {
     if(plan == nullptr) return MJX_ERR_NULL_DATA;
+    if(plan->njobs > 0) { // the plan's tables (and its side stream) belong to the device it was made on
+        int dev = -1;
+        if(hipGetDevice(&dev) != hipSuccess || dev != plan->device) return MJX_ERR_BAD_ARG;
+    }
     // the blend first (the long-running waves), then the streams of the blocks that need none; the two kernels
     // touch disjoint blocks
     if(plan->nbeside > 0) {
@@ -1044,9 +1082,14 @@ int Arena::order_after(mjx_stream_t caller) {
         // A marker is a packet through the hardware queue the caller's stream shares with other streams, behind whatever kernels
         // are in it: with sixteen threads calling the coders, markers cost 10-25 % of the throughput (bench.py entropy_1080p_batch:
         // 2 900-3 500 against 3 900 pairs per second); the query is a look at the stream's last signal on the host.
-        const hipError_t q = hipStreamQuery((hipStream_t)caller);
-        if(q == hipSuccess) return MJX_OK;
-        (void)hipGetLastError(); // hipErrorNotReady is not an error
+        // (Only for a stream of the caller's own: the legacy default stream stands for every blocking stream of the device, and a
+        // query of it says nothing about work that is pending on those - there the marker is always recorded; recording on the
+        // default stream is what makes it wait for them.)
+        if(caller != nullptr) {
+            const hipError_t q = hipStreamQuery((hipStream_t)caller);
+            if(q == hipSuccess) return MJX_OK;
+            (void)hipGetLastError(); // hipErrorNotReady is not an error
+        }
         if(int e = check_hip(hipEventRecord(entry, (hipStream_t)caller), "hipEventRecord(caller's stream)", MJX_ERR_LAUNCH)) return e;
         return check_hip(hipStreamWaitEvent(stream, entry, 0), "hipStreamWaitEvent(caller's stream)", MJX_ERR_LAUNCH);
 }

@@ -400,3 +400,15 @@ int mjh_from_mjx(int e) {
         default: return MJ_ERR_MEMORY;
     }
 }
+
+/* libmodjpeg.so.1 and libmjx_hip.so are built from one tree and exchange structs that grow between versions of mjx.h (104: the
+ * `stream` members, 105: the plan statistics).  A stale libmjx_hip.so found first on the library path would read garbage from
+ * them, so the pair is checked when the shim is loaded - like an unresolved symbol, a mismatch stops the program at load time
+ * with a message that names the cause.  (A library older than 105 has no mjx_version at all: the loader's own symbol error.) */
+__attribute__((constructor)) static void mjh_check_mjx_version(void) {
+    if(mjx_version() != MJX_VERSION) {
+        fprintf(stderr, "libmodjpeg (MI355X build): built against mjx.h version %d, but the libmjx_hip.so that was loaded implements %d; rebuild or fix the library path\n",
+                MJX_VERSION, mjx_version());
+        abort();
+    }
+}

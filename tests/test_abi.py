@@ -29,6 +29,34 @@ def test_header_symbols_all_exported(hiplib):
         assert hasattr(L, name), name
 
 
+def test_library_and_mirror_agree_on_the_header_version(hiplib):
+    """MJX_VERSION of include/mjx.h == mjx_version() of the built library == the Python mirror's constant (structs grow between
+    versions; _lib.lib() refuses a library of another version)"""
+    hdr = open(os.path.join(ROOT, "include", "mjx.h")).read()
+    v = int(re.search(r"#define\s+MJX_VERSION\s+(\d+)", hdr).group(1))
+    assert hiplib.lib().mjx_version() == v == hiplib.MJX_VERSION
+
+
+def test_plan_options_are_validated_on_the_host(hiplib):
+    L = hiplib.lib()
+    plan = ctypes.c_void_p()
+    job = hiplib.RectJob(16, 16, 16, 4, 4, 0, 0, 1, 1, 0)
+    q = np.ones(64, np.uint16)
+    qp = q.ctypes.data_as(ctypes.c_void_p)
+    assert L.mjx_compose_plan_create_opts(ctypes.byref(plan), ctypes.pointer(job), 1, qp, 1, None) == hiplib.MJX_ERR_NULL_DATA
+    for field, value in (("run_octets", 17), ("run_octets", -1), ("stream_run_octets", 25), ("tail_min_octets", -2), ("beside_share", 1.5), ("beside_share", -0.1), ("flags", 64)):
+        opt = hiplib.PlanOptions()
+        setattr(opt, field, value)
+        assert L.mjx_compose_plan_create_opts(ctypes.byref(plan), ctypes.pointer(job), 1, qp, 1, ctypes.byref(opt)) == hiplib.MJX_ERR_BAD_ARG, (field, value)
+    opt = hiplib.PlanOptions()
+    opt.reserved[3] = 1
+    assert L.mjx_compose_plan_create_opts(ctypes.byref(plan), ctypes.pointer(job), 1, qp, 1, ctypes.byref(opt)) == hiplib.MJX_ERR_BAD_ARG
+    # a pitch or a row count the kernels' 24-bit block arithmetic cannot hold
+    wide = hiplib.RectJob(16, 16, 16, 1 << 24, 4, 0, 0, 1, 1, 0)
+    ok = hiplib.PlanOptions()
+    assert L.mjx_compose_plan_create_opts(ctypes.byref(plan), ctypes.pointer(wide), 1, qp, 1, ctypes.byref(ok)) in (hiplib.MJX_ERR_BAD_ARG, hiplib.MJX_ERR_NO_DEVICE)
+
+
 def test_struct_layouts_match_header(hiplib):
     # mjx_rect_job: 3 pointers + 7 int32 (padded to 8) ; mjx_dc_job: pointer + 4 int32 + 2 uint16
     assert ctypes.sizeof(hiplib.RectJob) == 56
@@ -44,7 +72,8 @@ def test_ctypes_mirrors_have_the_c_layout(hiplib, tmp_path):
     mirrors = {
         "mjx_rect_job_t": (hiplib.RectJob, ["coef", "blocks_per_row", "qtable", "flags"]),
         "mjx_host_rect_t": (hiplib.HostRect, ["rows_ptr", "q", "blocks_per_row", "flags", "schedule", "stream"]),
-        "mjx_plan_stats_t": (hiplib.PlanStats, ["blocks", "runs", "union_terms", "dc_only_octets", "resident_waves", "run_octets_min"]),
+        "mjx_plan_stats_t": (hiplib.PlanStats, ["blocks", "runs", "union_terms", "dc_only_octets", "resident_waves", "run_octets_min", "low_row_octets", "build_us", "reserved"]),
+        "mjx_plan_options_t": (hiplib.PlanOptions, ["flags", "run_octets", "stream_run_octets", "tail_min_octets", "beside_share", "reserved"]),
         "mjx_dc_job_t": (hiplib.DcJob, ["coef", "value", "q0"]),
         "mjx_tileprep_t": (hiplib.TilePrep, ["image", "crop_w", "off_y", "source", "ncomp", "h_samp", "v_samp", "tile", "alpha_tile", "flags", "stream"]),
         "mjx_huff_table_t": (E.HuffTable, ["code", "size"]),

@@ -80,16 +80,25 @@ def test_full_batch_zero_alpha_is_identity(torch_mod):
 @pytest.mark.parametrize("regime", [2, 3, 4])
 def test_full_batch_schedule_independence_and_oracle_samples(torch_mod, regime):
     """regime 4 (mixed): every block has its own non-zero pattern, so octets mix blocks that skip
-    almost every term with blocks that need all 64"""
+    almost every term with blocks that need all 64.  The run length is a real parameter of the plan
+    (mjx_plan_options_t.run_octets; rounds 3-4 set an environment variable that the product library
+    stopped reading): the test asserts through mjx_compose_plan_stats that the three plans really are cut differently,
+    once with the low-column build of the blend kernel and (regime 2) once with the general build doing the same runs."""
     torch = torch_mod
     n = N_IMAGES if regime == 2 else 1024
-    ref = None
-    for run_octets in ("16", "1", "5"):
-        os.environ["MJX_RUN_OCTETS"] = run_octets
-        try:
-            b = _batch(regime, n).build_plan()
-        finally:
-            del os.environ["MJX_RUN_OCTETS"]
+    ref, seen = None, []
+    cases = [(16, True), (1, True), (5, True)] + ([(5, False), (1, False)] if regime == 2 else [])
+    for run_octets, low_column_build in cases:
+        b = _batch(regime, n).build_plan(run_octets=run_octets, stream_run_octets=(0 if run_octets == 16 else run_octets), low_column_build=low_column_build)
+        st = b.plan_stats()
+        if run_octets == 16:
+            assert st["run_octets_max"] == 16, st
+        elif run_octets == 1:
+            assert st["run_octets_max"] == 1 and st["run_octets_min"] == 1, st
+        else:  # a rest shorter than half a run joins the run before it
+            assert 5 <= st["run_octets_max"] <= 7 and st["run_octets_min"] >= 2, st
+        assert (st["runs_low_columns"] > 0) == (low_column_build and regime == 2), st
+        seen.append((st["runs"], st["run_octets_max"], st["runs_low_columns"] > 0))
         b.run()
         torch.cuda.synchronize()
         rects = [_rect_view(b, c).clone() for c in range(3)]
@@ -108,8 +117,9 @@ def test_full_batch_schedule_independence_and_oracle_samples(torch_mod, regime):
                     assert np.array_equal(rects[c][i].cpu().numpy().reshape(-1), want), (regime, i, c)
         else:
             for c in range(3):
-                assert torch.equal(rects[c], ref[c]), (regime, run_octets, c)
+                assert torch.equal(rects[c], ref[c]), (regime, run_octets, low_column_build, c)
         del b
+    assert len(set(seen)) == len(seen), f"the plans do not differ: {seen}"
 
 
 @pytest.mark.parametrize("dims", [(256, 256, 512), (48, 80, 64), (16, 16, 32)])
@@ -415,3 +425,79 @@ def test_entropy_round_trip_of_composed_images_on_the_device(torch_mod, size, n)
                 assert torch.equal(pad[0, 0::2, 0], planes[c][h - 1, 1:w:2, 0])
                 assert torch.equal(pad[0, 1::2, 0], pad[0, 0::2, 0])
     assert total > n * 100000  # real amounts of scan data
+
+
+@pytest.mark.parametrize("i16", [False, True])
+def test_rectangles_beyond_4_gib_of_a_plane(torch_mod, i16):
+    """One component plane of 4.5 GiB (8 192 blocks per row x 4 608 rows x 128 bytes: a 65 536 pixel wide image; JPEG allows
+    65 535 x 65 535, reference compose.c:264-272 addresses rows and columns without any such limit) with two rectangles whose
+    blocks need no blend - empty alpha blocks and blocks whose only weight is (0,0), a few blended ones among them: one that
+    ends below 4 GiB of the plane and one in its last rows, past block 2^25.  Round 4's stream kernel addressed the plane with
+    32-bit byte offsets in both launch modes; now the kernel of the serial launch uses 64-bit offsets and a plan whose rectangles
+    reach beyond 4 GiB never takes the kernel that cannot (mjx_compose_plan_stats: runs_beside == 0 even when side by side is
+    asked for).  Quantisers up to 4 000 make coef * q leave int16, so the blocks without weights ARE written back.  Checked:
+    both rectangles equal the oracle, and every other byte of the 4.5 GiB is what it was (a wrapped offset would land there)."""
+    torch = torch_mod
+    from libmodjpeg_amd._lib import (MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_SERIAL, MJX_PLAN_SIDE_BY_SIDE, MJX_PLAN_TILES_I16, PlanStats, RectJob,
+                                     check, lib)
+    bpr, prow = 8192, 4608
+    assert bpr * prow * 128 >= int(4.5 * 2 ** 30)
+    rng = np.random.default_rng(4500 + i16)
+    gen = torch.Generator(device="cuda").manual_seed(4500 + i16)
+    pristine = torch.randint(-1024, 1024, (prow, bpr, 64), dtype=torch.int16, device="cuda", generator=gen)
+    # (row0, col0, rows, cols): the first ends at byte 3.9 GiB of the plane, the second starts past block 2^25 (row 4096)
+    rects = [(3000, 17, 40, 48), (4560, 8100, 48, 64)]
+    assert (rects[0][0] + rects[0][2]) * bpr * 128 < 2 ** 32 and rects[1][0] * bpr >= 2 ** 25
+    quant = np.stack([rng.integers(1, 256, 64), rng.integers(1, 4000, 64)]).astype(np.uint16)
+    c0, c1 = 0.3535534, 0.5
+    kscale = np.array([(c0 if j // 8 == 0 else c1) * (c0 if j % 8 == 0 else c1) / 1020.0 for j in range(64)], np.float64)
+    host = []
+    for (row0, col0, rows, cols) in rects:
+        n = rows * cols
+        kind = rng.choice(3, n, p=[0.45, 0.45, 0.10])  # no weight / only (0,0) / a handful anywhere
+        if i16:
+            ti = rng.integers(-2000, 2000, (n, 64)).astype(np.int16)
+            ai = np.zeros((n, 64), np.int16)
+            ai[kind == 1, 0] = rng.choice(np.array([2040, 1020, 1, -7], np.int16), int((kind == 1).sum()))
+            dense = rng.integers(-2040, 2040, (n, 64)).astype(np.int16) * (rng.random((n, 64)) < 0.2)
+            ai[kind == 2] = dense[kind == 2]
+            host.append((ti, ai, ti.astype(np.float32), (ai.astype(np.float32).astype(np.float64) * kscale).astype(np.float32)))
+        else:
+            t = np.round(rng.standard_normal((n, 64)) * 200).astype(np.float32)
+            a = np.zeros((n, 64), np.float32)
+            a[kind == 1, 0] = rng.choice(np.array([0.25, 0.125, 1e-3, -0.01], np.float32), int((kind == 1).sum()))
+            dense = (rng.random((n, 64)) * 0.1).astype(np.float32) * (rng.random((n, 64)) < 0.2)
+            a[kind == 2] = dense[kind == 2]
+            host.append((t, a, t, a))
+    want = []
+    for j, (row0, col0, rows, cols) in enumerate(rects):  # the oracle on the rows the rectangle touches
+        rowsv = pristine[row0:row0 + rows].cpu().numpy().reshape(-1).copy()
+        O.compose_rect(rowsv, bpr, 0, col0, rows, cols, np.ascontiguousarray(quant[j]), host[j][2].reshape(-1), host[j][3].reshape(-1))
+        want.append(torch.from_numpy(rowsv.reshape(rows, bpr, 64)).cuda())
+    dev = [(torch.from_numpy(np.ascontiguousarray(h[0])).cuda(), torch.from_numpy(np.ascontiguousarray(h[1])).cuda()) for h in host]
+    final = MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | (MJX_PLAN_TILES_I16 if i16 else 0)
+    # (which rectangles, launch flag, is the co-resident stream kernel allowed)
+    for which, how, beside in (((0, 1), MJX_PLAN_SERIAL, False), ((0, 1), MJX_PLAN_SIDE_BY_SIDE, False), ((0,), MJX_PLAN_SIDE_BY_SIDE, True), ((1,), MJX_PLAN_SIDE_BY_SIDE, False)):
+        plane = pristine.clone()
+        jobs = (RectJob * len(which))()
+        for k, j in enumerate(which):
+            row0, col0, rows, cols = rects[j]
+            # plane_rows = 0: "not given" (it is optional) - the guard must not depend on it
+            jobs[k] = RectJob(plane.data_ptr(), dev[j][0].data_ptr(), dev[j][1].data_ptr(), bpr, 0 if j == 1 else prow, row0, col0, rows, cols, j, 0)
+        plan = ctypes.c_void_p()
+        torch.cuda.synchronize()
+        check(lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(which), quant.ctypes.data_as(ctypes.c_void_p), 2, final | how), "plan")
+        st = PlanStats()
+        check(lib().mjx_compose_plan_stats(plan, ctypes.byref(st)), "stats")
+        assert st.zero_alpha_octets > 0 and st.dc_only_octets > 0, "the rectangles have blocks of both stream kinds"
+        assert (st.runs_beside > 0) == beside, (which, how, st.runs_beside)
+        check(lib().mjx_compose_run(plan, None), "run")
+        torch.cuda.synchronize()
+        lib().mjx_compose_plan_destroy(plan)
+        expect = pristine.clone()
+        for j in which:
+            expect[rects[j][0]:rects[j][0] + rects[j][2]] = want[j]
+        if not torch.equal(plane, expect):
+            diff = (plane != expect).any(dim=2).nonzero()
+            raise AssertionError(f"rectangles {which}, flags {how}: {diff.shape[0]} blocks differ, first at (row, col) {diff[0].tolist()}")
+        del plane, expect

@@ -194,3 +194,76 @@ def test_device_plane_effects_wait_for_a_pending_write(torch_mod, spin, side):
         check(lib().mjx_effect_dc_device(dev.data_ptr(), bpr, rows, cols, int(q[0]), 37, caller_stream()), "mjx_effect_dc_device")
         check(lib().mjx_effect_zero_device(dev.data_ptr(), bpr, rows, cols, 1, caller_stream()), "mjx_effect_zero_device")
     assert np.array_equal(dev.cpu().numpy(), want.reshape(-1))
+
+
+def test_null_stream_caller_waits_for_a_producer_on_a_blocking_stream(torch_mod, spin):
+    """`stream` = NULL stands for the legacy default stream, which waits for every BLOCKING stream of the device: a producer
+    (spin + fill) on a stream made by hipStreamCreate with default flags, then the decoder with stream = NULL.  A query of the
+    NULL stream says nothing about such a producer, so the library must record its marker there unconditionally."""
+    torch = torch_mod
+    from libmodjpeg_amd import _lib
+    from libmodjpeg_amd import entropy as E
+    hip = ctypes.CDLL("libamdhip64.so")
+    handle = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(handle)) == 0  # default flags: a blocking stream
+    try:
+        rng = np.random.default_rng(35)
+        planes = _planes(rng)
+        true_dims = [(p.shape[1], p.shape[0]) for p in planes]
+        data = E.encode_scan(planes, true_dims, GEOM, MCUS_X, MCUS_Y)
+        back = [torch.zeros(p.shape, dtype=torch.int16, device="cuda") for p in planes]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.ExternalStream(handle.value)):
+            spin(40)
+            for t in back:
+                t.fill_(0x5555)
+        real = E.caller_stream
+        try:
+            E.caller_stream = lambda: 0  # NULL: the legacy default stream
+            E.decode_scan(data + E.EOI, back, GEOM, MCUS_X, MCUS_Y)
+        finally:
+            E.caller_stream = real
+        for c, p in enumerate(planes):
+            assert np.array_equal(back[c].cpu().numpy(), p), c
+    finally:
+        torch.cuda.synchronize()
+        hip.hipStreamDestroy(handle)
+
+
+@pytest.mark.parametrize("side", [False, True])
+def test_tile_preparation_waits_for_pending_work_on_its_output_tiles(torch_mod, spin, side):
+    """mjx_tiles_prepare overwrites tile[] / alpha_tile[]: a fill of those arrays that is still queued behind a spin on the
+    caller's stream (`stream` member) must not land on top of the prepared tiles"""
+    torch = torch_mod
+    from libmodjpeg_amd._lib import MJX_PREP_SOURCE_RGB, MJX_PREP_TARGET_YCC, TilePrep, caller_stream, check, lib
+    from libmodjpeg_amd.batch import disc_overlay
+    w, h = 64, 48
+    rgba = disc_overlay(w, h)
+    image = np.ascontiguousarray(rgba[..., :3])
+    alpha = np.ascontiguousarray(np.repeat(rgba[..., 3:4], 3, axis=2))
+    samp = [(2, 2), (1, 1), (1, 1)]
+
+    def prepare(bufs, stream_handle):
+        p = TilePrep(image.ctypes.data, alpha.ctypes.data, w, h, 0, 0, w, h, 0, 0, MJX_PREP_SOURCE_RGB, MJX_PREP_TARGET_YCC, 3)
+        for c, (hs, vs) in enumerate(samp):
+            p.h_samp[c], p.v_samp[c] = hs, vs
+            p.tile[c], p.alpha_tile[c] = bufs[c][0].data_ptr(), bufs[c][1].data_ptr()
+        p.stream = stream_handle
+        check(lib().mjx_tiles_prepare(ctypes.byref(p)), "mjx_tiles_prepare")
+
+    def buffers():
+        return [torch.zeros((2, (h // 16 * vs) * (w // 16 * hs), 64), dtype=torch.float32, device="cuda") for hs, vs in samp]
+
+    want = buffers()
+    torch.cuda.synchronize()
+    prepare(want, caller_stream())
+    got = buffers()
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream() if side else torch.cuda.current_stream()
+    with torch.cuda.stream(stream):
+        spin(40)
+        for t in got:
+            t.fill_(12345.0)
+        prepare(got, caller_stream())
+    for c in range(3):
+        assert torch.equal(got[c], want[c]), c

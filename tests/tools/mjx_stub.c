@@ -94,6 +94,7 @@ static void must_be_mine(const void *p, const char *what) {
 
 #define NEED_DEVICE() do { if(ndevices() == 0) return MJX_ERR_NO_DEVICE; } while(0)
 
+int mjx_version(void) { return MJX_VERSION; }
 int mjx_device_count(void) { return ndevices(); }
 int mjx_set_device(int ordinal) {
     NEED_DEVICE();
@@ -280,6 +281,7 @@ int mjx_huff_wave_tables(const mjx_huff_dscan_t *scan, uint32_t *out, size_t out
 #define UNUSED_INT(name, args) int name args { return MJX_ERR_NO_DEVICE; }
 UNUSED_INT(mjx_compose_plan_create, (mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq))
 UNUSED_INT(mjx_compose_plan_create_ex, (mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, int flags))
+UNUSED_INT(mjx_compose_plan_create_opts, (mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, const mjx_plan_options_t *opts))
 int64_t mjx_compose_plan_gather_octets(const mjx_compose_plan_t *plan) { (void)plan; return 0; }
 UNUSED_INT(mjx_compose_plan_stats, (const mjx_compose_plan_t *plan, mjx_plan_stats_t *out))
 void    mjx_compose_plan_destroy(mjx_compose_plan_t *plan) { (void)plan; }
