@@ -1044,8 +1044,13 @@ MJX_DEV void compose_light_stream(const Run *__restrict__ runs, int nruns, const
         const float *qrow = mine + (lane & 7) * kQuantRowDwords;
         constexpr int kDepthDc = SHARED ? (I16 ? MJX_STREAM_DEPTH_DC_I16 : MJX_STREAM_DEPTH_DC_F32) : MJX_LIGHT_DEPTH_DC;
         constexpr int kDepthZa = SHARED ? MJX_STREAM_DEPTH_ZA : MJX_LIGHT_DEPTH_ZA;
-        if(__builtin_amdgcn_readfirstlane(run.kind) == kRunDcOnly) light_stream_run<I16, true, kDepthDc, !SHARED>(run, qrow, lane);
-        else light_stream_run<I16, false, kDepthZa, !SHARED>(run, qrow, lane);
+#ifdef MJX_EXP_NARROW_STREAM_OFFSETS /* experiment only (wrong beyond 4 GiB of a plane): round 4's addressing, to show that the test of it has teeth */
+        constexpr bool kWide = false;
+#else
+        constexpr bool kWide = !SHARED;
+#endif
+        if(__builtin_amdgcn_readfirstlane(run.kind) == kRunDcOnly) light_stream_run<I16, true, kDepthDc, kWide>(run, qrow, lane);
+        else light_stream_run<I16, false, kDepthZa, kWide>(run, qrow, lane);
     }
 }
 

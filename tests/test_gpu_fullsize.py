@@ -91,8 +91,8 @@ def test_full_batch_schedule_independence_and_oracle_samples(torch_mod, regime):
     for run_octets, low_column_build in cases:
         b = _batch(regime, n).build_plan(run_octets=run_octets, stream_run_octets=(0 if run_octets == 16 else run_octets), low_column_build=low_column_build)
         st = b.plan_stats()
-        if run_octets == 16:
-            assert st["run_octets_max"] == 16, st
+        if run_octets == 16:  # (a rest shorter than half a run joins the run before it: up to 16 + 7)
+            assert 16 <= st["run_octets_max"] <= 23, st
         elif run_octets == 1:
             assert st["run_octets_max"] == 1 and st["run_octets_min"] == 1, st
         else:  # a rest shorter than half a run joins the run before it
