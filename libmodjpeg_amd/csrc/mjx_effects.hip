@@ -6,6 +6,19 @@
 // The DC effects touch 2 bytes of every 128-byte block: a pure strided HBM stream, one lane per
 // block.  All jobs of a batch (Y, Cb, Cr of every image, luminance and tint fused) go into one
 // launch: blockIdx.y selects the job, blockIdx.x/threadIdx.x the block inside it.
+//
+// What the memory system charges for this (scripts/ubench/dc_stride.hip, profiles/r05/dc_stride_*.txt; 8 GiB of blocks):
+//  * a read of ANY part of a block leaves L2 as ONE request for its whole 128-byte line (TCC_EA0_RDREQ = 1 per block, none of them
+//    32-byte ones, for 2, 4, 16, 64 and 128 bytes read; FETCH_SIZE tallies it at 64 bytes) and all of these read-only passes run at
+//    the same 49-56 G blocks/s = 6.3-7.2 TB/s of lines: the HBM read roof.  There is no sector-sized read to be had;
+//  * a write of 2 or 16 bytes leaves L2 as one 32-byte request and runs at 24.6 G blocks/s, a write of the first 64 bytes at 59,
+//    of the whole line at 46.6: partial writes below 64 bytes cost more than twice a 64-byte one;
+//  * read-modify-write of 2 / 16 / 64 / 128 bytes per block: 19.5 / 20.7 / 21.2 / 21.7 G blocks/s with plain accesses, and the
+//    cache policy matters more than the width: plain load + NON-TEMPORAL store of the 2-byte DC 22.3, everything non-temporal on
+//    whole lines 22.6-23.4, non-temporal LOADS of the 2-byte form 15-16 (the line is gone from L2 when its store arrives).
+//    Four blocks in flight per lane is the best depth (8: -12 %, 16: -23 %).
+// Hence: plain loads, non-temporal stores, four DCs per lane.  No form of the update reaches 1 / (1/50 + 1/59) = 27 G blocks/s,
+// the sum of what its read and a 64-byte write cost alone.
 #include "mjx_block_math.hpp"
 #include "mjx_internal.hpp"
 
@@ -13,26 +26,32 @@ namespace mjx {
 
 constexpr int kDcPerThread = 4;
 
+// (the plane pointer comes out of the job table, i.e. out of memory: cast to the global address space, or its accesses are FLAT
+// instructions that count on vmcnt and lgkmcnt at once)
+typedef __attribute__((address_space(1))) int16_t gs16_t;
+
 __global__ __launch_bounds__(256) void effect_dc_kernel(const DevDcJob *__restrict__ jobs) {
     const DevDcJob j = jobs[blockIdx.y];
     const int      total = j.rows * j.cols;
     const int      base = (blockIdx.x * kDcPerThread) * 256 + threadIdx.x;
+    if(total <= 0 || (int)(blockIdx.x * kDcPerThread) * 256 >= total) return; // (uniform: a job smaller than the launch's largest)
     const bool     dense = (j.cols == j.bpr);
 
-    int16_t *p[kDcPerThread];
-    int      dc[kDcPerThread];
-    bool     ok[kDcPerThread];
+    gs16_t *p[kDcPerThread];
+    int     dc[kDcPerThread];
+    bool    ok[kDcPerThread];
 #pragma unroll
     for(int i = 0; i < kDcPerThread; ++i) {
         const int g = base + i * 256;
         ok[i] = g < total;
-        size_t blk = (size_t)g;
-        if(!dense && ok[i]) {
-            const int row = g / j.cols;
-            blk = (size_t)row * (size_t)j.bpr + (size_t)(g - row * j.cols);
+        const int gc = ok[i] ? g : total - 1; // lanes past the end read the job's last block (no branch around the load) and store nothing
+        size_t    blk = (size_t)gc;
+        if(!dense) {
+            const int row = gc / j.cols;
+            blk = (size_t)row * (size_t)j.bpr + (size_t)(gc - row * j.cols);
         }
-        p[i] = j.coef + blk * 64;
-        dc[i] = ok[i] ? (int)*p[i] : 0;
+        p[i] = (gs16_t *)(uintptr_t)(j.coef + blk * 64);
+        dc[i] = (int)*p[i];
     }
 #pragma unroll
     for(int i = 0; i < kDcPerThread; ++i) {
@@ -40,7 +59,7 @@ __global__ __launch_bounds__(256) void effect_dc_kernel(const DevDcJob *__restri
         int d = dequant(dc[i], j.q0);
         d = wrap16((int)((unsigned)d + (unsigned)j.value));
         d = d > 2047 ? 2047 : (d < -2047 ? -2047 : d);
-        if(ok[i]) *p[i] = (int16_t)requant(d, j.rq0);
+        if(ok[i]) __builtin_nontemporal_store((int16_t)requant(d, j.rq0), p[i]);
     }
 }
 

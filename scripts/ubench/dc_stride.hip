@@ -38,10 +38,10 @@ template <Policy P, class T> __device__ __forceinline__ void st(T v, T *p) {
     else *p = v;
 }
 
-constexpr int kPer = 4; // blocks per lane in flight (effect_dc_kernel's kDcPerThread)
+// KPER: blocks per lane in flight (effect_dc_kernel's kDcPerThread: 4)
 
 // MODE: 0 read, 1 write, 2 read-modify-write.  One lane per block, T = the part of the block's head that is touched.
-template <Policy LP, Policy SP, int MODE, class T> __global__ __launch_bounds__(256) void head_kernel(char *__restrict__ base, size_t nblocks, unsigned *__restrict__ sink) {
+template <Policy LP, Policy SP, int MODE, class T, int kPer = 4> __global__ __launch_bounds__(256) void head_kernel(char *__restrict__ base, size_t nblocks, unsigned *__restrict__ sink) {
     const size_t g0 = (size_t)blockIdx.x * (256 * kPer) + threadIdx.x;
     T            v[kPer];
     unsigned     acc = 0;
@@ -67,11 +67,11 @@ template <Policy LP, Policy SP, int MODE, class T> __global__ __launch_bounds__(
             if(g < nblocks) st<SP>(v[i], reinterpret_cast<T *>(base + g * 128));
         }
     }
-    if(MODE == 0 && acc == 0x12345678u) sink[0] = acc; // keeps the loads alive
+    if(MODE == 0 && acc == 0x12345678u) atomicAdd(sink, acc); // keeps the loads alive
 }
 
 // LANES lanes per block, 16 bytes each (LANES = 4: the first half line, 8: the whole line)
-template <Policy LP, Policy SP, int MODE, int LANES> __global__ __launch_bounds__(256) void wide_kernel(char *__restrict__ base, size_t nblocks, unsigned *__restrict__ sink) {
+template <Policy LP, Policy SP, int MODE, int LANES, int kPer = 4> __global__ __launch_bounds__(256) void wide_kernel(char *__restrict__ base, size_t nblocks, unsigned *__restrict__ sink) {
     const size_t t0 = (size_t)blockIdx.x * (256 * kPer) + threadIdx.x;
     u32x4        v[kPer];
     unsigned     acc = 0;
@@ -134,7 +134,8 @@ int main(int argc, char **argv) {
     CK(hipMalloc((void **)&sink, 256));
     CK(hipMemset(buf, 1, nblocks * 128));
     CK(hipDeviceSynchronize());
-    printf("%zu blocks of 128 bytes (%.1f GiB), %d blocks in flight per lane\n", nblocks, gib, kPer);
+    constexpr int kPer = 4;
+    printf("%zu blocks of 128 bytes (%.1f GiB), %d blocks in flight per lane unless the name says otherwise\n", nblocks, gib, kPer);
     const unsigned g1 = (unsigned)((nblocks + 256 * kPer - 1) / (256 * kPer));
 #define HEAD(NAME, LP, SP, MODE, T) timed(NAME, nblocks, [&] { hipLaunchKernelGGL((head_kernel<LP, SP, MODE, T>), dim3(g1), dim3(256), 0, 0, buf, nblocks, sink); })
 #define WIDE(NAME, LP, SP, MODE, LANES) \
@@ -171,6 +172,26 @@ int main(int argc, char **argv) {
     WIDE("rmw64_nt", NT, NT, 2, 4);
     WIDE("rmw128_plain", PLAIN, PLAIN, 2, 8);
     WIDE("rmw128_nt", NT, NT, 2, 8);
+#define HEADK(NAME, LP, SP, MODE, T, K) timed(NAME, nblocks, [&] { hipLaunchKernelGGL((head_kernel<LP, SP, MODE, T, K>), dim3((unsigned)((nblocks + 256 * K - 1) / (256 * K))), dim3(256), 0, 0, buf, nblocks, sink); })
+#define WIDEK(NAME, LP, SP, MODE, LANES, K) \
+    timed(NAME, nblocks, [&] { hipLaunchKernelGGL((wide_kernel<LP, SP, MODE, LANES, K>), dim3((unsigned)((nblocks * LANES + 256 * K - 1) / (256 * K))), dim3(256), 0, 0, buf, nblocks, sink); })
+    // plain loads (the line stays in L2 until its store has merged), non-temporal stores
+    HEAD("rmw16_ntst", PLAIN, NT, 2, u32x4);
+    WIDE("rmw64_ntst", PLAIN, NT, 2, 4);
+    WIDE("rmw128_ntst", PLAIN, NT, 2, 8);
+    // more of the stream in flight per lane
+    HEADK("rmw2_ntst_k1", PLAIN, NT, 2, unsigned short, 1);
+    HEADK("rmw2_ntst_k2", PLAIN, NT, 2, unsigned short, 2);
+    HEADK("rmw2_ntst_k8", PLAIN, NT, 2, unsigned short, 8);
+    HEADK("rmw2_ntst_k16", PLAIN, NT, 2, unsigned short, 16);
+    HEADK("rmw2_plain_k8", PLAIN, PLAIN, 2, unsigned short, 8);
+    HEADK("rmw2_plain_k16", PLAIN, PLAIN, 2, unsigned short, 16);
+    WIDEK("rmw128_nt_k1", NT, NT, 2, 8, 1);
+    WIDEK("rmw128_nt_k2", NT, NT, 2, 8, 2);
+    WIDEK("rmw128_nt_k8", NT, NT, 2, 8, 8);
+    WIDEK("rmw128_ntst_k8", PLAIN, NT, 2, 8, 8);
+    WIDEK("rmw64_ntst_k8", PLAIN, NT, 2, 4, 8);
+    HEADK("rd2_agent_k16", AGENT, AGENT, 0, unsigned short, 16);
     timed("dense2", nblocks, [&] { hipLaunchKernelGGL(dense2_kernel, dim3((unsigned)((nblocks / 8 + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<unsigned short *>(buf), nblocks); });
     CK(hipFree(buf));
     CK(hipFree(sink));
