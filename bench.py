@@ -76,6 +76,10 @@ def parse(argv=None):
     ap.add_argument("--launch", choices=["auto", "serial", "side-by-side"], default="auto",
                     help="compose, plans with blocks that are blended AND blocks that need no blend (regimes A4, A5): the two kernels of a step one after "
                          "the other, side by side, or as the library decides (default; side by side when both fill the device)")
+    ap.add_argument("--beside-share", type=float, default=0.0, help="compose, side-by-side launches: this share of the stream runs goes beside the blend kernel (mjx_plan_options_t; 0 = the library's estimate)")
+    ap.add_argument("--run-octets", type=int, default=0, help="compose: octets per wave of the blend kernel (mjx_plan_options_t.run_octets; 0 = by the size of the launch)")
+    ap.add_argument("--stream-run-octets", type=int, default=0, help="compose: octets per run of the stream kernel (mjx_plan_options_t.stream_run_octets; 0 = 4)")
+    ap.add_argument("--no-low-column-build", action="store_true", help="compose: MJX_PLAN_NO_LOW_COLUMN_BUILD (smooth runs take the general build of the blend kernel)")
     ap.add_argument("--keep-zero-alpha", action="store_true",
                     help="compose: blocks without any weight still stream their tile and alpha blocks (no MJX_PLAN_ALPHA_IS_FINAL)")
     ap.add_argument("--also", default="auto", choices=["auto", "none"],
@@ -515,7 +519,8 @@ def bench_compose(args, rank, world):
     batch = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, regime, image0=image0, tiles_i16=(args.tiles == "i16"))
     bytes_per_block = 512 if args.tiles == "i16" else BYTES_PER_BLOCK  # int16 tiles: 128 + 128 + 128 read, 128 written
     batch.fill_synthetic()
-    batch.build_plan(group_by_density=not args.no_group, alpha_is_final=not args.keep_zero_alpha, side_by_side={"auto": None, "serial": False, "side-by-side": True}[args.launch])
+    batch.build_plan(group_by_density=not args.no_group, alpha_is_final=not args.keep_zero_alpha, side_by_side={"auto": None, "serial": False, "side-by-side": True}[args.launch],
+                     run_octets=args.run_octets, stream_run_octets=args.stream_run_octets, beside_share=args.beside_share, low_column_build=not args.no_low_column_build)
     plan_stats = batch.plan_stats()
     blocks_per_step = batch.total_blocks()
     sync = torch.cuda.synchronize
@@ -636,7 +641,7 @@ def bench_compose(args, rank, world):
                               "its results coming down, the host's schedule (patterns -> octets -> runs), tables going up; once per plan, not inside the timed region; "
                               "in steps of the headline launch: %.1f" % (plan_stats["build_ms"]["total"] / mean_kern_ms))
         headline = (args.workload == "compose_1080p_batch" and args.regime == "A2" and args.tiles == "f32" and args.launch == "auto" and not args.no_group
-                    and not args.keep_zero_alpha and not args.images and world == 1)
+                    and not args.keep_zero_alpha and not args.images and world == 1 and not (args.beside_share or args.run_octets or args.stream_run_octets or args.no_low_column_build))
         if args.also == "auto" and headline:
             cfg = (width, height, dw, dh, mcu_x, mcu_y)
             t_also = time.perf_counter()

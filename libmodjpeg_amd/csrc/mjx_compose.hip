@@ -53,6 +53,15 @@ template <int N, class F> MJX_DEV void static_for(F &&f) { static_for_impl(std::
 
 MJX_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
+// The value again, but opaque to the optimiser: what is derived from it afterwards is computed afterwards.  Per-lane LDS offsets
+// (a lane's row in each of the images, the eight rotated weight rows ...) are loop-invariant, and the compiler keeps every one of them
+// in a register of its own across the whole run of octets - about thirty registers in the blend kernel, for arithmetic that costs two
+// or three instructions where it is used.
+MJX_DEV int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // row layout -> LDS: lane (b,v) writes its 8 registers as row v
 MJX_DEV void lds_put_row(float *img, int b, int r, const float (&a)[8]) {
     float4 *p = reinterpret_cast<float4 *>(img + b * kBlockStride + r * kRowStride);
@@ -572,7 +581,8 @@ MJX_DEV void octet_dc_only_rq(int16_t *cptr, const uint4 q4, const float (&rq)[8
 }
 
 // one octet whose operands have landed in (pC, pT, pA): registers, blend, store to cptr
-template <bool SZ0, bool LOWL>
+// FRESH (the lean build): the address of a weight row is derived when the row is reached (opaque(), above)
+template <bool SZ0, bool LOWL, bool FRESH = false>
 MJX_DEV void octet_compute(const DevJob &job, unsigned cblk, int lane, int b, int r, const float *qrow, const uint4 c4, const float4 t_lo, const float4 t_hi, const float4 a_lo,
                            const float4 a_hi, const float *pA, float *imgZ) {
     const uint4 q4 = *reinterpret_cast<const uint4 *>(qrow); // this lane's quant row, 8 x u16
@@ -604,8 +614,9 @@ MJX_DEV void octet_compute(const DevJob &job, unsigned cblk, int lane, int b, in
     else {
         octet_blend<SZ0, 8, true>(x, al, y,
                                   [&](int K, float (&wk)[8]) {
-                                      const float *wrow = pA + b * 64 + ((K + 2 * b) & 7) * 8;
-                                      const float4 lo = *reinterpret_cast<const float4 *>(wrow + 4 * ph), hi = *reinterpret_cast<const float4 *>(wrow + 4 - 4 * ph);
+                                      const int    bk = FRESH ? opaque(b) : b, pk = FRESH ? (bk >> 1) & 1 : ph;
+                                      const float *wrow = pA + bk * 64 + ((K + 2 * bk) & 7) * 8;
+                                      const float4 lo = *reinterpret_cast<const float4 *>(wrow + 4 * pk), hi = *reinterpret_cast<const float4 *>(wrow + 4 - 4 * pk);
                                       wk[0] = lo.x; wk[1] = lo.y; wk[2] = lo.z; wk[3] = lo.w; wk[4] = hi.x; wk[5] = hi.y; wk[6] = hi.z; wk[7] = hi.w;
                                   },
                                   imgZ, b, r); // compose.c:300-312
@@ -624,9 +635,20 @@ MJX_DEV void octet_compute(const DevJob &job, unsigned cblk, int lane, int b, in
 // into the kernel: tile = (float)coef exactly, weight = (float)((double)(float)coef * K) with the
 // reference's double constants, computed by the lane that holds the row and written into the same
 // rotated, half-swapped LDS image the float path's DMA fills.
-// LEAN: the build that shares a CU with the waves of compose_light_kernel (launch_compose(shared)): at most 144 registers, so
+// LEAN: the build that shares a CU with the waves of compose_light_shared_kernel (launch_compose(shared)): at most 144 registers, so
 // that three of its waves leave 80 of a SIMD's 512 to a wave of the other kernel - M_SQRT2 * (double)z_l[0] is recomputed per
 // term (+2 of ~31 instructions per term k >= 1) and the lane's chunk offsets per octet (+8 instructions).
+// MJX_LEAN_FRESH=1 (round 5, measured and not kept): every LDS offset that depends on the lane is derived where it is used instead
+// of once per run (opaque()): 116-120 registers instead of 142-144, which leaves a SIMD room for TWO stream waves of 72
+// (MJX_STREAM_WAVES_PER_SIMD=2).  Same box, alternating (profiles/r05/side_by_side_two_stream_waves.txt): the 120-register build
+// with one stream wave beside it is 3-4 % SLOWER than the 144-register one (A5 0.694 against 0.670 ms, A4 0.734 against 0.710),
+// with two stream waves 10 % slower (0.738 / 0.777), at every share of the stream runs.  A step of these plans is bound by the
+// vector ALU that both kernels share - the stream kernel's 136 instructions per octet over 84 % of the octets are a third of the
+// blend kernel's work - not by the stream waves' bytes in flight, so instructions added to either kernel cost time and more
+// stream waves only take issue slots from the blend waves earlier.
+#ifndef MJX_LEAN_FRESH
+#define MJX_LEAN_FRESH 0
+#endif
 template <bool I16, bool LEAN, bool LOWL = false>
 MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
     using WaveLds = WaveLdsT<LOWL>;
@@ -690,27 +712,35 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
         const int ahead = noct - 1 - i < MJX_DEPTH - 1 ? noct - 1 - i : MJX_DEPTH - 1; // octets i+1.. already in flight
         wait_vmcnt_n(kPieces * ahead + (i < MJX_DEPTH ? i : MJX_DEPTH));
 
-        float      *pC = L.C[sc], *pT = L.T[sc];
-        float      *pA = L.A[sa];
-        const uint4 c4 = *reinterpret_cast<const uint4 *>(pC + lane * 4);
+        // FR (MJX_LEAN_FRESH): everything that depends on the lane is derived afresh for every octet (opaque(): ~30 registers of
+        // loop-invariant LDS offsets less, ~20 instructions per octet more)
+        constexpr bool FR = LEAN && MJX_LEAN_FRESH;
+        const int      ln = FR ? opaque(lane) : lane;
+        const int      bb = FR ? ln >> 3 : b, rr = FR ? ln & 7 : r, phh = FR ? (bb >> 1) & 1 : ph;
+        const float   *qrow_i = FR ? L.Q + rr * kQuantRowDwords : qrow;
+        const int      k_src_i = FR ? (LOWL ? rr : (rr - 2 * bb) & 7) : k_src;
+        const double   k_first_i = FR ? (k_src_i == 0 ? kc0 : kc1) * kc0 / 1020.0 : k_first, k_rest_i = FR ? (k_src_i == 0 ? kc0 : kc1) * kc1 / 1020.0 : k_rest;
+        float       *pC = L.C[sc], *pT = L.T[sc];
+        float       *pA = L.A[sa];
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(pC + ln * 4);
         float4      t_lo, t_hi, a_lo, a_hi;
         uint4       ti4, ai4;
         if constexpr(I16) { // tile row r of this block; alpha source row k_src of this block (8 x int16 each)
-            ti4 = *reinterpret_cast<const uint4 *>(pT + lane * 4);
-            ai4 = *reinterpret_cast<const uint4 *>(pT + 256 + (b * 8 + k_src) * 4);
+            ti4 = *reinterpret_cast<const uint4 *>(pT + ln * 4);
+            ai4 = *reinterpret_cast<const uint4 *>(pT + 256 + (bb * 8 + k_src_i) * 4);
         }
         else {
-            t_lo = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4 * ph);
-            t_hi = *reinterpret_cast<const float4 *>(pT + lane * 8 + 4 - 4 * ph);
+            t_lo = *reinterpret_cast<const float4 *>(pT + ln * 8 + 4 * phh);
+            t_hi = *reinterpret_cast<const float4 *>(pT + ln * 8 + 4 - 4 * phh);
             if constexpr(LOWL) { // this lane's own row, weights of columns 0..3 (natural order): the skip ballots look at it
-                a_lo = *reinterpret_cast<const float4 *>(pA + lane * 4);
+                a_lo = *reinterpret_cast<const float4 *>(pA + ln * 4);
                 a_hi = a_lo;
             }
             else {
                 // the alpha row stored at row position r of this block = source row (r - 2b) & 7: only the
                 // skip ballots of octet_blend look at it (row_mask)
-                a_lo = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 * ph);
-                a_hi = *reinterpret_cast<const float4 *>(pA + lane * 8 + 4 - 4 * ph);
+                a_lo = *reinterpret_cast<const float4 *>(pA + ln * 8 + 4 * phh);
+                a_hi = *reinterpret_cast<const float4 *>(pA + ln * 8 + 4 - 4 * phh);
             }
         }
         // the JCOEF and tile slots are about to be overwritten by the DMA of octet i + DEPTH
@@ -719,7 +749,7 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
         int sn = sa + MJX_DEPTH; // alpha slot of octet i + DEPTH
         sn = sn > MJX_DEPTH ? sn - (MJX_DEPTH + 1) : sn;
         cp[MJX_DEPTH] = cp[0];
-        if(i + MJX_DEPTH < noct) cp[MJX_DEPTH] = (LEAN ? dma_octet_lean<I16> : dma_octet<I16, LOWL>)(job, rc, i + MJX_DEPTH, lane, addr, lds_addr(pC), lds_addr(pT), lds_addr(L.A[sn]));
+        if(i + MJX_DEPTH < noct) cp[MJX_DEPTH] = (LEAN ? dma_octet_lean<I16> : dma_octet<I16, LOWL>)(job, rc, i + MJX_DEPTH, ln, addr, lds_addr(pC), lds_addr(pT), lds_addr(L.A[sn]));
 
         if constexpr(I16) {
             const unsigned tw[4] = {ti4.x, ti4.y, ti4.z, ti4.w}, aw[4] = {ai4.x, ai4.y, ai4.z, ai4.w};
@@ -728,25 +758,25 @@ MJX_DEV void compose_body(const Run *__restrict__ runs, int nruns, const void *_
                 t[2 * P] = s16_lo_to_f32(tw[P]); // dropon.c:476-485: tile = (float)coef
                 t[2 * P + 1] = s16_hi_to_f32(tw[P]);
                 // dropon.c:548-566: weight = (float)((float)coef * K), K a double constant (the DC already carries +1024)
-                a[2 * P] = (float)((double)s16_lo_to_f32(aw[P]) * (P == 0 ? k_first : k_rest));
-                a[2 * P + 1] = (float)((double)s16_hi_to_f32(aw[P]) * k_rest);
+                a[2 * P] = (float)((double)s16_lo_to_f32(aw[P]) * (P == 0 ? k_first_i : k_rest_i));
+                a[2 * P + 1] = (float)((double)s16_hi_to_f32(aw[P]) * k_rest_i);
             });
             t_lo = make_float4(t[0], t[1], t[2], t[3]);
             t_hi = make_float4(t[4], t[5], t[6], t[7]);
             a_lo = make_float4(a[0], a[1], a[2], a[3]);
             if constexpr(LOWL) { // the natural image of the low-column build: block b row k at (8b + k) * 16 bytes, columns 0..3 (the others hold no weight)
                 a_hi = a_lo;
-                *reinterpret_cast<float4 *>(pA + lane * 4) = a_lo;
+                *reinterpret_cast<float4 *>(pA + ln * 4) = a_lo;
             }
             else {
                 a_hi = make_float4(a[4], a[5], a[6], a[7]);
                 // the float image the broadcast weight reads expect: this row at position r, halves swapped per block
-                *reinterpret_cast<float4 *>(pA + lane * 8 + 4 * ph) = a_lo;
-                *reinterpret_cast<float4 *>(pA + lane * 8 + 4 - 4 * ph) = a_hi;
+                *reinterpret_cast<float4 *>(pA + ln * 8 + 4 * phh) = a_lo;
+                *reinterpret_cast<float4 *>(pA + ln * 8 + 4 - 4 * phh) = a_hi;
             }
             wave_sync();
         }
-        octet_compute<!LEAN && !LOWL && MJX_SZ0_CACHE, LOWL>(job, cp[0], lane, b, r, qrow, c4, t_lo, t_hi, a_lo, a_hi, pA, L.Z);
+        octet_compute<!LEAN && !LOWL && MJX_SZ0_CACHE, LOWL, FR>(job, cp[0], ln, bb, rr, qrow_i, c4, t_lo, t_hi, a_lo, a_hi, pA, L.Z);
 
         static_for<MJX_DEPTH>([&](auto D) { cp[D] = cp[D + 1]; });
         sc = sc + 1 == MJX_DEPTH ? 0 : sc + 1;
@@ -772,7 +802,7 @@ __global__ __launch_bounds__(64 * MJX_GROUP_WAVES, 4) void compose_lowl_i16_kern
 }
 // (amdgpu_num_vgpr counts the architected half of the unified register file: 72 = 144 registers per lane)
 template <bool I16>
-__global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) __attribute__((amdgpu_num_vgpr(72))) void compose_lean_kernel(const Run *__restrict__ runs, int nruns,
+__global__ __launch_bounds__(64 * MJX_GROUP_WAVES, MJX_COMPOSE_MIN_WAVES) __attribute__((amdgpu_num_vgpr(MJX_LEAN_FRESH ? 60 : 72))) void compose_lean_kernel(const Run *__restrict__ runs, int nruns,
                                                                                                                                 const void *__restrict__ qrq) {
     compose_body<I16, true>(runs, nruns, qrq);
 }
@@ -1007,7 +1037,15 @@ MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
     }
 }
 
-// octets in flight per wave in the kernel that runs beside the blend kernel (80 registers: more does not fit) ...
+// The kernel that runs beside the blend kernel: three lean blend waves of 144 registers leave a SIMD 80, i.e. ONE wave of this
+// kernel.  MJX_STREAM_WAVES_PER_SIMD=2 (with MJX_LEAN_FRESH=1: the lean build in 120 registers leaves 152, i.e. two waves of 72 -
+// registers are handed out in eights, so 76 would not do) was measured in round 5 and is slower: see MJX_LEAN_FRESH.
+#ifndef MJX_STREAM_WAVES_PER_SIMD
+#define MJX_STREAM_WAVES_PER_SIMD 1
+#endif
+// octets in flight per wave (more do not fit the registers without spilling) ...
+#if MJX_STREAM_WAVES_PER_SIMD == 1
+#define MJX_STREAM_VGPR_CAP 40 /* amdgpu_num_vgpr counts the architected half of the unified register file: 40 = 80 registers per lane */
 #ifndef MJX_STREAM_DEPTH_ZA
 #define MJX_STREAM_DEPTH_ZA 8
 #endif
@@ -1016,6 +1054,18 @@ MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
 #endif
 #ifndef MJX_STREAM_DEPTH_DC_F32
 #define MJX_STREAM_DEPTH_DC_F32 3
+#endif
+#else
+#define MJX_STREAM_VGPR_CAP 36 /* 72 registers per lane */
+#ifndef MJX_STREAM_DEPTH_ZA
+#define MJX_STREAM_DEPTH_ZA 7
+#endif
+#ifndef MJX_STREAM_DEPTH_DC_I16
+#define MJX_STREAM_DEPTH_DC_I16 3
+#endif
+#ifndef MJX_STREAM_DEPTH_DC_F32
+#define MJX_STREAM_DEPTH_DC_F32 2
+#endif
 #endif
 // ... and in the kernel that has the device to itself (8 waves per SIMD)
 #ifndef MJX_LIGHT_DEPTH_ZA
@@ -1068,11 +1118,9 @@ __global__ __launch_bounds__(256) MJX_LIGHT_ATTR void compose_light_kernel(const
     compose_light_stream<I16, false>(runs, ridx < nruns ? ridx + 1 : 0, qrq, ridx, 1 << 30); // this wave's one run
 #endif
 }
-// (amdgpu_num_vgpr counts the architected half of the unified register file: 40 = 80 registers per lane; three octets of int16
-// tiles or two of float tiles in flight fit without spilling)
 template <bool I16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(40))) void compose_light_shared_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
-    // few long-lived workgroups (launch_compose_light_pair: one per CU): each wave takes every (4 x gridDim.x)-th run
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MJX_STREAM_VGPR_CAP))) void compose_light_shared_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
+    // few long-lived workgroups (launch_compose_light_pair: MJX_STREAM_WAVES_PER_SIMD per CU): each wave takes every (4 x gridDim.x)-th run
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     compose_light_stream<I16, true>(runs, nruns, qrq, blockIdx.x * 4 + wave, gridDim.x * 4);
 }
@@ -1094,7 +1142,8 @@ int launch_compose_light_pair(const Run *runs, int nruns, int nbeside, const voi
     if(nbeside > 0) {
         int dev = 0, cus = 256;
         if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        const unsigned g = (unsigned)((nbeside + 3) / 4 < cus ? (nbeside + 3) / 4 : cus);
+        const int      want = cus * MJX_STREAM_WAVES_PER_SIMD; // a workgroup is four waves, one per SIMD
+        const unsigned g = (unsigned)((nbeside + 3) / 4 < want ? (nbeside + 3) / 4 : want);
         if(tiles_i16) hipLaunchKernelGGL(compose_light_shared_kernel<true>, dim3(g), dim3(256), 0, beside, runs, nbeside, qrq);
         else hipLaunchKernelGGL(compose_light_shared_kernel<false>, dim3(g), dim3(256), 0, beside, runs, nbeside, qrq);
         if(int e = check_hip(hipGetLastError(), "compose_light_shared_kernel launch", MJX_ERR_LAUNCH)) return e;
