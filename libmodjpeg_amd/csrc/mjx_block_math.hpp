@@ -80,7 +80,8 @@ template <int L> MJX_DEV void hstage(const float (&x)[8], double sx0, float (&z)
 
 // ---- V stage: y[v] += T_K(z)[v] * w for one column (reference convolve.c:567-1096) ---------
 // sz0 = M_SQRT2 * (double)z[0], hoisted by the caller (used by every K >= 1 at v == K).
-template <int K, int V> MJX_DEV float vstage_elem(float y, const float (&z)[8], double sz0, float w, double wd, double w2d) {
+// (z: anything indexable by a constant row 0..7 - an array of 8 floats, or one half of the paired storage below)
+template <int K, int V, class Z> MJX_DEV float vstage_elem(float y, const Z &z, double sz0, float w, double wd, double w2d) {
     if constexpr(K == 0) {
         // y = (float)((double)y + (2.0 * (double)z) * (double)w)
         // 2.0*z is exact; (2z)*w is a 24x24-bit product, exact in double and inside double's
@@ -131,7 +132,7 @@ MJX_DEV void vstage_first(float (&y)[8], const float (&z)[8], float w) {
     y[7] = __builtin_fmaf(z[7], w2, 0.0f);
 }
 
-template <int K> MJX_DEV void vstage(float (&y)[8], const float (&z)[8], double sz0, float w) {
+template <int K, class Z> MJX_DEV void vstage(float (&y)[8], const Z &z, double sz0, float w) {
     const double wd = (double)w;
     const double w2d = wd + wd; // 2.0 * (double)w, exact
     y[0] = vstage_elem<K, 0>(y[0], z, sz0, w, wd, w2d);
@@ -142,6 +143,52 @@ template <int K> MJX_DEV void vstage(float (&y)[8], const float (&z)[8], double 
     y[5] = vstage_elem<K, 5>(y[5], z, sz0, w, wd, w2d);
     y[6] = vstage_elem<K, 6>(y[6], z, sz0, w, wd, w2d);
     y[7] = vstage_elem<K, 7>(y[7], z, sz0, w, wd, w2d);
+}
+
+
+// ---- two terms of one k-row at once: (K, L) and (K, L + 1), K >= 1 -----------------------------
+// The six rows v not in {0, K} of a term are three f32 operations each (t = z[a] +- z[b]; p = t * w; y += p: convolve.c:567-1096),
+// over a third of the blend's issue time.  With z of two adjacent l stored as a register PAIR, zz[v] = {z_L[v], z_L+1[v]}, the
+// first two operations of both terms are one packed instruction each (v_pk_add_f32, v_pk_mul_f32: one IEEE rounding per half, the
+// same value as the scalar instruction gives) and only the two accumulations, which the reference orders l inside k, stay scalar:
+// 4 instructions instead of 6 per row, and a packed f32 instruction issues in 4.5 cycles against 2 x 2.95 for the two it stands
+// for (profiles/r01_final/valu_rate_ubench.txt).  Rows 0 and K are double precision as in vstage_elem, term L first, then L + 1.
+// The caller takes this path only for octets whose z are all finite and far from overflow, where a term whose weight is zero in
+// some block adds +-0 to y there (t * 0 with t finite), which (int)Y cannot see: no per-term guard is needed.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int H> struct ZHalf { // z of l = 2j + H as the scalar code sees it
+    const f32x2 (&zz)[8];
+    MJX_DEV float operator[](int v) const { return zz[v][H]; }
+};
+
+template <int K, int V> MJX_DEV float vstage_pair_elem(float y, const f32x2 (&zz)[8], double sz0a, double sz0b, f32x2 w2, double wda, double wdb) {
+    static_assert(K >= 1, "terms of k = 0 are double precision in every row");
+    if constexpr(V == 0 || V == K) {
+        y = vstage_elem<K, V>(y, ZHalf<0>{zz}, sz0a, w2.x, wda, 0.0);
+        return vstage_elem<K, V>(y, ZHalf<1>{zz}, sz0b, w2.y, wdb, 0.0);
+    }
+    else {
+        using R = Refl<K, V>;
+        f32x2 t = zz[R::first];
+        if constexpr(R::sign > 0) t = t + zz[R::idx];
+        if constexpr(R::sign < 0) t = t - zz[R::idx];
+        const f32x2 p = t * w2;
+        y = y + p.x;
+        return y + p.y;
+    }
+}
+
+template <int K> MJX_DEV void vstage_pair(float (&y)[8], const f32x2 (&zz)[8], double sz0a, double sz0b, f32x2 w2) {
+    const double wda = (double)w2.x, wdb = (double)w2.y;
+    y[0] = vstage_pair_elem<K, 0>(y[0], zz, sz0a, sz0b, w2, wda, wdb);
+    y[1] = vstage_pair_elem<K, 1>(y[1], zz, sz0a, sz0b, w2, wda, wdb);
+    y[2] = vstage_pair_elem<K, 2>(y[2], zz, sz0a, sz0b, w2, wda, wdb);
+    y[3] = vstage_pair_elem<K, 3>(y[3], zz, sz0a, sz0b, w2, wda, wdb);
+    y[4] = vstage_pair_elem<K, 4>(y[4], zz, sz0a, sz0b, w2, wda, wdb);
+    y[5] = vstage_pair_elem<K, 5>(y[5], zz, sz0a, sz0b, w2, wda, wdb);
+    y[6] = vstage_pair_elem<K, 6>(y[6], zz, sz0a, sz0b, w2, wda, wdb);
+    y[7] = vstage_pair_elem<K, 7>(y[7], zz, sz0a, sz0b, w2, wda, wdb);
 }
 
 // ---- integer steps ---------------------------------------------------------------------

@@ -118,6 +118,107 @@ constexpr unsigned long long row_mask(int K) {
 // NL: columns l of weights the octet can have at all: 8, or 4 in the build for runs whose weights all lie in columns 0..3
 // (compose_lowl_kernel): half the z_l, i.e. 32 registers less.  ROT: the alpha rows of block b are stored rotated by 2b
 // (the landing layout of the full-width alpha pieces); the low-column build stores them in natural order.
+// MJX_PK_F32=1: pairs of adjacent terms of a k-row through packed f32 instructions (mjx_block_math.hpp: vstage_pair; VERDICT r04
+// item 6).  Bit-exact in every parity test, and slower in every regime (round 5, same box, alternating, three rounds:
+// profiles/r05/packed_f32_pairs_ab.txt): A3 2.53 -> 2.67 ms, A5 0.686 -> 0.742, A4 0.716 -> 0.787, A2 0.752 -> 0.788.  The
+// counters (profiles/r05/packed_f32_pairs_sq_counters_A3.txt) show what was asked for - 2 273 -> 1 983 VALU instructions per dense
+// octet, f32 add 659 -> 515, f32 mul 344 -> 176 - but the launch's cycles go UP 11 %: in this instruction mix (three waves per
+// SIMD taking turns on f64, conversion and f32 instructions) a packed f32 instruction costs more than the two it replaces, as it
+// did when the compiler's SLP vectoriser formed the pairs (round 1: -fno-slp-vectorize), and the pair / scalar choice per pair of
+// terms adds 350 scalar instructions per octet.  Kept for the record, off.
+#ifndef MJX_PK_F32
+#define MJX_PK_F32 0
+#endif
+#if MJX_PK_F32
+template <bool SZ0, int NL, bool ROT, class WRow>
+MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[NL], float (&yrow)[8], WRow &&weight_row, float *imgZ, int b, int r) {
+    // which terms does this octet need?  bit (8b + rp) of m[l] <=> alpha_b[(rp - 2b) & 7][l] != 0
+    unsigned long long m[NL];
+    static_for<NL>([&](auto L) { m[L] = __ballot(al[L] != 0.0f); });
+
+    // H stage in row layout, z_l moved to column layout through LDS, only for the columns l that
+    // some block of the octet uses; z[l] of the others stays undefined and is never consumed (its
+    // terms all have w == 0).  The round trips of consecutive l overlap: DS operations of one wave
+    // execute in order, so the next put_row may be issued before this get_col has returned.
+    // z of l = 2j and l = 2j + 1 share a register pair: zz[j][v] = {z_2j[v], z_2j+1[v]} (vstage_pair)
+    f32x2        zz[NL / 2][8];
+    const double sx0 = kSqrt2 * (double)x[0];
+    double       sz0[SZ0 ? NL : 1]; // M_SQRT2 * (double)z_l[0], used by the row v == k of every term (k >= 1, l)
+    static_for<NL>([&](auto L) {
+        if(m[L] != 0ull) {
+            float zr[8], zc[8];
+            hstage<L>(x, sx0, zr);
+            lds_put_row(imgZ, b, r, zr);
+            wave_sync();
+            lds_get_col(imgZ, b, r, zc);
+            wave_sync();
+            static_for<8>([&](auto V) { zz[L / 2][V][L % 2] = zc[V]; });
+            if constexpr(SZ0) sz0[L] = kSqrt2 * (double)zc[0];
+        }
+    });
+    // every x finite and below 2^120 in magnitude: every z and every t = z +- z' is finite (|t| <= 4.9 max|x|), so a term whose
+    // weight is zero in some block adds +-0 there, and the pair path needs no per-term guard.  (Octets with NaN, infinite or
+    // astronomically large tiles take the scalar path, which skips exactly like convolve.c:32.)
+    const float xmax = fmaxf(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))), fmaxf(fmaxf(fabsf(x[4]), fabsf(x[5])), fmaxf(fabsf(x[6]), fabsf(x[7]))));
+    bool        all_x = true;
+    static_for<8>([&](auto U) { all_x = all_x && (x[U] == x[U]); }); // (fmaxf drops a NaN operand)
+    // (`tame` is the same in every lane, but it is kept in a form the compiler takes for lane-dependent: a uniform branch between the
+    // pair path and the two scalar terms gets eight register moves on each side, where the accumulators y change registers - more
+    // than the packed instructions save; lane-dependent branches update y in place under the execution mask, as the `w != 0` guards do)
+    const bool tame = (__ballot(!(all_x && xmax < 0x1p120f)) == 0ull) && opaque(1) != 0;
+
+    // V stage in column layout: k outer, l inner, as reference compose.c:303-312.  Rows of alpha
+    // that are zero in every block of the octet are skipped as a whole (scalar test); inside a row
+    // each term is guarded per block by `w != 0` (convolve.c:32) and the compiler's execz skip.
+    unsigned long long any = 0ull;
+    static_for<NL>([&](auto L) { any |= m[L]; });
+    float y[8];
+    static_for<8>([&](auto V) { y[V] = 0.0f; });
+    static_for<8>([&](auto K) {
+        constexpr unsigned long long kRowK = ROT ? row_mask(K) : 0x0101010101010101ull << K;
+        if((any & kRowK) != 0ull) {
+            float wk[NL];
+            weight_row(K, wk); // alpha_b[K][0..NL-1], broadcast inside the block
+            auto term = [&](auto L) {
+                const float w = wk[L];
+                if(w != 0.0f) {
+                    const ZHalf<L % 2> z{zz[L / 2]};
+                    if constexpr(K == 0 && L == 0) {
+                        const float z0[8] = {z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]};
+                        vstage_first(y, z0, w);
+                    }
+                    else {
+                        if constexpr(SZ0) vstage<K>(y, z, K == 0 ? 0.0 : sz0[L], w);
+                        else vstage<K>(y, z, K == 0 ? 0.0 : kSqrt2 * (double)z[0], w);
+                    }
+                }
+            };
+            static_for<NL / 2>([&](auto J) {
+                constexpr int L0 = 2 * J, L1 = 2 * J + 1;
+                if constexpr(K >= 1) {
+                    // both terms occur in this octet (wave-uniform): one pass over the rows for the two of them
+                    if(tame && (m[L0] & kRowK) != 0ull && (m[L1] & kRowK) != 0ull) {
+                        const f32x2 w2 = {wk[L0], wk[L1]};
+                        if(w2.x != 0.0f || w2.y != 0.0f) {
+                            if constexpr(SZ0) vstage_pair<K>(y, zz[J], sz0[L0], sz0[L1], w2);
+                            else vstage_pair<K>(y, zz[J], kSqrt2 * (double)zz[J][0].x, kSqrt2 * (double)zz[J][0].y, w2);
+                        }
+                        return;
+                    }
+                }
+                term(std::integral_constant<int, L0>{});
+                term(std::integral_constant<int, L1>{});
+            });
+        }
+    });
+
+    // back to row layout for the integer tail and the store
+    lds_put_col_y(imgZ, b, r, y);
+    wave_sync();
+    lds_get_row_y(imgZ, b, r, yrow);
+    wave_sync();
+}
+#else
 template <bool SZ0, int NL, bool ROT, class WRow>
 MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[NL], float (&yrow)[8], WRow &&weight_row, float *imgZ, int b, int r) {
     // which terms does this octet need?  bit (8b + rp) of m[l] <=> alpha_b[(rp - 2b) & 7][l] != 0
@@ -176,6 +277,7 @@ MJX_DEV void octet_blend(const float (&x)[8], const float (&al)[NL], float (&yro
     lds_get_row_y(imgZ, b, r, yrow);
     wave_sync();
 }
+#endif
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
