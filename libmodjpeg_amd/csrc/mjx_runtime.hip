@@ -94,6 +94,22 @@ using namespace mjx;
 // schedules: which blocks share a wavefront, and in which order the wavefronts are dispatched
 // ------------------------------------------------------------------------------------------
 namespace {
+// storage that is filled by a copy from the device: not zeroed first (a vector's resize would pass over tens of megabytes twice)
+template <class T> struct RawBuf {
+    T *p = nullptr;
+    ~RawBuf() { free(p); }
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    bool     resize(size_t n) {
+        free(p);
+        p = static_cast<T *>(malloc((n ? n : 1) * sizeof(T)));
+        return p != nullptr;
+    }
+    T       *data() { return p; }
+    const T *data() const { return p; }
+};
+
 // a stretch of octets of one job that are alike (same kind, same cost class)
 struct Segment {
     int32_t kind;    // RunKind
@@ -656,7 +672,7 @@ static int32_t us_since(std::chrono::steady_clock::time_point t0) {
 
 // us (optional): [0] the scan on the device, [1] the patterns coming down (large scans only: the small ones are one queue of
 // upload, kernel and download whose parts the host cannot tell apart, counted under [0])
-int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<uint32_t> &w00, mjx_stream_t after, int32_t *us = nullptr) {
+int scan_patterns(const Tables &t, RawBuf<uint64_t> &pattern, RawBuf<uint32_t> &w00, mjx_stream_t after, int32_t *us = nullptr) {
     const auto t_start = std::chrono::steady_clock::now();
     std::vector<Run> tmp;
     for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
@@ -671,8 +687,7 @@ int scan_patterns(const Tables &t, std::vector<uint64_t> &pattern, std::vector<u
             tmp.push_back(r);
         }
     }
-    pattern.resize((size_t)t.blocks);
-    w00.resize((size_t)t.blocks);
+    if(!pattern.resize((size_t)t.blocks) || !w00.resize((size_t)t.blocks)) return MJX_ERR_MEMORY;
     const size_t run_bytes = round256(tmp.size() * sizeof(Run)), pat_bytes = round256((size_t)t.blocks * sizeof(uint64_t)), w_bytes = (size_t)t.blocks * sizeof(uint32_t);
     if(run_bytes + pat_bytes + w_bytes <= ((size_t)12 << 20)) {
         // the usual case (the tiles of one overlay): through a pooled staging arena, no hipMalloc / hipFree
@@ -827,11 +842,21 @@ int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t
     }
 
     const auto t_call = std::chrono::steady_clock::now();
+    // (test build: MJX_PLAN_DEBUG=1 prints where the call's time goes)
+    static const bool plan_debug = tuning_env("MJX_PLAN_DEBUG") != nullptr;
+    auto              t_lap = t_call;
+    auto              lap = [&](const char *what) {
+        if(!plan_debug) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "mjx plan: %-28s %8.3f ms\n", what, (double)std::chrono::duration_cast<std::chrono::microseconds>(now - t_lap).count() / 1e3);
+        t_lap = now;
+    };
     Tables t;
     t.opt = *opts;
     int    err = build_tables(jobs, njobs, qtables, nq, tiles_i16, t);
     if(err != MJX_OK) return err;
 
+    lap("build_tables");
     mjx_compose_plan *p = new(std::nothrow) mjx_compose_plan;
     if(p == nullptr) return MJX_ERR_MEMORY;
     (void)hipGetDevice(&p->device);
@@ -845,9 +870,10 @@ int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t
             // one pass over the alpha tiles as they are now; the grouping only decides which blocks share
             // a wavefront (results do not depend on it) - except that with MJX_PLAN_ALPHA_IS_FINAL blocks
             // without weights leave their tiles behind, which is why that needs the caller's promise
-            std::vector<uint64_t> pattern;
-            std::vector<uint32_t> w00;
+            RawBuf<uint64_t> pattern;
+            RawBuf<uint32_t> w00;
             if((err = scan_patterns(t, pattern, w00, nullptr, p->build_us)) != MJX_OK) break; // after the legacy default stream (mjx.h)
+            lap("scan + download");
             // The jobs' schedules are independent (each looks at its own blocks' patterns only), and a batch has thousands of them
             // (4096 images x 3 components: 6.3 M patterns, 40-50 ms on one thread): host threads take contiguous shares of the jobs,
             // each job's gather octets are numbered from 0 and moved behind the plan's table afterwards.
@@ -869,37 +895,54 @@ int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t
             unsigned nthreads = std::thread::hardware_concurrency();
             nthreads = nthreads > 16 ? 16 : (nthreads < 1 ? 1 : nthreads);
             if((int64_t)nthreads * 100000 > t.blocks) nthreads = (unsigned)(t.blocks / 100000); // a thread's start costs what 100 000 patterns do
-            if(nthreads > 1) {
+            // run `work(lo, hi)` over contiguous shares of the jobs on host threads (here too when no thread can be had)
+            auto on_threads = [&](auto &&work) {
+                if(nthreads <= 1) return work(0, njobs_dev);
                 std::vector<std::thread> pool;
-                bool                     spawned = true;
                 try {
-                    for(unsigned k = 0; k < nthreads; ++k) pool.emplace_back(share, (int)((int64_t)njobs_dev * k / nthreads), (int)((int64_t)njobs_dev * (k + 1) / nthreads));
+                    for(unsigned k = 0; k < nthreads; ++k) pool.emplace_back(work, (int)((int64_t)njobs_dev * k / nthreads), (int)((int64_t)njobs_dev * (k + 1) / nthreads));
                 } catch(...) { // no more threads to be had: the jobs the started ones do not cover are done here
-                    spawned = false;
                 }
                 const int done_to = (int)((int64_t)njobs_dev * pool.size() / nthreads);
-                if(!spawned) share(done_to, njobs_dev);
+                if(done_to < njobs_dev) work(done_to, njobs_dev);
                 for(std::thread &th : pool) th.join();
+            };
+            on_threads(share);
+            lap("schedule_tiles (threads)");
+            // the jobs' gather octets behind the plan's table: where each job's start, then the threads copy
+            std::vector<size_t> base((size_t)njobs_dev + 1);
+            base[0] = t.gather.size();
+            size_t nsegs = 0;
+            for(int jid = 0; jid < njobs_dev; ++jid) {
+                base[(size_t)jid + 1] = base[(size_t)jid] + per[(size_t)jid].gather.size();
+                nsegs += per[(size_t)jid].segs.size();
             }
-            else {
-                share(0, njobs_dev);
-            }
+            t.gather.resize(base[(size_t)njobs_dev]);
+            on_threads([&](int lo, int hi) {
+                for(int jid = lo; jid < hi; ++jid) {
+                    std::vector<int32_t> &g = per[(size_t)jid].gather;
+                    if(!g.empty()) memcpy(t.gather.data() + base[(size_t)jid], g.data(), g.size() * sizeof(int32_t));
+                    std::vector<int32_t>().swap(g);
+                }
+            });
             std::vector<JobSegment> all;
+            all.reserve(nsegs);
             for(int jid = 0; jid < njobs_dev; ++jid) {
                 JobSched &o = per[(size_t)jid];
-                const int base = (int)(t.gather.size() / kWaveBlocks);
+                const int first_octet = (int)(base[(size_t)jid] / kWaveBlocks);
                 for(Segment sg : o.segs) {
-                    if(sg.kind != kRunConsecutive) sg.first += base;
+                    if(sg.kind != kRunConsecutive) sg.first += first_octet;
                     all.push_back(JobSegment{jid, -1, sg});
                 }
-                t.gather.insert(t.gather.end(), o.gather.begin(), o.gather.end());
                 t.stats.add(o.st);
-                std::vector<int32_t>().swap(o.gather);
             }
+            lap("merge");
             cut_runs(t, all);
+            lap("cut_runs");
         }
         else {
             plain_runs(t);
+            lap("plain_runs");
         }
         // side by side, the lean build of the blend kernel takes every blended run (the low-column build would fill the registers
         // the stream kernel needs)
@@ -924,6 +967,7 @@ int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t
             t.runs.insert(t.runs.end(), t.lowl.begin(), t.lowl.end());
             t.lowl.clear();
         }
+        lap("share, low-column choice");
         p->build_us[2] = us_since(t_call) - p->build_us[0] - p->build_us[1]; // (build_tables included)
         const auto t_up = std::chrono::steady_clock::now();
         p->nruns = (int)t.runs.size();
@@ -939,6 +983,7 @@ int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t
             if((err = check_hip(hipMalloc((void **)&p->d_gather, t.gather.size() * sizeof(int32_t)), "hipMalloc(gather)", MJX_ERR_MEMORY))) break;
             if((err = check_hip(hipMemcpy(p->d_gather, t.gather.data(), t.gather.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(gather)", MJX_ERR_LAUNCH))) break;
         }
+        lap("upload q, gather");
         std::vector<Run> runs(t.runs.size() + t.lowl.size() + t.light.size());
         expand_runs(t, t.runs, runs.data(), p->d_gather, nullptr);
         expand_runs(t, t.lowl, runs.data() + t.runs.size(), p->d_gather, nullptr);
@@ -953,6 +998,7 @@ int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t
             if((err = check_hip(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH))) break;
             if((err = check_hip(hipEventCreateWithFlags(&p->join, hipEventDisableTiming), "hipEventCreate", MJX_ERR_LAUNCH))) break;
         }
+        lap("expand + upload runs, events");
         p->build_us[3] = us_since(t_up);
     } while(0);
     p->build_us[4] = us_since(t_call);
@@ -1052,9 +1098,9 @@ int mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha, int
     d.inv_cols = 1.0f / (float)cols;
     t.jobs.push_back(d);
     t.blocks = d.nblocks;
-    std::vector<uint64_t> pattern;
-    std::vector<uint32_t> w00;
-    int                   err = scan_patterns(t, pattern, w00, after);
+    RawBuf<uint64_t> pattern;
+    RawBuf<uint32_t> w00;
+    int              err = scan_patterns(t, pattern, w00, after);
     if(err != MJX_OK) return err;
     mjx_tile_schedule *s = new(std::nothrow) mjx_tile_schedule;
     if(s == nullptr) return MJX_ERR_MEMORY;
