@@ -982,13 +982,13 @@ bool zero_planes(char *const *ptr, const size_t *len, int ncomp, hipStream_t s, 
 // all lane / all wave / lane first: 1080p quality 85 (4 000 chunks) 0.45-0.58 / 0.17-0.21 / -;  4K quality 95 (28 700) 0.75 / 0.65 /
 // 0.51 (3 lane rounds);  8K quality 85 (62 700) 0.77 / 1.12 / 0.66 (3), 0.65 (4).  Hence: up to kWaveChunkLimit chunks in a batch every
 // round runs one wavefront per chunk; above it the first 3 rounds (4 above four times the limit) run one lane per chunk.
-// MJX_DECODE_ROUNDS overrides the choice (the one documented switch; the parity tests walk every form with it):
+// MJX_OPTIONS=decode-rounds=... overrides the choice (the parity tests walk every form with it):
 //   "wave"    every round one wavefront per chunk        "lane"    every round one lane per chunk
 //   "lane:N"  N rounds one lane per chunk, then wavefronts
 constexpr long long kWaveChunkLimit = 16384;
 int lane_rounds_override() { // -1: none
     static const int n = [] {
-        const char *e = getenv("MJX_DECODE_ROUNDS");
+        const char *e = option("decode-rounds");
         if(e == nullptr || e[0] == 0) return -1;
         if(strcmp(e, "wave") == 0) return 0;
         if(strcmp(e, "lane") == 0) return 1 << 20;

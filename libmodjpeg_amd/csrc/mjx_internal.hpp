@@ -68,13 +68,22 @@ struct DevDcJob {
 // Experiment and trace switches (run lengths, batches in flight, stage timings on stderr ...) exist only in the TEST build of the
 // library (libmjx_hip_faultinj.so: every source compiled with -DMJX_TEST_BUILD, __graft_entry__.build_hip); in the product build
 // tuning_env() is a constant nullptr, the tuned values are constants and the trace code is compiled out.  What the product reads
-// from the environment is documented in INTEGRATION.md: MJX_WAIT, MJX_ARENAS, MJX_SIDE_BY_SIDE, MJX_DECODE_ROUNDS,
-// MJX_COMPOSE_COPIES, MJX_EFFECT_COPIES.
+// from the environment is ONE variable, MJX_OPTIONS (option(), below).
 #ifdef MJX_TEST_BUILD
 inline const char *tuning_env(const char *name) { return getenv(name); }
 #else
 inline const char *tuning_env(const char *) { return nullptr; }
 #endif
+
+// The ONE environment variable the product library reads: MJX_OPTIONS = comma-separated list of
+//   wait=block          host threads sleep in hipStreamSynchronize instead of spinning (many threads on few cores); before first use
+//   arenas=N            staging arenas (each owns a stream) in use at most, 1 .. 64, default 32
+//   decode-rounds=wave | lane | lane:N   how the entropy decoder walks its synchronisation rounds (mjx_huffdec.hip; the parity tests
+//                       force every form; default: by the size of the batch)
+//   compose-copies, effect-copies        the per-image host-buffer calls always stage through device memory instead of letting the
+//                       kernels work in mapped pinned memory (tests compare the two forms)
+// option("name"): nullptr when absent, else the text after '=' ("" for a bare token).  Parsed once; unknown tokens are reported once.
+const char *option(const char *name);
 
 // host helpers (mjx_runtime.hip)
 int   check_hip(hipError_t e, const char *what, int err_code);

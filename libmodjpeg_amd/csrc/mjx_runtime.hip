@@ -53,6 +53,41 @@ int check_hip(hipError_t e, const char *what, int err_code) {
     return err_code;
 }
 
+const char *option(const char *name) {
+    static const char *const known[] = {"wait", "arenas", "decode-rounds", "compose-copies", "effect-copies"};
+    constexpr int            kKnown = 5;
+    struct Parsed {
+        const char *value[kKnown] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        std::vector<char> text; // the variable's text, tokens terminated in place
+        Parsed() {
+            const char *e = getenv("MJX_OPTIONS");
+            if(e == nullptr) return;
+            text.assign(e, e + strlen(e) + 1);
+            for(char *t = text.data(); *t != 0;) {
+                char *end = strchr(t, ',');
+                char *next = end != nullptr ? end + 1 : t + strlen(t);
+                if(end != nullptr) *end = 0;
+                char *eq = strchr(t, '=');
+                if(eq != nullptr) *eq = 0;
+                bool hit = *t == 0;
+                for(int i = 0; i < kKnown && !hit; ++i) {
+                    if(strcmp(t, known[i]) == 0) {
+                        value[i] = eq != nullptr ? eq + 1 : t + strlen(t);
+                        hit = true;
+                    }
+                }
+                if(!hit) fprintf(stderr, "libmjx_hip: MJX_OPTIONS: unknown option \"%s\" ignored\n", t);
+                t = next;
+            }
+        }
+    };
+    static const Parsed parsed;
+    for(int i = 0; i < kKnown; ++i) {
+        if(strcmp(name, known[i]) == 0) return parsed.value[i];
+    }
+    return nullptr;
+}
+
 bool ensure_device() {
     static std::atomic<int> state{0}; // 0 unknown, 1 ok, -1 none
     int                     s = state.load();
@@ -60,10 +95,10 @@ bool ensure_device() {
         int        n = 0;
         hipError_t e = hipGetDeviceCount(&n);
         s = (e == hipSuccess && n > 0) ? 1 : -1;
-        // MJX_WAIT=block: host threads sleep in hipStreamSynchronize instead of spinning (many
+        // MJX_OPTIONS=wait=block: host threads sleep in hipStreamSynchronize instead of spinning (many
         // threads on few cores); must be set before the device is first used by this process
         if(s > 0) {
-            const char *w = getenv("MJX_WAIT");
+            const char *w = option("wait");
             if(w != nullptr && w[0] == 'b') (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
         }
         if(s < 0) {
@@ -1230,11 +1265,11 @@ pthread_cond_t  g_pool_free = PTHREAD_COND_INITIALIZER;
 
 // borrow an arena that already lives on the calling thread's device if there is one, else an
 // unused slot; blocks while all slots are busy
-// arenas in use at most (MJX_ARENAS, default 32; created on first use, so a program with few threads has few): each owns a stream, and more streams than
+// arenas in use at most (MJX_OPTIONS=arenas=N, default 32; created on first use, so a program with few threads has few): each owns a stream, and more streams than
 // hardware queues buy no further overlap
 int arena_limit() {
         static const int n = [] {
-            const char *e = getenv("MJX_ARENAS");
+            const char *e = option("arenas");
             const int   v = e ? atoi(e) : 32;
             return v < 1 ? 1 : (v > kMaxArenas ? kMaxArenas : v);
         }();
@@ -1418,8 +1453,8 @@ int mjx_compose_host(const mjx_host_rect_t *rects, int n) {
 
     // A small span does not travel at all: the kernels work on the pinned buffer itself (it is mapped into the device's address
     // space; a quarter of a megabyte over PCIe costs the kernel a few microseconds, the two copies and their set-up cost thirty).
-    // MJX_COMPOSE_COPIES=1: always copy.
-    static const bool always_copy = getenv("MJX_COMPOSE_COPIES") != nullptr;
+    // MJX_OPTIONS=compose-copies: always copy.
+    static const bool always_copy = option("compose-copies") != nullptr;
     const bool        in_place = one_span && !always_copy && stage_bytes > 0 && stage_bytes <= kInPlaceBytes;
     char             *rows_base = in_place ? arena->pin : base; // where the kernels find packet and gathered rows
 
@@ -1670,8 +1705,8 @@ int mjx_effect_dc_host(int16_t *plane, int blocks_per_row, int rows, int cols, u
     hipStream_t s = arena->stream;
     // The DCs of a plane are tens of kilobytes: the kernel works on the pinned buffer itself (it is mapped into the device's
     // address space) instead of on a copy — one launch and its completion instead of copy, launch, copy (0.057 -> 0.03 ms per
-    // call; the reference's CPU loop takes 0.022).  MJX_EFFECT_COPIES=1: the staged form.
-    static const bool copies = getenv("MJX_EFFECT_COPIES") != nullptr;
+    // call; the reference's CPU loop takes 0.022).  MJX_OPTIONS=effect-copies: the staged form.
+    static const bool copies = option("effect-copies") != nullptr;
     if(copies) {
         MJX_HIP(hipMemcpyAsync(arena->dev, stage, n * sizeof(int16_t), hipMemcpyHostToDevice, s), MJX_ERR_LAUNCH);
         err = launch_effect_dc_vector(reinterpret_cast<int16_t *>(arena->dev), n, q0, rq_of(q0), value, s);

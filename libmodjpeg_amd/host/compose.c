@@ -52,7 +52,7 @@ int mj_compose(mj_jpeg_t *m, mj_dropon_t *d, unsigned int align, int offset_x, i
     struct mjh_tiles   *cached = NULL;
     axis_t              ax, ay;
     int                 inblock_x, inblock_y, mcu_x, mcu_y, rv;
-    double              t_start = 0, t_tiles = 0; /* MJ_DEBUG_TILES */
+    double              t_start = 0, t_tiles = 0; /* MJ_AMD=debug-tiles */
 
     if(m == NULL || d == NULL) return MJ_ERR_NULL_DATA;
     if(d->blend == MJ_BLEND_NONE) return MJ_OK; /* fully transparent: nothing to do (compose.c:38) */
@@ -79,7 +79,7 @@ int mj_compose(mj_jpeg_t *m, mj_dropon_t *d, unsigned int align, int offset_x, i
      * been prepared before, else prepared now exactly as the reference does on every call */
     {
         struct timespec ts;
-        if(getenv("MJ_DEBUG_TILES") != NULL) {
+        if(mjh_option(MJH_OPT_DEBUG_TILES)) {
             clock_gettime(CLOCK_MONOTONIC, &ts);
             t_start = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
         }

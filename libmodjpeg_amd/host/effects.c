@@ -14,8 +14,7 @@ static int op_dc(int16_t *plane, int bpr, int rows, int cols, const jpeg_compone
 static int op_zero(int16_t *plane, int bpr, int rows, int cols, const jpeg_component_info *ci, int keep_dc);
 
 static int fold_effects(void) {
-    const char *e = getenv("MJ_FOLD_EFFECTS");
-    return !(e != NULL && e[0] == '0');
+    return !mjh_option(MJH_OPT_NO_FOLD_EFFECTS);
 }
 
 static int on_component(mj_jpeg_t *m, int c, plane_op_t op, int arg) {
@@ -39,7 +38,7 @@ static int on_component(mj_jpeg_t *m, int c, plane_op_t op, int arg) {
          * in and out per DC (profiles/r02: 64 + 32 bytes per DC for 4 algorithmic ones).  The image is
          * going to be read block by block by the entropy encoder anyway, so the value is only NOTED here
          * and applied there (mjx_huff_component_t.dc_fx_*); whatever else looks at the plane before that
-         * runs the pending effects first (mjh_shadow_settle).  MJ_FOLD_EFFECTS=0: one launch now. */
+         * runs the pending effects first (mjh_shadow_settle).  MJ_AMD=no-fold-effects: one launch now. */
         if(fold_effects()) {
             if(s->fx_n[c] == MJX_HUFF_MAX_DC_FX) {
                 rv = mjh_shadow_settle(m, c);

@@ -29,7 +29,7 @@ static double now_ms(void) {
 
 #define BAIL(code, why)                                                                              \
     do {                                                                                             \
-        if(getenv("MJ_DEBUG") != NULL) fprintf(stderr, "gpudecode: fall back to libjpeg: %s\n", why); \
+        if(mjh_option(MJH_OPT_DEBUG)) fprintf(stderr, "gpudecode: fall back to libjpeg: %s\n", why); \
         rv = (code);                                                                                 \
         goto done;                                                                                   \
     } while(0)
@@ -90,7 +90,7 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
          * coefficient plane that comes down; the rounds grow steeply with the bits per block.  Fitted to
          * scripts/r03_decode_crossover.sh (profiles/r03/decoder/small_files_device_vs_libjpeg.txt): 640x480 quality 85
          * 0.33 ms against libjpeg's 0.76, quality 100 0.91 against 2.5; 320x240 quality 85 0.27 against 0.20 - the
-         * crossover is near 30 KB of scan data.  The result is the same either way.  MJ_GPU_DECODE_MIN_BYTES replaces
+         * crossover is near 30 KB of scan data.  The result is the same either way.  MJ_AMD=gpu-decode-min-bytes=N replaces
          * the model by a plain size threshold (0: always the device). */
         static long   min_bytes = -2;
         const double  nbytes = (double)d->src->bytes_in_buffer;
@@ -103,7 +103,7 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
         }
         const double  plane_bytes = (double)nmcu * blocks_in_mcu * 128.0;
         const double  gpu_ms = 0.12 + 0.0106 * rounds + nbytes * 0.35e-6 + plane_bytes * 3.0e-8, cpu_ms = nbytes * 0.95e-5;
-        if(min_bytes == -2) min_bytes = getenv("MJ_GPU_DECODE_MIN_BYTES") != NULL ? atol(getenv("MJ_GPU_DECODE_MIN_BYTES")) : -1;
+        if(min_bytes == -2) min_bytes = mjh_option_decode_min_bytes();
         if(min_bytes >= 0 ? nbytes < (double)min_bytes : gpu_ms >= cpu_ms) BAIL(MJH_DECODE_UNSUPPORTED, "libjpeg is faster for this one");
     }
 
@@ -202,7 +202,7 @@ int mjh_read_gpu_entropy(mj_jpeg_t *m) {
         if(staged[c] != NULL) mjh_rows_scatter(m, c, 0, sc.mcus_y * sc.comp[c].v_samp, staged[c]);
     __sync_fetch_and_add(&mjh_gpu_decode_count, 1);
     rv = MJ_OK;
-    if(getenv("MJ_DEBUG") != NULL)
+    if(mjh_option(MJH_OPT_DEBUG))
         fprintf(stderr, "gpudecode: arrays %.3f ms, decode %.3f ms\n", t2 - t1, now_ms() - t2);
 
 done:

@@ -23,10 +23,10 @@ int mjh_gpu_encode_count = 0; /* how many files went through the GPU entropy enc
 
 static int be16(const unsigned char *p) { return (p[0] << 8) | p[1]; }
 
-/* why the GPU path was not taken (MJ_DEBUG=1) */
+/* why the GPU path was not taken (MJ_AMD=debug) */
 #define BAIL(why)                                                                          \
     do {                                                                                   \
-        if(getenv("MJ_DEBUG") != NULL) fprintf(stderr, "gpuencode: fall back to libjpeg: %s\n", why); \
+        if(mjh_option(MJH_OPT_DEBUG)) fprintf(stderr, "gpuencode: fall back to libjpeg: %s\n", why); \
         goto done;                                                                         \
     } while(0)
 
@@ -58,7 +58,7 @@ static int tiny_jpeg(mj_jpeg_t *m, int optimize, unsigned char **buf, unsigned l
     *len = 0;
     mjh_trap_install(&trap, (j_common_ptr)&enc);
     if(setjmp(trap.trap)) {
-        if(getenv("MJ_DEBUG") != NULL) {
+        if(mjh_option(MJH_OPT_DEBUG)) {
             char msg[JMSG_LENGTH_MAX];
             (*enc.err->format_message)((j_common_ptr)&enc, msg);
             fprintf(stderr, "gpuencode: header generation failed: %s\n", msg);

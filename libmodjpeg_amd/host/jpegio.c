@@ -127,9 +127,9 @@ int mj_read_jpeg_from_memory(mj_jpeg_t *m, const unsigned char *memory, size_t l
     }
 
     /* sequential Huffman files: the scan data is decoded on the GPU into arrays identical to
-     * libjpeg's (gpudecode.c; MJ_GPU_DECODE=0 keeps everything in libjpeg).  Everything else,
+     * libjpeg's (gpudecode.c; MJ_AMD=no-gpu-decode keeps everything in libjpeg).  Everything else,
      * and every file that path refuses, is read by jpeg_read_coefficients() as in the reference. */
-    if(!(getenv("MJ_GPU_DECODE") != NULL && getenv("MJ_GPU_DECODE")[0] == '0')) {
+    if(!mjh_option(MJH_OPT_NO_GPU_DECODE)) {
         const int rv = mjh_read_gpu_entropy(m);
         if(rv == MJH_DECODE_FAILED) { /* arrays were already requested: start over with a fresh object */
             jpeg_destroy_decompress(&m->cinfo);
@@ -179,8 +179,8 @@ int mj_write_jpeg_to_memory(mj_jpeg_t *m, unsigned char **memory, size_t *len, i
     if(m->coef == NULL) return MJ_ERR_NULL_DATA;
 
     /* sequential Huffman, fixed or optimised tables: the entropy-coded segment is produced on the
-     * GPU, byte-identical to libjpeg's (MJ_GPU_ENCODE=0 keeps everything in libjpeg) */
-    if((options == MJ_OPTION_NONE || options == MJ_OPTION_OPTIMIZE) && !(getenv("MJ_GPU_ENCODE") != NULL && getenv("MJ_GPU_ENCODE")[0] == '0')) {
+     * GPU, byte-identical to libjpeg's (MJ_AMD=no-gpu-encode keeps everything in libjpeg) */
+    if((options == MJ_OPTION_NONE || options == MJ_OPTION_OPTIMIZE) && !mjh_option(MJH_OPT_NO_GPU_ENCODE)) {
         const int rv = mjh_write_gpu_entropy(m, memory, len, options == MJ_OPTION_OPTIMIZE);
         if(rv != MJH_ENCODE_UNSUPPORTED) return rv;
     }

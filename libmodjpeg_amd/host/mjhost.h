@@ -109,6 +109,17 @@ const mjx_tile_schedule_t *mjh_tiles_schedule(const struct mjh_tiles *t, int c);
 /* MJX_* -> MJ_ERR_* (INTEGRATION.md "error mapping"); prints once when the GPU is unusable */
 int mjh_from_mjx(int mjx_err);
 
+/* options.c: the one place that reads the environment (MJ_AMD=token,token,...) */
+enum {
+    MJH_OPT_DEVICE_RESIDENT, MJH_OPT_NO_DEVICE_RESIDENT, MJH_OPT_NO_GPU_DECODE, MJH_OPT_NO_GPU_ENCODE, MJH_OPT_NO_DEVICE_TILEPREP, MJH_OPT_NO_TILE_CACHE,
+    MJH_OPT_FLOAT_TILES, MJH_OPT_NO_TILE_SCHEDULE, MJH_OPT_NO_FOLD_EFFECTS, MJH_OPT_DEBUG, MJH_OPT_DEBUG_TILES, MJH_OPT_CLI_TIMING, MJH_OPT_COUNT
+};
+int  mjh_option(int which);                /* 1 when the token is in MJ_AMD */
+void mjh_set_option(int which, int on);    /* in-process tools (tests/tools/probe.c) */
+void mjh_set_option_named(const char *token, int on);
+int  mjh_option_named(const char *token);
+long mjh_option_decode_min_bytes(void);    /* gpu-decode-min-bytes=N, -1 when absent */
+
 /* reference-internal entry points that stay exported (compose.h:28-29, convolve.h:28,
  * dropon.h:28-38) because downstream code and tests link against them */
 int  mj_compose_with_mask(mj_jpeg_t *m, mj_compileddropon_t *cd, int block_x, int block_y);

@@ -150,7 +150,7 @@ static double now_ms(void) {
 
 typedef struct {
     char          **files;
-    double          t_read, t_script, t_write; /* summed over the workers (MJ_CLI_TIMING) */
+    double          t_read, t_script, t_write; /* summed over the workers (MJ_AMD=cli-timing) */
     int             nfiles, next, failed;
     const action_t *script;
     int             nscript;
@@ -219,6 +219,7 @@ static void *batch_worker(void *arg) {
 /* drop-in internal (shadow.c): images stay on the device between read and write.  Safe here
  * because this program only ever touches an image through the mj_* functions. */
 void mjh_set_device_resident(int on);
+int  mjh_option_named(const char *token); /* host/options.c: a token of MJ_AMD */
 
 static int run_batch(const char *list, const char *outdir, int jobs, int devices, const action_t *script, int nscript) {
     batch_t    b;
@@ -265,7 +266,7 @@ static int run_batch(const char *list, const char *outdir, int jobs, int devices
         const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
         fprintf(stderr, "modjpeg: %d files, %d failed, %d threads on %d GPU%s, %.3f s, %.1f images/s\n", b.nfiles, b.failed, jobs, b.ndevices, b.ndevices == 1 ? "" : "s", sec,
                 sec > 0 ? b.nfiles / sec : 0.0);
-        if(getenv("MJ_CLI_TIMING") != NULL && b.nfiles > 0) {
+        if(mjh_option_named("cli-timing") && b.nfiles > 0) {
             extern int mjh_shadow_count, mjh_gpu_decode_count, mjh_gpu_encode_count;
             fprintf(stderr, "modjpeg: per file, in the worker that had it: read %.3f ms, script %.3f ms, write+free %.3f ms\n", b.t_read / b.nfiles, b.t_script / b.nfiles,
                     b.t_write / b.nfiles);
@@ -285,8 +286,8 @@ int main(int argc, char **argv) {
     int         nscript = 0, jobs = 4, devices = 0, c, i, rc = 0;
 
     /* this program only ever touches an image through the mj_* functions, so images may stay on the
-     * device between read and write (MJ_DEVICE_RESIDENT=0 keeps the host arrays authoritative) */
-    if(getenv("MJ_DEVICE_RESIDENT") == NULL) mjh_set_device_resident(1);
+     * device between read and write (MJ_AMD=no-device-resident keeps the host arrays authoritative) */
+    mjh_set_device_resident(!mjh_option_named("no-device-resident")); /* MJ_AMD=no-device-resident: images travel through libjpeg's host arrays as in the API */
     opterr = 1;
     /* leading ':' => a missing argument is reported as ':' like the reference's option string */
     while((c = getopt_long(argc, argv, ":i:o:d:p:m:y:b:r:xgPOAh", long_options, NULL)) != -1) {

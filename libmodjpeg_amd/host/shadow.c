@@ -11,7 +11,7 @@
  * The host arrays still exist (requested from libjpeg as always) but are not filled.  That is only
  * sound when nothing but this library looks at them, so the mode is opt-in: the batch CLI turns it
  * on for its workers (mjh_set_device_resident), a program that sticks to the mj_* functions can do
- * the same with MJ_DEVICE_RESIDENT=1.  Whenever the library itself needs the host copy (a write
+ * the same with MJ_AMD=device-resident.  Whenever the library itself needs the host copy (a write
  * libjpeg has to do: -P/-A, restart intervals; the tile preparation's read-back) it downloads
  * the shadow first and drops it (mjh_host_sync), and the image continues as an ordinary one.
  */
@@ -39,8 +39,7 @@ int mjh_download(void *host, const void *dev, size_t bytes) { return mjh_from_mj
 
 int mjh_device_resident(void) {
     if(g_resident < 0) {
-        const char *e = getenv("MJ_DEVICE_RESIDENT");
-        g_resident = (e != NULL && e[0] == '1') ? 1 : 0;
+        g_resident = mjh_option(MJH_OPT_DEVICE_RESIDENT) && !mjh_option(MJH_OPT_NO_DEVICE_RESIDENT);
     }
     return g_resident;
 }

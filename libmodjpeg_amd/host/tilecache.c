@@ -13,16 +13,16 @@
  * visible pixels and no PCIe traffic for tiles.  The hash only says where to look: an entry is used
  * when its device, its parameters and its copy of the visible pixels equal the caller's byte for
  * byte, so a hash collision can never hand out another overlay's tiles.  It is transparent (same
- * results as without it; MJ_TILE_CACHE=0 disables it), bounded (8 entries, 1 GiB including the
+ * results as without it; MJ_AMD=no-tile-cache disables it), bounded (8 entries, 1 GiB including the
  * pixel copies), process-wide and mutex-protected; entries in use are never evicted, and the lock
  * is held only for table look-ups and pointer moves: the byte-for-byte comparison of the window (tens
  * of MB for a 4K overlay), tile preparation, hipMalloc, the upload and every hipFree happen outside it.
  *
  * What a slot holds (round 3): the tiles as the int16 coefficients they are made from when the device
  * prepared them (MJX_PREP_TILES_I16: 512 instead of 768 bytes of traffic per composed block, the
- * kernel converts them bit for bit; MJ_TILES_I16=0 keeps floats), and per component a schedule
+ * kernel converts them bit for bit; MJ_AMD=float-tiles keeps floats), and per component a schedule
  * (mjx_tile_schedule_create: which blocks share a wavefront, from the zero patterns of the alpha
- * blocks, read once; MJ_TILE_SCHEDULE=0 disables).  Both are what mj_compose hands to
+ * blocks, read once; MJ_AMD=no-tile-schedule disables).  Both are what mj_compose hands to
  * mjx_compose_host, so the reference's API runs the same kernel paths as the batch plans.
  *
  * The device preparation reproduces ONE library's arithmetic (IJG libjpeg 9d's forward DCTs with DCT
@@ -66,8 +66,7 @@ static pthread_mutex_t  g_lock = PTHREAD_MUTEX_INITIALIZER;
 static uint64_t         g_clock;
 
 static int cache_enabled(void) {
-    const char *e = getenv("MJ_TILE_CACHE");
-    return !(e != NULL && e[0] == '0');
+    return !mjh_option(MJH_OPT_NO_TILE_CACHE);
 }
 
 /* two independent multiply-xorshift lanes over 8-byte words: an index into the cache, not an
@@ -264,7 +263,7 @@ static void contents_free(struct mjh_tiles *t) {
     memset(t, 0, sizeof(*t));
 }
 
-/* MJ_DEBUG_TILES=1: where the time of a look-up / a miss goes (stderr) */
+/* MJ_AMD=debug-tiles: where the time of a look-up / a miss goes (stderr) */
 #include <time.h>
 static double now_ms(void) {
     struct timespec t;
@@ -273,14 +272,10 @@ static double now_ms(void) {
 }
 static int debug_tiles(void) {
     static int on = -1;
-    if(on < 0) on = getenv("MJ_DEBUG_TILES") != NULL;
+    if(on < 0) on = mjh_option(MJH_OPT_DEBUG_TILES);
     return on;
 }
 
-static int env_on(const char *name) { /* switches that default to on */
-    const char *e = getenv(name);
-    return !(e != NULL && e[0] == '0');
-}
 
 /* The schedules of a slot (which blocks share a wavefront: read once from the alpha tiles, kept with them).
  * They are made when an entry is hit for the FIRST time, not when it is filled: tiles that are used once
@@ -289,7 +284,7 @@ static int env_on(const char *name) { /* switches that default to on */
  * the lock, it holds the entry pinned), the others compose without until sched_state is 2. */
 static int contents_schedule(struct mjh_tiles *t) {
     int c, e;
-    if(!env_on("MJ_TILE_SCHEDULE")) return MJX_OK;
+    if(mjh_option(MJH_OPT_NO_TILE_SCHEDULE)) return MJX_OK;
     for(c = 0; c < t->ncomp; c++) {
         if(t->rows[c] <= 0 || t->cols[c] <= 0 || t->dev_alpha[c] == NULL) continue;
         if((int64_t)t->rows[c] * t->cols[c] >= (1 << 24)) continue; /* beyond what one schedule covers: consecutive octets */
@@ -344,10 +339,10 @@ static int contents_fill(struct mjh_tiles *t, const mj_compileddropon_t *cd, con
     return window_copy(t, d, cx, cy, cw, ch);
 }
 
-/* MJ_GPU_TILEPREP=0: always prepare tiles with libjpeg on the host */
+/* MJ_AMD=no-device-tileprep: always prepare tiles with libjpeg on the host */
 static int device_prep_enabled(void) {
 #if JPEG_LIB_VERSION >= 90
-    return env_on("MJ_GPU_TILEPREP");
+    return !mjh_option(MJH_OPT_NO_DEVICE_TILEPREP);
 #else
     return 0; /* the integer forms of csrc/mjx_fdct_tables.h are IJG 9's transforms: not this library's */
 #endif
@@ -574,7 +569,7 @@ int mjh_tiles_acquire(struct mjh_tiles **out, mj_dropon_t *d, J_COLOR_SPACE cs, 
     fresh.device = device; /* recycled device buffers are looked up by device */
     rv = MJX_ERR_BAD_ARG;
     if(device_prep_enabled() && device_prep_covers(d, cs, s) && device_prep_verified(d, cs, s))
-        rv = contents_fill_device(&fresh, d, cs, s, bx, by, cx, cy, cw, ch, env_on("MJ_TILES_I16"));
+        rv = contents_fill_device(&fresh, d, cs, s, bx, by, cx, cy, cw, ch, !mjh_option(MJH_OPT_FLOAT_TILES));
     if(rv == MJX_OK) {
         __sync_fetch_and_add(&mjh_tiles_gpu_prepared, 1);
         rv = MJ_OK;

@@ -26,13 +26,13 @@ echo "== 2. host C code against a no-device stub of mjx.h"
 # tests/tools/mjx_stub.c (tracked): with MJX_STUB_DEVICES unset it answers "no device" to everything
 gcc $SAN -fPIC -std=gnu99 -I$R/include -shared -o $O/libmjx_hip.so tests/tools/mjx_stub.c -Wno-unused-parameter
 ( cd $H && gcc $SAN -fPIC -std=gnu99 -Wall -I/opt/conda/include -DWITH_LIBPNG -I/opt/conda/include/libpng16 -shared -Wl,-soname,libmodjpeg.so.1 -o $O/libmodjpeg.so.1 \
-    jpegio.c dropon.c tiles.c tilecache.c compose.c effects.c gpuencode.c gpudecode.c shadow.c /opt/conda/lib/libjpeg.so /opt/conda/lib/libpng16.so -Wl,-rpath,/opt/conda/lib -L$O -Wl,-rpath,$O -lmjx_hip -lm -lpthread
+    jpegio.c dropon.c tiles.c tilecache.c compose.c effects.c gpuencode.c gpudecode.c shadow.c options.c /opt/conda/lib/libjpeg.so /opt/conda/lib/libpng16.so -Wl,-rpath,/opt/conda/lib -L$O -Wl,-rpath,$O -lmjx_hip -lm -lpthread
   ln -sf libmodjpeg.so.1 $O/libmodjpeg.so
   for p in $R/tests/tools/probe.c modjpeg.c example.c; do
     gcc $SAN -std=gnu99 -I$R/include -I/opt/conda/include -o $O/$(basename $p .c) $p -L$O -Wl,-rpath,$O -Wl,--allow-shlib-undefined -lmodjpeg -lpthread -ldl -lm /opt/conda/lib/libjpeg.so -Wl,-rpath,/opt/conda/lib
   done )
 I=tests/golden/images
-export MJ_GPU_DECODE=0 MJ_GPU_ENCODE=0
+export MJ_AMD=no-gpu-decode,no-gpu-encode
 # tile preparation for every colour space / offset / crop the parity test uses, plus odd sizes
 python3 - > $O/raw.bin <<'PY'
 import sys, random

@@ -8,7 +8,7 @@ H=libmodjpeg_amd/host
 T=tests/tools
 for i in $(seq 1 $n); do
   f=$work/in/img$i.jpg
-  if [ $i -le 8 ]; then BENCH_DUMP_INPUT=$f MJ_GPU_DECODE=0 MJ_GPU_ENCODE=0 $T/bench_dropin $H/libmodjpeg.so.1 1920 1080 16 16 1 > /dev/null; else cp $work/in/img$(( (i % 8) + 1 )).jpg $f; fi
+  if [ $i -le 8 ]; then BENCH_DUMP_INPUT=$f MJ_AMD=no-gpu-decode,no-gpu-encode $T/bench_dropin $H/libmodjpeg.so.1 1920 1080 16 16 1 > /dev/null; else cp $work/in/img$(( (i % 8) + 1 )).jpg $f; fi
   echo $f >> $work/list.txt
 done
 cp tests/golden/images/dropon.png $work/logo.png

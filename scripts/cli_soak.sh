@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 work=$(mktemp -d /tmp/mjq.XXXX); mkdir -p $work/in $work/out
 H=libmodjpeg_amd/host
 T=tests/tools
-for i in $(seq 1 16); do BENCH_DUMP_INPUT=$work/in/img$i.jpg MJ_GPU_DECODE=0 MJ_GPU_ENCODE=0 $T/bench_dropin $H/libmodjpeg.so.1 1920 1080 16 16 1 > /dev/null; done
+for i in $(seq 1 16); do BENCH_DUMP_INPUT=$work/in/img$i.jpg MJ_AMD=no-gpu-decode,no-gpu-encode $T/bench_dropin $H/libmodjpeg.so.1 1920 1080 16 16 1 > /dev/null; done
 cp tests/golden/images/dropon.png $work/logo.png
 for n in ${SIZES:-8192 65536}; do
   rm -f $work/list.txt; for i in $(seq 1 $n); do echo $work/in/img$(( (i % 16) + 1 )).jpg >> $work/list.txt; done

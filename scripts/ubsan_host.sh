@@ -8,16 +8,16 @@ cd "$(dirname "$0")/.."
 R=$PWD; H=$R/libmodjpeg_amd/host; O=$R/gpurun_variants/ubsan; mkdir -p $O
 SAN="-O1 -g -fsanitize=undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer"
 ( cd $H && gcc $SAN -fPIC -std=gnu99 -I/opt/conda/include -DWITH_LIBPNG -I/opt/conda/include/libpng16 -shared -Wl,-soname,libmodjpeg.so.1 -o $O/libmodjpeg.so.1 \
-    jpegio.c dropon.c tiles.c tilecache.c compose.c effects.c gpuencode.c gpudecode.c shadow.c -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -ljpeg -L$R/libmodjpeg_amd -Wl,-rpath,$R/libmodjpeg_amd -lmjx_hip -lm -lpthread -lpng16
+    jpegio.c dropon.c tiles.c tilecache.c compose.c effects.c gpuencode.c gpudecode.c shadow.c options.c -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -ljpeg -L$R/libmodjpeg_amd -Wl,-rpath,$R/libmodjpeg_amd -lmjx_hip -lm -lpthread -lpng16
   ln -sf libmodjpeg.so.1 $O/libmodjpeg.so
   for p in $R/tests/tools/probe.c modjpeg.c $R/tests/tools/bench_dropin.c; do
     gcc $SAN -std=gnu99 -I$R/include -I/opt/conda/include -o $O/$(basename $p .c) $p -L$O -Wl,-rpath,$O -Wl,--allow-shlib-undefined -lmodjpeg -lpthread -ldl -lm -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -ljpeg
   done )
 I=tests/golden/images
-BENCH_DUMP_INPUT=$O/in.jpg MJ_GPU_DECODE=0 MJ_GPU_ENCODE=0 $O/bench_dropin $O/libmodjpeg.so.1 800 600 16 16 1 > /dev/null
-export MJ_GPU_DECODE_MIN_BYTES=0
+BENCH_DUMP_INPUT=$O/in.jpg MJ_AMD=no-gpu-decode,no-gpu-encode $O/bench_dropin $O/libmodjpeg.so.1 800 600 16 16 1 > /dev/null
+export MJ_AMD=gpu-decode-min-bytes=0
 $O/probe stress $O/in.jpg $I/dropon.png 16 20
-MJ_DEVICE_RESIDENT=1 $O/probe stress $O/in.jpg $I/dropon.png 16 20
+MJ_AMD=gpu-decode-min-bytes=0,device-resident $O/probe stress $O/in.jpg $I/dropon.png 16 20
 $O/probe decodecmp $O/in.jpg
 $O/probe decodefuzz $O/in.jpg 150 5
 for i in $(seq 1 64); do echo $O/in.jpg; done > $O/list.txt; mkdir -p $O/out

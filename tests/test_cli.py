@@ -105,14 +105,14 @@ def test_batch_pipeline_keeps_images_on_the_device_and_matches_the_reference(cli
     names = []
     for k in range(6):
         p = src / f"img{k}.jpg"
-        env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DUMP_INPUT=str(p), BENCH_QUALITY=str(60 + 7 * k), MJ_GPU_DECODE="0", MJ_GPU_ENCODE="0")
+        env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DUMP_INPUT=str(p), BENCH_QUALITY=str(60 + 7 * k), MJ_AMD="no-gpu-decode,no-gpu-encode")
         subprocess.check_output([os.path.join(TOOLS, "bench_dropin"), os.path.join(HOST, "libmodjpeg.so.1"), str(400 + 33 * k), str(300 + 17 * k), "16", "16", "1"], env=env)
         names.append(str(p))
     (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
     out = tmp_path / "out"
     out.mkdir()
     res = subprocess.run([cli, "--batch", str(tmp_path / "list.txt"), "--outdir", str(out), "--jobs", "3"] + script, capture_output=True, text=True,
-                         env=dict(os.environ, MJ_CLI_TIMING="1", MJ_GPU_DECODE_MIN_BYTES="0"))
+                         env=dict(os.environ, MJ_AMD="cli-timing,gpu-decode-min-bytes=0"))
     assert res.returncode == 0, res.stderr[-500:]
     import re
     kept = re.search(r"(\d+) kept on the device", res.stderr)

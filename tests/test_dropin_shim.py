@@ -147,7 +147,7 @@ def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case
     mj_compile_dropon prepared through libjpeg, as float bit patterns: image tiles, alpha DC offset
     and scaling, padding, in-MCU offsets.  The cache keeps them as int16 coefficients by default
     (converted with the reference's expressions by the probe, as the kernel does) or, with
-    MJ_TILES_I16=0, as the floats themselves."""
+    MJ_AMD=float-tiles, as the floats themselves."""
     g = np.load(os.path.join(golden_dir, "compose_kat.npz"))
     w, h, cs, blend = [int(v) for v in g[f"{case}_dropon_meta"]]
     img = g[f"{case}_dropon_image"].reshape(h, w, 3)
@@ -159,7 +159,7 @@ def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case
     out = tmp_path / "tiles.bin"
     res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "tilesgpu", os.path.join(IMAGES, "image.jpg"), str(raw), str(w), str(h), "2", "255",
                           str(bx), str(by), str(cx), str(cy), str(cw), str(ch), str(out)], capture_output=True, text=True,
-                         env=dict(os.environ, MJ_TILES_I16="1" if tiles == "i16" else "0"))
+                         env=dict(os.environ, MJ_AMD="" if tiles == "i16" else "float-tiles"))
     assert res.returncode == 0 and res.stdout.strip() == "gpu", (res.returncode, res.stdout, res.stderr[-300:])
     for c, (hib, wib, tile, alpha) in enumerate(_read_tiles(out)):
         rows, cols = int(g[f"{case}_rect_c{c}"][2]), int(g[f"{case}_rect_c{c}"][3])
@@ -281,7 +281,7 @@ def test_gpu_entropy_encoder_byte_identical(shim, size, sampling):
     args = [*size, "16", "16", "3", "9", "-4", "6"]
     env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_VARY_POSITION="1")
     gpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))
-    cpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=dict(env, MJ_GPU_ENCODE="0")))
+    cpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=dict(env, MJ_AMD="no-gpu-encode")))
     assert gpu["gpu_encodes"] == 4 and cpu["gpu_encodes"] == 0  # 3 images + the warm-up pass
     assert gpu["out_bytes"] == cpu["out_bytes"] and gpu["fnv1a"] == cpu["fnv1a"], (gpu, cpu)
     ref = os.path.join(ROOT, "oracle", "_ref", "libmodjpeg_ref.so")
@@ -312,7 +312,7 @@ def test_gpu_entropy_encoder_with_optimised_tables_byte_identical(shim, size, sa
     args = [*size, "16", "16", "2", "9", "-4", "6"]
     env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_WRITE_OPTIONS="1")
     gpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))
-    cpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=dict(env, MJ_GPU_ENCODE="0")))
+    cpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=dict(env, MJ_AMD="no-gpu-encode")))
     assert gpu["gpu_encodes"] == 3 and cpu["gpu_encodes"] == 0
     assert gpu["out_bytes"] == cpu["out_bytes"] and gpu["fnv1a"] == cpu["fnv1a"], (gpu, cpu)
     ref = os.path.join(ROOT, "oracle", "_ref", "libmodjpeg_ref.so")
@@ -332,7 +332,7 @@ def test_written_jpegs_byte_identical_to_reference(shim, args):
     if not os.path.exists(ref):
         pytest.skip("oracle/_ref not present")
     exe = os.path.join(TOOLS, "bench_dropin")
-    for env in (dict(os.environ, BENCH_VARY_POSITION="1"), dict(os.environ), dict(os.environ, MJ_TILE_CACHE="0")):
+    for env in (dict(os.environ, BENCH_VARY_POSITION="1"), dict(os.environ), dict(os.environ, MJ_AMD="no-tile-cache")):
         a = json.loads(subprocess.check_output([exe, ref, *args], text=True, env=env))
         b = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))  # tile cache: misses, hits, disabled
         assert a["out_bytes"] == b["out_bytes"] and a["fnv1a"] == b["fnv1a"], (a, b)
@@ -372,9 +372,7 @@ def test_concurrent_compose_with_cache_evictions(shim, tmp_path, mode):
     if mode != "host":
         image = str(tmp_path / "big.jpg")
         _make_input(image, ("800", "600"), "420")
-        env["MJ_GPU_DECODE_MIN_BYTES"] = "0"
-    if mode == "device-resident":
-        env["MJ_DEVICE_RESIDENT"] = "1"
+        env["MJ_AMD"] = "gpu-decode-min-bytes=0" + (",device-resident" if mode == "device-resident" else "")
     res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "stress", image, os.path.join(IMAGES, "dropon.png"), "16", "40"], capture_output=True, text=True,
                          env=env)
     assert res.returncode == 0 and res.stdout.strip() == "ok", (res.stdout, res.stderr[-500:])
@@ -382,7 +380,7 @@ def test_concurrent_compose_with_cache_evictions(shim, tmp_path, mode):
 
 def _make_input(path, size, sampling, **knobs):
     """one synthetic JPEG from the bench harness's generator (libjpeg encoder)"""
-    env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DUMP_INPUT=str(path), MJ_GPU_DECODE="0", MJ_GPU_ENCODE="0")
+    env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DUMP_INPUT=str(path), MJ_AMD="no-gpu-decode,no-gpu-encode")
     for k, v in knobs.items():
         env["BENCH_" + k.upper()] = str(v)
     subprocess.check_output([os.path.join(TOOLS, "bench_dropin"), os.path.join(HOST, "libmodjpeg.so.1"), *size, "16", "16", "1"], env=env)
@@ -412,16 +410,16 @@ def test_gpu_entropy_decoder_matches_libjpeg(shim, tmp_path, sampling, case):
     src = tmp_path / "in.jpg"
     _make_input(src, size, sampling, **knobs)
     res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "decodecmp", str(src)], capture_output=True, text=True,
-                         env=dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0"))
+                         env=dict(os.environ, MJ_AMD="gpu-decode-min-bytes=0"))
     assert res.returncode == 0 and res.stdout.strip() == "same gpu", (res.stdout, res.stderr[-500:])
 
 
-ROUND_MODES = {  # how the decoder's synchronisation rounds are walked (MJX_DECODE_ROUNDS)
+ROUND_MODES = {  # how the decoder's synchronisation rounds are walked (MJX_OPTIONS=decode-rounds=...)
     "default": {},
-    "a-lane-per-chunk": {"MJX_DECODE_ROUNDS": "lane"},
-    "a-wavefront-per-chunk": {"MJX_DECODE_ROUNDS": "wave"},
-    "one-lane-round-then-wavefronts": {"MJX_DECODE_ROUNDS": "lane:1"},
-    "four-lane-rounds-then-wavefronts": {"MJX_DECODE_ROUNDS": "lane:4"},
+    "a-lane-per-chunk": {"MJX_OPTIONS": "decode-rounds=lane"},
+    "a-wavefront-per-chunk": {"MJX_OPTIONS": "decode-rounds=wave"},
+    "one-lane-round-then-wavefronts": {"MJX_OPTIONS": "decode-rounds=lane:1"},
+    "four-lane-rounds-then-wavefronts": {"MJX_OPTIONS": "decode-rounds=lane:4"},
 }
 
 
@@ -430,7 +428,7 @@ ROUND_MODES = {  # how the decoder's synchronisation rounds are walked (INTEGRAT
 def test_gpu_entropy_decoder_rounds_walked_either_way(shim, tmp_path, mode):
     """the two kinds of synchronisation round (one lane / one wavefront per chunk) and their mixtures leave the same states
     behind: every choice decodes the same arrays as libjpeg (4:2:0 at two qualities, 4:4:4 with restart markers, grayscale)"""
-    env = dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0", **ROUND_MODES[mode])
+    env = dict(os.environ, MJ_AMD="gpu-decode-min-bytes=0", **ROUND_MODES[mode])
     for i, (size, sampling, knobs) in enumerate([(("1280", "720"), "420", {}), (("800", "600"), "420", {"quality": 97}), (("641", "479"), "444", {"restart": 7}),
                                                   (("1000", "700"), "gray", {"optimize": 1})]):
         src = tmp_path / ("in%d.jpg" % i)
@@ -448,9 +446,9 @@ def test_gpu_entropy_decoder_declines_what_it_does_not_decode(shim, tmp_path):
     for flag in ("-P", "-A"):
         out = tmp_path / ("out%s.jpg" % flag)
         subprocess.check_call([cli, flag, "-i", str(src), "-o", str(out)])
-        res = subprocess.run([probe, "decodecmp", str(out)], capture_output=True, text=True, env=dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0"))
+        res = subprocess.run([probe, "decodecmp", str(out)], capture_output=True, text=True, env=dict(os.environ, MJ_AMD="gpu-decode-min-bytes=0"))
         assert res.stdout.strip() == "same fallback", (flag, res.stdout, res.stderr[-300:])
-    res = subprocess.run([probe, "decodecmp", str(src)], capture_output=True, text=True, env=dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="100000000"))
+    res = subprocess.run([probe, "decodecmp", str(src)], capture_output=True, text=True, env=dict(os.environ, MJ_AMD="gpu-decode-min-bytes=100000000"))
     assert res.stdout.strip() == "same fallback"
 
 
@@ -463,7 +461,7 @@ def test_gpu_entropy_decoder_on_damaged_files(shim, tmp_path, sampling, knobs):
     src = tmp_path / "in.jpg"
     _make_input(src, ("400", "300"), sampling, **knobs)
     res = subprocess.run([os.path.join(TOOLS, "mjhost_probe"), "decodefuzz", str(src), "150", "7"], capture_output=True, text=True,
-                         env=dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0"))
+                         env=dict(os.environ, MJ_AMD="gpu-decode-min-bytes=0"))
     assert res.returncode == 0 and res.stdout.strip().endswith(" 0 differ"), (res.stdout, res.stderr[-500:])
 
 
@@ -476,7 +474,7 @@ def test_read_compose_write_identical_with_both_entropy_paths_on_the_gpu(shim):
     args = ["1920", "1080", "256", "256", "3", "7", "5", "-3"]
     env = dict(os.environ, BENCH_RESTART="120")
     gpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=env))
-    cpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=dict(env, MJ_GPU_DECODE="0", MJ_GPU_ENCODE="0")))
+    cpu = json.loads(subprocess.check_output([exe, shim, *args], text=True, env=dict(env, MJ_AMD="no-gpu-decode,no-gpu-encode")))
     assert gpu["gpu_decodes"] >= 4 and cpu["gpu_decodes"] == 0
     assert gpu["out_bytes"] == cpu["out_bytes"] and gpu["fnv1a"] == cpu["fnv1a"], (gpu, cpu)
     ref = os.path.join(ROOT, "oracle", "_ref", "libmodjpeg_ref.so")
@@ -497,7 +495,7 @@ def test_files_from_another_encoder(shim, tmp_path):
     img = PIL.fromarray((base + rng.integers(-20, 20, base.shape)).clip(0, 255).astype(np.uint8))
     probe, cli = os.path.join(TOOLS, "mjhost_probe"), os.path.join(HOST, "modjpeg")
     ref_cli = os.path.join(ROOT, "oracle", "_ref", "modjpeg_ref")
-    env = dict(os.environ, MJ_GPU_DECODE_MIN_BYTES="0")
+    env = dict(os.environ, MJ_AMD="gpu-decode-min-bytes=0")
     k = 0
     for quality in (20, 75, 96):
         for subsampling in (0, 1, 2):
@@ -529,15 +527,15 @@ def test_mj_compose_takes_the_pattern_schedule_and_int16_tiles(shim):
     the reference's own logo overlay (tests/golden/images/dropon.png: text, i.e. blocks with very
     different zero patterns) reaches the compose kernel with the tiles as int16 coefficients and, from
     the second use of the cached tiles on (the schedule is made at an entry's first hit, not for tiles
-    that are used once), with a schedule that picks the blocks of an octet by pattern; MJ_TILES_I16=0 /
-    MJ_TILE_SCHEDULE=0 switch each off.  (That the files stay byte-identical to the reference's is tests/test_cli.py and
+    that are used once), with a schedule that picks the blocks of an octet by pattern; MJ_AMD=float-tiles /
+    MJ_AMD=no-tile-schedule switch each off.  (That the files stay byte-identical to the reference's is tests/test_cli.py and
     test_example_program_matches_reference, which run through this default.)"""
     probe = os.path.join(TOOLS, "mjhost_probe")
     args = [probe, "composepath", os.path.join(IMAGES, "image.jpg"), os.path.join(IMAGES, "dropon.png"), "4"]
     rects, i16, sched, gpu = [int(v) for v in subprocess.check_output(args, text=True).split()]
     assert rects == 12 and i16 == 12 and gpu == 1, (rects, i16, sched, gpu)
     assert 3 <= sched <= 9, "the luma rectangle of a text overlay has blocks of very different patterns: calls 2..4 carry its schedule, call 1 (the miss) none"
-    rects, i16, sched, gpu = [int(v) for v in subprocess.check_output(args, text=True, env=dict(os.environ, MJ_TILES_I16="0")).split()]
+    rects, i16, sched, gpu = [int(v) for v in subprocess.check_output(args, text=True, env=dict(os.environ, MJ_AMD="float-tiles")).split()]
     assert rects == 12 and i16 == 0 and 3 <= sched <= 9
-    rects, i16, sched, gpu = [int(v) for v in subprocess.check_output(args, text=True, env=dict(os.environ, MJ_TILE_SCHEDULE="0")).split()]
+    rects, i16, sched, gpu = [int(v) for v in subprocess.check_output(args, text=True, env=dict(os.environ, MJ_AMD="no-tile-schedule")).split()]
     assert rects == 12 and i16 == 12 and sched == 0

@@ -325,7 +325,7 @@ print("ok")
     if not os.path.exists(faulty):
         import __graft_entry__ as g
         g.build_hip()
-    env = dict(os.environ, MJX_INJECT_FAILURE=where, MJX_ROOT=root, MJX_ARENAS="1", MJX_HIP_LIB=faulty)
+    env = dict(os.environ, MJX_INJECT_FAILURE=where, MJX_ROOT=root, MJX_OPTIONS="arenas=1", MJX_HIP_LIB=faulty)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert res.returncode == 0 and res.stdout.strip().endswith("ok"), (res.stdout[-300:], res.stderr[-800:])
     assert "failure injected" in res.stderr
@@ -668,20 +668,20 @@ def test_rectangles_made_of_blocks_that_need_no_blend(mj, i16):
 
 def test_host_paths_in_place_and_staged_give_the_same_bytes(mj):
     """mjx_compose_host / mjx_effect_dc_host work IN PLACE on pinned memory by default (spans up to 1 MB) and through staged
-    copies with MJX_COMPOSE_COPIES=1 / MJX_EFFECT_COPIES=1 or above 1 MB: both forms == oracle and == each other
+    copies with MJX_OPTIONS=compose-copies,effect-copies or above 1 MB: both forms == oracle and == each other
     (tests/tools/host_paths_check.py, one process per setting because the library reads the switches once)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = []
     for copies in (False, True):
-        env = {k: v for k, v in os.environ.items() if k not in ("MJX_COMPOSE_COPIES", "MJX_EFFECT_COPIES")}
+        env = {k: v for k, v in os.environ.items() if k != "MJX_OPTIONS"}
         if copies:
-            env.update(MJX_COMPOSE_COPIES="1", MJX_EFFECT_COPIES="1")
+            env.update(MJX_OPTIONS="compose-copies,effect-copies")
         out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "host_paths_check.py")], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stdout + out.stderr
         last = out.stdout.strip().splitlines()[-1].split()
-        assert last[:3] == ["host", "paths", "ok"] and last[3] == ("1" if copies else "-")
+        assert last[:3] == ["host", "paths", "ok"] and last[3] == ("compose-copies,effect-copies" if copies else "-")
         digests.append(last[-1])
     assert digests[0] == digests[1]
 

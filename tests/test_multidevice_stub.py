@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "libmodjpeg_amd", "host")
 IMAGES = os.path.join(ROOT, "tests", "golden", "images")
 JPEG = "/opt/conda"
-HOST_SRCS = ["jpegio.c", "dropon.c", "tiles.c", "tilecache.c", "compose.c", "effects.c", "gpuencode.c", "gpudecode.c", "shadow.c"]
+HOST_SRCS = ["jpegio.c", "dropon.c", "tiles.c", "tilecache.c", "compose.c", "effects.c", "gpuencode.c", "gpudecode.c", "shadow.c", "options.c"]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(JPEG, "include", "jpeglib.h")), reason="no jpeglib.h in this image")
 
@@ -38,7 +38,7 @@ def stubbed(tmp_path_factory):
     for prog, src in (("modjpeg", "modjpeg.c"), ("probe", os.path.join(ROOT, "tests", "tools", "probe.c"))):
         run(["gcc", *san, "-std=gnu99", *inc, "-o", os.path.join(d, prog), src, "-L" + d, "-Wl,-rpath," + d, "-Wl,--allow-shlib-undefined", "-lmodjpeg", "-lpthread", "-ldl", "-lm",
              *libs, "-Wl,-rpath," + os.path.join(JPEG, "lib")], cwd=HOST)
-    env = dict(os.environ, MJ_GPU_DECODE="0", MJ_GPU_ENCODE="0", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    env = dict(os.environ, MJ_AMD="no-gpu-decode,no-gpu-encode", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     return d, env
 
 

@@ -1,5 +1,5 @@
 """Run by tests/test_gpu_parity.py::test_host_paths_in_place_and_staged_give_the_same_bytes, once per setting of
-MJX_COMPOSE_COPIES / MJX_EFFECT_COPIES (the library reads them once per process): the per-image host-buffer calls
+MJX_OPTIONS=compose-copies,effect-copies (the library reads it once per process): the per-image host-buffer calls
 (mjx_compose_host with gathered rectangles, mjx_effect_dc_host) through their in-place form (the kernels work on the
 pinned staging buffer, which is mapped into the device) and through their staged form (copies up and down), against the
 oracle, and a digest of every output on stdout so that the caller can compare the two processes byte for byte.
@@ -75,4 +75,4 @@ for (bpr, rows, cols, value) in [(240, 136, 240, 7), (120, 68, 120, -2047), (33,
     assert np.array_equal(plane, want), (bpr, rows, cols, value)
     digest.update(plane.tobytes())
 
-print("host paths ok", os.environ.get("MJX_COMPOSE_COPIES", "-"), os.environ.get("MJX_EFFECT_COPIES", "-"), digest.hexdigest())
+print("host paths ok", os.environ.get("MJX_OPTIONS", "-"), digest.hexdigest())

@@ -17,7 +17,7 @@
  *        result must equal the one a single thread computed for the same placement.  Prints
  *        "ok" or the number of mismatches.
  *   mjhost_probe decodecmp <image.jpg>
- *        reads the file twice, with libjpeg's entropy decoder (MJ_GPU_DECODE=0) and with the GPU
+ *        reads the file twice, with libjpeg's entropy decoder (MJ_AMD=no-gpu-decode) and with the GPU
  *        one, and compares everything downstream code looks at: every block of every array row
  *        (the MCU padding included), the latched quantisation tables, the dimensions that
  *        jpeg_copy_critical_parameters() copies.  Prints "same gpu" (GPU path taken),
@@ -93,6 +93,7 @@ static uint64_t compose_hash(int placement) {
 /* MJ_STRESS_DEVICES=n: worker t works on GPU t mod n (cached tiles, schedules and staging arenas of the
  * n devices interleave in the same cache / pool; nothing of one device may reach a thread of another) */
 extern int mjh_use_device(int ordinal);
+extern void mjh_set_option_named(const char *token, int on); /* host/options.c: a token of MJ_AMD, switched inside the process */
 static void *stress_worker(void *arg) {
     const int   id = (int)(intptr_t)arg;
     const char *e = getenv("MJ_STRESS_DEVICES");
@@ -141,9 +142,9 @@ static int compare_reads(const unsigned char *buf, size_t len) {
     int        c, before, took_gpu, ra, rb, result = 2;
     mj_init_jpeg(&a);
     mj_init_jpeg(&b);
-    setenv("MJ_GPU_DECODE", "0", 1);
+    mjh_set_option_named("no-gpu-decode", 1);
     ra = mj_read_jpeg_from_memory(&a, buf, len, 0);
-    setenv("MJ_GPU_DECODE", "1", 1);
+    mjh_set_option_named("no-gpu-decode", 0);
     before = mjh_gpu_decode_count;
     rb = mj_read_jpeg_from_memory(&b, buf, len, 0);
     took_gpu = mjh_gpu_decode_count - before;
@@ -238,8 +239,8 @@ static int opttables(const char *path, int mode, uint32_t seed) {
     }
     if(mjx_huff_optimal_table == NULL) return 9;
     mj_init_jpeg(&m);
-    setenv("MJ_GPU_DECODE", "0", 1);
-    setenv("MJ_GPU_ENCODE", "0", 1);
+    mjh_set_option_named("no-gpu-decode", 1);
+    mjh_set_option_named("no-gpu-encode", 1);
     if(mj_read_jpeg_from_file(&m, path, 0) != MJ_OK) return 10;
     memset(hist, 0, sizeof(hist));
     for(c = 0; c < m.cinfo.num_components; c++) {
@@ -537,7 +538,7 @@ int main(int argc, char **argv) {
         void     *p0, *p1, *p2;
         char      probe16[16];
         mj_init_jpeg(&m);
-        setenv("MJ_GPU_DECODE", "0", 1);
+        mjh_set_option_named("no-gpu-decode", 1);
         if(mj_read_jpeg_from_file(&m, argv[2], 0) != MJ_OK) return 10;
         mjh_set_device_resident(1);
         if(mjh_use_device(0) != MJ_OK || mjh_shadow_create(&m) == NULL) return 11;
