@@ -39,7 +39,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 BYTES_PER_BLOCK = 768  # 128 JCOEF read + 256 tile + 256 alpha + 128 JCOEF write
-EFFECT_SECTOR_BYTES = 96  # what the counters show per DC of the effects pass: a 64-byte fetch and a 32-byte write-back (profiles/r04/effects_4k_rocprof_summary.txt)
+# what the memory system moves per DC of the effects pass: ONE read request for the DC's whole 128-byte line (TCC_EA0_RDREQ = 1 per DC, none
+# of them 32-byte ones; FETCH_SIZE tallies it at 64 bytes, as it does the compose kernels' 128-byte requests) and one 32-byte write request
+# (profiles/r05/rocprof_summary.txt, profiles/r05/dc_stride_counters.txt: a read of 2, 16, 64 or 128 bytes of a block is the same request)
+EFFECT_MOVED_BYTES = 160
 
 WORKLOADS = {
     # name: (width, height, dropon_w, dropon_h, mcu_x, mcu_y, images of the whole job)
@@ -470,7 +473,8 @@ def also_effects(steps, image0=0, images=4096):
     out = {"workload": "effects_4k_batch", "images": images, "dc_blocks_per_step": dcs, "steps": steps, "ms_per_step": ms, "blocks_per_s": dcs / (ms * 1e-3),
            "parity": "bit-exact" if bad == 0 else f"MISMATCH in {bad} of 6 planes", "parity_sample_images": 2,
            "frac_at_4_bytes_per_dc": dcs * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "frac_at_sector_bytes_per_dc": dcs * EFFECT_SECTOR_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "sector_bytes_per_dc": EFFECT_SECTOR_BYTES,
+           "bytes_moved_per_dc": EFFECT_MOVED_BYTES, "frac_on_bytes_moved": dcs * EFFECT_MOVED_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "read_only_pass_would_take_ms": dcs / 50e9 * 1e3,  # 49-56 G lines/s: what reading every DC costs alone (scripts/ubench/dc_stride.hip rd2 .. rd128)
            "wall_s": None}
     eb.destroy_plans()
     del eb
@@ -773,9 +777,9 @@ def bench_effects(args, rank, world):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "mjx::effect_dc_kernel (two launches per step)", "kernel_ms_mean": mean_ms,
                          "algorithmic_bytes_per_launch": dcs * 4,
-                         # "also report the sector-realistic figure": what the counters show travelling per DC (FETCH_SIZE 64 B, WRITE_SIZE 32 B)
-                         "sector_granular": {"achieved": dcs * EFFECT_SECTOR_BYTES / (mean_ms * 1e-3) / 1e9, "frac": dcs * EFFECT_SECTOR_BYTES / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                             "bytes_per_dc": EFFECT_SECTOR_BYTES, "note": "64 bytes fetched + 32 bytes written back per 2-byte DC by the rocprofv3 counters"},
+                         # "also report the sector-realistic figure": what the memory system moves per DC
+                         "bytes_moved": {"achieved": dcs * EFFECT_MOVED_BYTES / (mean_ms * 1e-3) / 1e9, "frac": dcs * EFFECT_MOVED_BYTES / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "bytes_per_dc": EFFECT_MOVED_BYTES, "note": "one read request for the whole 128-byte line (TCC_EA0_RDREQ 1 per DC, no 32-byte ones) + one 32-byte write request per 2-byte DC"},
                          "line_granular": {"achieved": line_gbs, "frac": line_gbs / HBM_PEAK_GBS, "bytes_per_dc": 256,
                                            "note": "one 128-byte line touched for reading and one for writing per DC: the unit the pass's time scales with (DESIGN.md 5), not bytes the counters show"}},
             "per_rank": per_rank,

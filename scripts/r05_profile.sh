@@ -61,7 +61,7 @@ with open(f"{O}/summary.txt", "w") as out:
                 if "also" in d:
                     P("   plan_ms", json.dumps({k: v for k, v in d["plan_ms"].items() if k != "note"}), " frac_without_promise", r.get("frac_without_promise"), "kernel_ms_without_promise", r.get("kernel_ms_without_promise"))
                     for k, v in d["also"].items():
-                        if isinstance(v, dict): P("   also", k, "ms_per_step %.4f" % v["ms_per_step"], v["parity"], "frac_on_bytes_moved", v.get("frac_on_bytes_moved", v.get("frac_at_sector_bytes_per_dc")))
+                        if isinstance(v, dict): P("   also", k, "ms_per_step %.4f" % v["ms_per_step"], v["parity"], "frac_on_bytes_moved", v.get("frac_on_bytes_moved"))
             except Exception as e:
                 P("   bench line unreadable", e)
         else:
