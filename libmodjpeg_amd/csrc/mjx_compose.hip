@@ -1047,17 +1047,31 @@ MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
         if constexpr(DC) static_for<kWaveBlocks>([&](auto K) { t.w[K] = (unsigned)g[kWaveBlocks + K]; });
         return t;
     };
+    // Every lane takes its block's word out of eight wave-uniform ones (SGPRs).  Round 4 did it with seven selects per word, which
+    // on gfx950 (one scalar operand per VALU instruction) the compiler turns into 7 v_cndmask + 15-30 v_mov: 22 of a zero-alpha
+    // octet's 82 vector instructions and 73 of a DC-only octet's 182 (two words: index and weight) - in a step that is bound by the
+    // vector ALU.  Now: v_writelane puts word K into lane 8K, and two DPP moves spread it over the block's eight
+    // lanes (quad_perm [0,0,0,0]: lanes 8K..8K+3; row_shr:4 into banks 1 and 3: lanes 8K+4..8K+7): 10 instructions per word.
+    // (inline asm: this compiler has no writelane builtin; the s_nop are the two wait states a DPP read of a register needs after a
+    // VALU write of it; v_writelane ignores EXEC, the DPP moves run with all 64 lanes active, as everything in this kernel does)
+    auto pick = [&](const auto &w8) {
+        int v;
+        asm("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 8\n\tv_writelane_b32 %0, %3, 16\n\tv_writelane_b32 %0, %4, 24\n\t"
+            "v_writelane_b32 %0, %5, 32\n\tv_writelane_b32 %0, %6, 40\n\tv_writelane_b32 %0, %7, 48\n\tv_writelane_b32 %0, %8, 56\n\t"
+            "s_nop 1\n\tv_mov_b32_dpp %0, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_mov_b32_dpp %0, %0 row_shr:4 row_mask:0xf bank_mask:0xa"
+            : "=&v"(v)
+            : "s"((int)w8[0]), "s"((int)w8[1]), "s"((int)w8[2]), "s"((int)w8[3]), "s"((int)w8[4]), "s"((int)w8[5]), "s"((int)w8[6]), "s"((int)w8[7]));
+        return v;
+    };
     auto fetch = [&](const Tab &t) {
-        int n = t.n[0];
-        static_for<kWaveBlocks - 1>([&](auto K) { n = b == K + 1 ? t.n[K + 1] : n; });
+        const int n = pick(t.n);
         Octet o;
         o.pblk = plane_block_of(job, n);
         if constexpr(WIDE) o.c4 = global_load16_nt(reinterpret_cast<const char *>(job.coef) + ((size_t)o.pblk * 128 + (size_t)r * 16));
         else o.c4 = global_load16_nt(reinterpret_cast<const char *>(job.coef) + (o.pblk * 128u + (unsigned)r * 16u));
         if constexpr(DC) {
-            unsigned w = t.w[0];
-            static_for<kWaveBlocks - 1>([&](auto K) { w = b == K + 1 ? t.w[K + 1] : w; });
-            o.w[0] = w;
+            o.w[0] = (unsigned)pick(t.w);
             if constexpr(I16) {
                 o.t[0] = global_load16_nt(reinterpret_cast<const char *>(job.tile) + ((unsigned)n * 128u + (unsigned)r * 16u));
             }
