@@ -39,10 +39,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 BYTES_PER_BLOCK = 768  # 128 JCOEF read + 256 tile + 256 alpha + 128 JCOEF write
-# what the memory system moves per DC of the effects pass: ONE read request for the DC's whole 128-byte line (TCC_EA0_RDREQ = 1 per DC, none
-# of them 32-byte ones; FETCH_SIZE tallies it at 64 bytes, as it does the compose kernels' 128-byte requests) and one 32-byte write request
-# (profiles/r05/rocprof_summary.txt, profiles/r05/dc_stride_counters.txt: a read of 2, 16, 64 or 128 bytes of a block is the same request)
-EFFECT_MOVED_BYTES = 160
+# what the effects pass moves per DC: the DC's whole 128-byte block in and out (effect_dc_lines_kernel: eight lanes per block, non-temporal).  A
+# read of ANY part of a block is one request for its whole line anyway (TCC_EA0_RDREQ = 1 per DC, none of them 32-byte ones, whether 2, 16, 64 or
+# 128 bytes are read: profiles/r05/dc_stride_counters.txt), and whole-line writes are what the memory system takes fastest
+EFFECT_MOVED_BYTES = 256
 
 WORKLOADS = {
     # name: (width, height, dropon_w, dropon_h, mcu_x, mcu_y, images of the whole job)
@@ -764,7 +764,6 @@ def bench_effects(args, rank, world):
     per_rank = gather_objects({"rank": rank, "image0": image0, "images": images, "dc_blocks_per_step": dcs, "kernel_ms_mean": mean_ms, "parity": parity}, world)
     if rank == 0:
         achieved = dcs * 4 / (mean_ms * 1e-3) / 1e9          # 2 B read + 2 B written per DC
-        line_gbs = dcs * 256 / (mean_ms * 1e-3) / 1e9        # what the memory system moves: one 128-byte line in, one out
         traffic, traffic_src = traffic_from_profiles(args.traffic_json, f"effects_4k_batch:{images}")
         verdicts = {r["parity"] for r in per_rank}
         print(json.dumps({
@@ -775,13 +774,11 @@ def bench_effects(args, rank, world):
                        "image": "3840x2160 4:2:0", "calls": "luminance(+7); tint(+5,-3)", "parallelism": f"images sharded x{world} ({args.scaling}), no collective, no RCCL"},
             "parity": verdicts.pop() if len(verdicts) == 1 else "mixed: see per_rank",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mjx::effect_dc_kernel (two launches per step)", "kernel_ms_mean": mean_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mjx::effect_dc_lines_kernel (two launches per step)", "kernel_ms_mean": mean_ms,
                          "algorithmic_bytes_per_launch": dcs * 4,
                          # "also report the sector-realistic figure": what the memory system moves per DC
                          "bytes_moved": {"achieved": dcs * EFFECT_MOVED_BYTES / (mean_ms * 1e-3) / 1e9, "frac": dcs * EFFECT_MOVED_BYTES / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                         "bytes_per_dc": EFFECT_MOVED_BYTES, "note": "one read request for the whole 128-byte line (TCC_EA0_RDREQ 1 per DC, no 32-byte ones) + one 32-byte write request per 2-byte DC"},
-                         "line_granular": {"achieved": line_gbs, "frac": line_gbs / HBM_PEAK_GBS, "bytes_per_dc": 256,
-                                           "note": "one 128-byte line touched for reading and one for writing per DC: the unit the pass's time scales with (DESIGN.md 5), not bytes the counters show"}},
+                                         "bytes_per_dc": EFFECT_MOVED_BYTES, "note": "the whole 128-byte block read and written back per 2-byte DC: a copy of the planes onto themselves"}},
             "per_rank": per_rank,
             "cpu_baseline": cpu_info}))
         sys.stdout.flush()

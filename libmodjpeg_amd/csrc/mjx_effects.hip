@@ -17,8 +17,9 @@
 //    cache policy matters more than the width: plain load + NON-TEMPORAL store of the 2-byte DC 22.3, everything non-temporal on
 //    whole lines 22.6-23.4, non-temporal LOADS of the 2-byte form 15-16 (the line is gone from L2 when its store arrives).
 //    Four blocks in flight per lane is the best depth (8: -12 %, 16: -23 %).
-// Hence: plain loads, non-temporal stores, four DCs per lane.  No form of the update reaches 1 / (1/50 + 1/59) = 27 G blocks/s,
-// the sum of what its read and a 64-byte write cost alone.
+// Hence, for the 2-byte form (effect_dc_kernel): plain loads, non-temporal stores, four DCs per lane - and, better still, not the
+// 2-byte form at all: effect_dc_lines_kernel below moves whole blocks.  No form of the update reaches 1 / (1/50 + 1/59) = 27 G
+// blocks/s, the sum of what its read and a 64-byte write cost alone.
 #include "mjx_block_math.hpp"
 #include "mjx_internal.hpp"
 
@@ -63,8 +64,63 @@ __global__ __launch_bounds__(256) void effect_dc_kernel(const DevDcJob *__restri
     }
 }
 
+// The same update moving every block WHOLE: eight lanes per block, 16 bytes each, everything non-temporal, two in flight per lane.
+// It reads and writes 256 bytes per DC instead of requesting 160, and is the faster form: dc_stride.hip 23.4 against 22.3 G blocks/s;
+// BASELINE configs[4] (4096 x 4K resident) 33.9-34.0 against 37.2-37.6 ms per step on one box, alternating
+// (profiles/r05/effects_whole_lines_ab.txt) = 204 GB in 34 ms = 6.0 TB/s: a copy of the planes onto themselves at the device's copy
+// rate, which is the floor of an update that has to touch every line.  MJX_EFFECT_WHOLE_LINES=0 builds the 2-byte form (above).
+#ifndef MJX_EFFECT_WHOLE_LINES
+#define MJX_EFFECT_WHOLE_LINES 1
+#endif
+constexpr int kLinesPerThread = 2;
+typedef unsigned int              eu32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) eu32x4 g_eu32x4;
+
+__global__ __launch_bounds__(256) void effect_dc_lines_kernel(const DevDcJob *__restrict__ jobs) {
+    const DevDcJob  j = jobs[blockIdx.y];
+    const int       total = j.rows * j.cols;
+    const long long first = (long long)blockIdx.x * (256 * kLinesPerThread);
+    if(total <= 0 || first >= (long long)total * 8) return; // (uniform: a job smaller than the launch's largest)
+    const bool dense = (j.cols == j.bpr);
+
+    g_eu32x4 *p[kLinesPerThread];
+    eu32x4    v[kLinesPerThread];
+    bool      ok[kLinesPerThread], head[kLinesPerThread];
+#pragma unroll
+    for(int i = 0; i < kLinesPerThread; ++i) {
+        const long long t = first + (long long)i * 256 + threadIdx.x;
+        const int       g = (int)(t >> 3), c = (int)(t & 7);
+        ok[i] = g < total;
+        head[i] = c == 0;
+        const int gc = ok[i] ? g : total - 1;
+        size_t    blk = (size_t)gc;
+        if(!dense) {
+            const int row = gc / j.cols;
+            blk = (size_t)row * (size_t)j.bpr + (size_t)(gc - row * j.cols);
+        }
+        p[i] = (g_eu32x4 *)(uintptr_t)(j.coef + blk * 64 + c * 8);
+        v[i] = __builtin_nontemporal_load(p[i]);
+    }
+#pragma unroll
+    for(int i = 0; i < kLinesPerThread; ++i) {
+        if(head[i]) { // effect.c:207-217 on coefficient 0, the low half of the first dword
+            int d = dequant((int)(short)(v[i].x & 0xFFFFu), j.q0);
+            d = wrap16((int)((unsigned)d + (unsigned)j.value));
+            d = d > 2047 ? 2047 : (d < -2047 ? -2047 : d);
+            v[i].x = (v[i].x & 0xFFFF0000u) | ((unsigned)requant(d, j.rq0) & 0xFFFFu);
+        }
+        if(ok[i]) __builtin_nontemporal_store(v[i], p[i]);
+    }
+}
+
 int launch_effect_dc(const DevDcJob *jobs, int njobs, int64_t max_blocks, hipStream_t s) {
     if(njobs <= 0 || max_blocks <= 0) return MJX_OK;
+#if MJX_EFFECT_WHOLE_LINES
+    const int64_t per_group_l = 256 * kLinesPerThread / 8; // blocks per workgroup
+    dim3          grid_l((unsigned)((max_blocks + per_group_l - 1) / per_group_l), (unsigned)njobs);
+    hipLaunchKernelGGL(effect_dc_lines_kernel, grid_l, dim3(256), 0, s, jobs);
+    return check_hip(hipGetLastError(), "effect_dc_lines_kernel launch", MJX_ERR_LAUNCH);
+#endif
     const int64_t per_group = 256 * kDcPerThread;
     dim3          grid((unsigned)((max_blocks + per_group - 1) / per_group), (unsigned)njobs);
     hipLaunchKernelGGL(effect_dc_kernel, grid, dim3(256), 0, s, jobs);
