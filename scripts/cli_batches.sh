@@ -10,6 +10,6 @@ for i in $(seq 1 $n); do echo $work/in/img$(( (i % 16) + 1 )).jpg >> $work/list.
 cp tests/golden/images/dropon.png $work/logo.png
 for b in ${BATCHES:-1 2 4 32}; do for jobs in 16 32; do
   echo -n "encode batches=$b jobs=$jobs : "
-  MJX_ENCODE_BATCHES=$b $H/modjpeg --batch $work/list.txt --outdir $work/out --jobs $jobs -p br -m -10,-10 -d $work/logo.png -y 10 2>&1 | tail -1
+  LD_PRELOAD=$PWD/libmodjpeg_amd/libmjx_hip_faultinj.so MJX_ENCODE_BATCHES=$b $H/modjpeg --batch $work/list.txt --outdir $work/out --jobs $jobs -p br -m -10,-10 -d $work/logo.png -y 10 2>&1 | tail -1
 done; done
 rm -rf $work
