@@ -57,3 +57,27 @@ def test_tile_cache_and_buffer_pools_across_devices(two_devices):
     assert res.returncode == 0 and res.stdout.strip() == "ok", (res.stdout[-300:], res.stderr[-800:])
     res = subprocess.run([probe, "shadowpool", os.path.join(IMAGES, "image.jpg")], capture_output=True, text=True)
     assert res.returncode == 0 and res.stdout.strip() == "ok", (res.returncode, res.stdout, res.stderr[-800:])
+
+
+def test_a_plan_runs_on_the_device_it_was_made_on(two_devices):
+    """mjx.h (105): a plan's tables, its side stream and its events belong to the device it was made on; mjx_compose_run from a
+    thread whose current device is another one is refused (MJX_ERR_BAD_ARG) instead of launching with foreign pointers"""
+    import ctypes
+    import numpy as np
+    import torch
+    from libmodjpeg_amd._lib import MJX_ERR_BAD_ARG, RectJob, check, lib
+    torch.cuda.set_device(0)
+    coef = torch.zeros((4, 4, 64), dtype=torch.int16, device="cuda:0")
+    tile = torch.zeros((4, 64), dtype=torch.float32, device="cuda:0")
+    q = np.ones(64, np.uint16)
+    job = RectJob(coef.data_ptr(), tile.data_ptr(), tile.data_ptr(), 4, 4, 1, 1, 2, 2, 0, 0)
+    plan = ctypes.c_void_p()
+    check(lib().mjx_compose_plan_create(ctypes.byref(plan), ctypes.pointer(job), 1, q.ctypes.data_as(ctypes.c_void_p), 1), "plan")
+    try:
+        check(lib().mjx_compose_run(plan, None), "run on device 0")
+        torch.cuda.synchronize()
+        torch.cuda.set_device(1)
+        assert lib().mjx_compose_run(plan, None) == MJX_ERR_BAD_ARG
+    finally:
+        torch.cuda.set_device(0)
+        lib().mjx_compose_plan_destroy(plan)

@@ -721,3 +721,18 @@ def test_grouped_plan_without_the_promise_follows_later_changes_of_alpha(mj):
     want = coef.reshape(-1).copy()
     O.compose_rect(want, bpr, row0, col0, rows, cols, q, tile.reshape(-1), dense.reshape(-1))
     assert np.array_equal(d_c.cpu().numpy().reshape(-1), want)
+
+
+def test_the_kernel_library_reads_one_environment_variable():
+    """mjx::option(): MJX_OPTIONS is parsed once; an unknown token is reported once on stderr and ignored, known tokens beside
+    it count (arenas=1 here; decode-rounds / compose-copies / effect-copies are forced by the tests that compare their forms)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, ctypes; sys.path.insert(0, %r); from libmodjpeg_amd._lib import lib; vp = ctypes.c_void_p\n"
+            "p = np.zeros(4 * 4 * 64, np.int16); q = np.ones(64, np.uint16); t = np.zeros(64, np.float32)\n"
+            "for _ in range(3): assert lib().mjx_compose_rect_host(p.ctypes.data_as(vp), 4, 4, 1, 1, 1, 1, q.ctypes.data_as(vp), t.ctypes.data_as(vp), t.ctypes.data_as(vp)) == 0\n"
+            "print('ok')\n") % root
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MJX_OPTIONS="bogus=3,arenas=1,,wait=block"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.strip().endswith("ok"), res.stdout + res.stderr
+    assert res.stderr.count('MJX_OPTIONS: unknown option "bogus" ignored') == 1, res.stderr[-800:]

@@ -139,3 +139,16 @@ def test_no_simulated_device_is_no_device(stubbed):
     d, env = stubbed
     res = subprocess.run([os.path.join(d, "probe"), "nodevice", os.path.join(IMAGES, "image.jpg")], env=env, capture_output=True, text=True)
     assert res.returncode == 0 and res.stdout.split()[:2] == ["1", "1"], (res.stdout, res.stderr[-500:])
+
+
+def test_the_drop_in_reads_one_environment_variable(stubbed):
+    """host/options.c: MJ_AMD is a comma-separated list of tokens, parsed once; an unknown token is reported once on stderr and
+    ignored, the known ones beside it still count (here `debug`: the probe's read of a progressive file says why it fell back)"""
+    d, env = stubbed
+    res = subprocess.run([os.path.join(d, "probe"), "nodevice", os.path.join(IMAGES, "image.jpg")], env=dict(env, MJ_AMD="bogus-token,no-gpu-decode,,no-gpu-encode"), capture_output=True, text=True)
+    assert res.returncode == 0, (res.stdout, res.stderr[-500:])
+    assert res.stderr.count('MJ_AMD: unknown option "bogus-token" ignored') == 1, res.stderr[-800:]
+    # the round-4 names are not read any more: setting them changes nothing and warns about nothing
+    res = subprocess.run([os.path.join(d, "probe"), "nodevice", os.path.join(IMAGES, "image.jpg")], env=dict({k: v for k, v in env.items() if k != "MJ_AMD"}, MJ_GPU_DECODE="0"), capture_output=True,
+                         text=True)
+    assert "unknown option" not in res.stderr
