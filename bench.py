@@ -22,9 +22,12 @@ Also printed on the same JSON line:
                 `kernel_ms_pristine` = the same kernel on planes restored from a pristine copy
                 before every launch (untimed restore; compose is in place and not idempotent)
   per_rank      kernel ms, blocks and the parity verdict of every rank
-  cpu_baseline  the CPU oracle (oracle/mjx_oracle.c, the restatement proven bit-identical to the
-                compiled reference) on a bounded sample of the same workload on this box's cores;
-                rank 0, N == 1 only.  The same sample is used to bit-compare the GPU output.
+  cpu_baseline  the UNMODIFIED reference's mj_compose_with_mask (oracle/_ref/ref_bench: compiled from the
+                reference's own sources, "kind": "reference") on a bounded sample of the same workload on
+                this box's cores, with the CPU oracle's figures beside it (oracle/mjx_oracle.c, "port": the
+                restatement, compared with the reference row by row in the same run; it alone when
+                oracle/_ref is absent); rank 0, N == 1 only.  The oracle's output on the sample is what
+                the GPU output is bit-compared with.
 """
 import argparse
 import json
@@ -332,7 +335,37 @@ def cpu_baseline_and_expected(batch_cfg, regime, nsample, image0, timing=True, t
                   f"(-O2 -ffp-contract=off), {cores} pthreads on {hw_threads} hardware threads = {physical} physical cores, {reps} repeats",
         "value_1thread": sub_blocks / t_one, "gbs_equiv": rate_all * BYTES_PER_BLOCK / 1e9, "cpu_model": cpu_model(),
     }
+    ref = reference_cpu_baseline(batch_cfg, regime, nsample, image0, cores) if tiles is None else None
+    if ref is not None:
+        # the UNMODIFIED reference's mj_compose_with_mask, compiled from its own sources (oracle/Makefile -> oracle/_ref), on the same
+        # sample: the baseline north_star names; the port's figures stay beside it
+        info = dict(info, kind="reference", value=ref["blocks_per_s"], value_1thread=ref["blocks_per_s_1thread"], gbs_equiv=ref["blocks_per_s"] * BYTES_PER_BLOCK / 1e9,
+                    sample=f"{nsample} images x {ref['blocks_per_image']} blocks of the same synthetic workload through the unmodified reference's mj_compose_with_mask "
+                           f"(compose.c:237; oracle/_ref/ref_bench, -O2 -ffp-contract=off, IJG libjpeg 9d arrays), {cores} pthreads on {hw_threads} hardware threads = {physical} physical cores, "
+                           f"whole passes for at least 2 s; timed: copying the rectangle's coefficients into libjpeg's arrays + the call",
+                    reference_rows_compared_with_the_port=ref["rows_compared_with_the_restatement"], reference_rows_that_differ=ref["rows_that_differ"],
+                    port={"value": rate_all, "value_1thread": sub_blocks / t_one, "what": "oracle/mjx_oracle.c on the same sample: the checker of the GPU output"})
     return info, expected
+
+
+def reference_cpu_baseline(batch_cfg, regime, nsample, image0, threads):
+    """oracle/_ref/ref_bench (oracle/ref_bench.c: our harness around the reference compiled from its own sources by oracle/Makefile; the
+    binaries are built in the build container and travel with the repository snapshot - nothing is read from the reference's tree at
+    run time).  Returns its JSON, or None when it is absent or fails (the port is the baseline then)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    if not os.path.exists(exe):
+        return None
+    width, height, dw, dh, mcu_x, mcu_y = batch_cfg
+    try:
+        out = subprocess.run([exe, str(width), str(height), str(dw), str(dh), str(mcu_x), str(mcu_y), str(regime), str(image0), str(nsample), str(threads), "2.0"],
+                             capture_output=True, text=True, timeout=300)
+        if out.returncode != 0:
+            print(f"bench.py: oracle/_ref/ref_bench failed ({out.returncode}): {out.stderr[-300:]}", file=sys.stderr)
+            return None
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001 - a missing libjpeg, a timeout: the port stays the baseline
+        print(f"bench.py: oracle/_ref/ref_bench not usable: {e}", file=sys.stderr)
+        return None
 
 
 def cpu_topology():

@@ -152,3 +152,19 @@ def test_synth_is_deterministic_and_in_range():
     assert 6.5 < cnt.mean() < 10
     octets = cnt.reshape(-1, 8)
     assert np.mean(octets.max(axis=1) >= 60) > 0.4 and np.mean((octets.max(axis=1) >= 60) & (octets.min(axis=1) <= 1)) > 0.4
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(O.ORACLE_DIR, "_ref", "ref_bench")), reason="oracle/_ref/ref_bench not built (no /root/reference here)")
+@pytest.mark.parametrize("regime", [1, 2, 3, 4])
+def test_block_loop_live_vs_reference_on_the_bench_workload(regime):
+    """oracle/_ref/ref_bench: the UNMODIFIED reference's mj_compose_with_mask (compose.c:237, 64 mj_convolve calls per block) on
+    libjpeg's coefficient arrays against the restatement, on the synthetic workload bench.py measures (a 64x48 dropon here, every
+    alpha regime): every row of every rectangle identical.  The same binary is bench.py's cpu_baseline ("kind": "reference")."""
+    import json
+    import subprocess
+    exe = os.path.join(O.ORACLE_DIR, "_ref", "ref_bench")
+    out = subprocess.run([exe, "640", "480", "64", "48", "5", "7", str(regime), "1000", "4", "2", "0.05"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["rows_compared_with_the_restatement"] == 4 * (6 + 3 + 3) and d["rows_that_differ"] == 0, d
+    assert d["blocks_per_s"] > 0 and d["blocks_per_s_1thread"] > 0
