@@ -750,6 +750,21 @@ def effects_cpu_baseline_and_expected(geo, quant, image0, nsample, lum, cb, cr, 
     info = {"value": dcs * reps / t_rep, "unit": "blocks/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{nsample} images x {dcs // nsample} DC blocks (3840x2160 4:2:0), oracle/mjx_oracle.c orc_effect_dc, 1 thread "
                       f"(the reference is single-threaded), {reps} repeats"}
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    if os.path.exists(exe):  # the unmodified reference's mj_effect_luminance + mj_effect_tint on libjpeg's arrays (oracle/ref_bench.c, effects mode)
+        try:
+            out = subprocess.run([exe, "effects", str(geo.width), str(geo.height), str(image0), str(nsample), str(lum), str(cb), str(cr), "2.0"], capture_output=True, text=True, timeout=300)
+            if out.returncode == 0:
+                ref = json.loads(out.stdout.strip().splitlines()[-1])
+                info = dict(info, kind="reference", value=ref["dc_blocks_per_s"],
+                            sample=f"{nsample} images x {ref['dc_blocks_per_image']} DC blocks ({geo.width}x{geo.height} 4:2:0) through the unmodified reference's mj_effect_luminance + mj_effect_tint "
+                                   f"(effect.c:185, :116; oracle/_ref/ref_bench), 1 thread (the reference is single-threaded), {ref['passes']} passes",
+                            reference_rows_compared_with_the_port=ref["rows_compared_with_the_restatement"], reference_rows_that_differ=ref["rows_that_differ"],
+                            port={"value": dcs * reps / t_rep, "what": "oracle/mjx_oracle.c orc_effect_dc on the same sample"})
+            else:
+                print(f"bench.py: oracle/_ref/ref_bench effects failed ({out.returncode}): {out.stderr[-300:]}", file=sys.stderr)
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: oracle/_ref/ref_bench not usable: {e}", file=sys.stderr)
     return info, expected
 
 

@@ -15,6 +15,7 @@
  * prepared tiles as well.)
  *
  * usage: ref_bench <width> <height> <dropon_w> <dropon_h> <mcu_x> <mcu_y> <regime> <image0> <nimages> <threads> <min_seconds>
+ *        ref_bench effects <width> <height> <image0> <nimages> <lum> <cb> <cr> <min_seconds>      (the DC effects, below)
  * prints one JSON object.
  */
 #include <stddef.h>
@@ -176,7 +177,81 @@ static void *worker_run(void *arg) {
     return NULL;
 }
 
+/* ---- effects mode: ref_bench effects <width> <height> <image0> <nimages> <lum> <cb> <cr> <min_seconds> --------------------------
+ * mj_effect_luminance(lum) then mj_effect_tint(cb, cr) (reference effect.c:185-222, :116-183) on whole images whose coefficient
+ * arrays hold the synthetic planes of bench.py's effects workload, one thread (the reference is single-threaded; the workload is a
+ * pass over memory); compared DC for DC and block for block with the restatement's orc_effect_dc. */
+static int effects_main(int argc, char **argv) {
+    if(argc != 10) {
+        fprintf(stderr, "usage: ref_bench effects width height image0 nimages lum cb cr min_seconds\n");
+        return 2;
+    }
+    g_w = atoi(argv[2]); g_h = atoi(argv[3]); g_image0 = strtoull(argv[4], NULL, 10); g_nimages = atoi(argv[5]);
+    const int    lum = atoi(argv[6]), cb = atoi(argv[7]), cr = atoi(argv[8]);
+    const double min_seconds = atof(argv[9]);
+    make_carrier();
+    mj_jpeg_t m;
+    mj_init_jpeg(&m);
+    if(mj_read_jpeg_from_memory(&m, g_jpeg, g_jpeg_len, 0) != MJ_OK || m.cinfo.num_components != 3) return 3;
+    int16_t  **pristine = calloc((size_t)g_nimages * 3, sizeof(int16_t *)), *want[3];
+    int        c, r, img, differ = 0, checked = 0;
+    long long  dcs_image = 0;
+    for(c = 0; c < 3; c++) {
+        const jpeg_component_info *ci = &m.cinfo.comp_info[c];
+        want[c] = malloc((size_t)ci->height_in_blocks * ci->width_in_blocks * 128);
+        dcs_image += (long long)ci->height_in_blocks * ci->width_in_blocks;
+    }
+    for(img = 0; img < g_nimages; img++) { /* the synthetic planes, generated once: the true width x height of every component, rows
+                                              keeping the workload's plane pitch (arrays of an interleaved scan: whole MCUs) */
+        for(c = 0; c < 3; c++) {
+            const jpeg_component_info *ci = &m.cinfo.comp_info[c];
+            const int      hmax = m.cinfo.max_h_samp_factor, mcus_x = (g_w + 8 * hmax - 1) / (8 * hmax);
+            const uint64_t bpr = (uint64_t)mcus_x * (uint64_t)ci->h_samp_factor;
+            uint16_t       q[64];
+            int            i;
+            for(i = 0; i < 64; i++) q[i] = (uint16_t)ci->quant_table->quantval[i];
+            pristine[3 * img + c] = malloc((size_t)ci->height_in_blocks * ci->width_in_blocks * 128);
+            for(r = 0; r < (int)ci->height_in_blocks; r++)
+                orc_synth_coef(pristine[3 * img + c] + (size_t)r * ci->width_in_blocks * 64, g_image0 + (uint64_t)img, (uint32_t)c, (uint64_t)r * bpr, (size_t)ci->width_in_blocks, q);
+        }
+    }
+    double    seconds = 0;
+    long long dcs = 0;
+    int       passes = 0;
+    do {
+        for(img = 0; img < g_nimages; img++) {
+            for(c = 0; c < 3; c++) {
+                const jpeg_component_info *ci = &m.cinfo.comp_info[c];
+                for(r = 0; r < (int)ci->height_in_blocks; r++)
+                    memcpy(row_ptr(&m, c, r)[0], pristine[3 * img + c] + (size_t)r * ci->width_in_blocks * 64, (size_t)ci->width_in_blocks * 128);
+            }
+            const double t0 = now_s();
+            if(mj_effect_luminance(&m, lum) != MJ_OK || mj_effect_tint(&m, cb, cr) != MJ_OK) return 4;
+            seconds += now_s() - t0;
+            dcs += dcs_image;
+            if(passes == 0 && img < 2) { /* parity with the restatement on the first images */
+                const int value[3] = {lum, cb, cr};
+                for(c = 0; c < 3; c++) {
+                    const jpeg_component_info *ci = &m.cinfo.comp_info[c];
+                    memcpy(want[c], pristine[3 * img + c], (size_t)ci->height_in_blocks * ci->width_in_blocks * 128);
+                    if(!(c > 0 && value[c] == 0)) orc_effect_dc(want[c], (int)ci->width_in_blocks, (int)ci->height_in_blocks, (int)ci->width_in_blocks, (uint16_t)ci->quant_table->quantval[0], value[c]);
+                    for(r = 0; r < (int)ci->height_in_blocks; r++) {
+                        if(memcmp(row_ptr(&m, c, r)[0], want[c] + (size_t)r * ci->width_in_blocks * 64, (size_t)ci->width_in_blocks * 128) != 0) differ++;
+                        checked++;
+                    }
+                }
+            }
+        }
+        passes++;
+    } while(seconds < min_seconds);
+    printf("{\"dc_blocks_per_s\": %.1f, \"threads\": 1, \"images\": %d, \"dc_blocks_per_image\": %lld, \"passes\": %d, \"rows_compared_with_the_restatement\": %d, "
+           "\"rows_that_differ\": %d, \"timed\": \"reference mj_effect_luminance + mj_effect_tint (effect.c:185, :116) on libjpeg's arrays\"}\n",
+           (double)dcs / seconds, g_nimages, dcs_image, passes, checked, differ);
+    return differ ? 7 : 0;
+}
+
 int main(int argc, char **argv) {
+    if(argc >= 2 && strcmp(argv[1], "effects") == 0) return effects_main(argc, argv);
     if(argc != 12) {
         fprintf(stderr, "usage: ref_bench width height dropon_w dropon_h mcu_x mcu_y regime image0 nimages threads min_seconds\n");
         return 2;

@@ -168,3 +168,16 @@ def test_block_loop_live_vs_reference_on_the_bench_workload(regime):
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["rows_compared_with_the_restatement"] == 4 * (6 + 3 + 3) and d["rows_that_differ"] == 0, d
     assert d["blocks_per_s"] > 0 and d["blocks_per_s_1thread"] > 0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(O.ORACLE_DIR, "_ref", "ref_bench")), reason="oracle/_ref/ref_bench not built (no /root/reference here)")
+def test_dc_effects_live_vs_reference_on_the_bench_workload():
+    """oracle/_ref/ref_bench effects: the reference's mj_effect_luminance + mj_effect_tint (effect.c:185, :116) on libjpeg's arrays
+    holding the synthetic planes of bench.py's effects workload == the restatement's orc_effect_dc, every row of every plane"""
+    import json
+    import subprocess
+    exe = os.path.join(O.ORACLE_DIR, "_ref", "ref_bench")
+    out = subprocess.run([exe, "effects", "330", "250", "77", "2", "7", "5", "-3", "0.02"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["rows_that_differ"] == 0 and d["rows_compared_with_the_restatement"] == 2 * (32 + 16 + 16), d
