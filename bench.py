@@ -758,7 +758,8 @@ def effects_cpu_baseline_and_expected(geo, quant, image0, nsample, lum, cb, cr, 
                 ref = json.loads(out.stdout.strip().splitlines()[-1])
                 info = dict(info, kind="reference", value=ref["dc_blocks_per_s"],
                             sample=f"{nsample} images x {ref['dc_blocks_per_image']} DC blocks ({geo.width}x{geo.height} 4:2:0) through the unmodified reference's mj_effect_luminance + mj_effect_tint "
-                                   f"(effect.c:185, :116; oracle/_ref/ref_bench), 1 thread (the reference is single-threaded), {ref['passes']} passes",
+                                   f"(effect.c:185, :116; oracle/_ref/ref_bench), 1 thread (the reference is single-threaded), {ref['passes']} passes over the same "
+                                   f"{nsample * geo.blocks_per_image() * 128 // 2 ** 20} MiB of planes, which a large last-level cache keeps: an upper bound for the CPU",
                             reference_rows_compared_with_the_port=ref["rows_compared_with_the_restatement"], reference_rows_that_differ=ref["rows_that_differ"],
                             port={"value": dcs * reps / t_rep, "what": "oracle/mjx_oracle.c orc_effect_dc on the same sample"})
             else:
