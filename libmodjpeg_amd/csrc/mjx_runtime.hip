@@ -518,6 +518,8 @@ struct JobSegment {
     Segment seg;
 };
 constexpr int kMaxRunOctets = 24; // a gather table piece holds 32 octets; consecutive runs have no limit of their own
+constexpr int MJX_GROUP_WAVES_HOST = 4; // waves per workgroup of the blend kernels (mjx_compose.hip: MJX_GROUP_WAVES)
+int run_length_for(const Tables &t, int64_t octets, int64_t slots);
 void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
     struct Labelled {
         RunRef  r;
@@ -530,35 +532,97 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
     // measured (round 3): 2..8 octets within 2 %, 16 is 3-5 % slower
     const int light_len = t.opt.stream_run_octets > 0 ? (t.opt.stream_run_octets > kMaxRunOctets ? kMaxRunOctets : t.opt.stream_run_octets) : 4;
     t.light.clear();
+    // The stretches of blended octets: same job, same kind, same table, each segment starting where the one before ends.
+    struct Stretch {
+        size_t i, e;
+        int    total, low; // octets; 1: goes to the low-column build
+    };
+    std::vector<Stretch> stretches;
     for(size_t i = 0; i < all.size();) {
-        // the stretch [i, e): same job, same kind, same table, each segment starting where the one before ends
         size_t e = i + 1;
         while(e < all.size() && all[e].job == all[i].job && all[e].sched == all[i].sched && all[e].seg.kind == all[i].seg.kind && all[i].seg.kind != kRunConsecutive &&
               all[e].seg.first == all[e - 1].seg.first + all[e - 1].seg.noctets && (all[e].seg.low & low_mask) == (all[i].seg.low & low_mask))
             ++e;
         int total = 0;
         for(size_t k = i; k < e; ++k) total += all[k].seg.noctets;
-        const int kind = all[i].seg.kind, base = all[i].seg.first;
+        stretches.push_back(Stretch{i, e, total, (all[i].seg.low & low_mask & 1) ? 1 : 0});
+        i = e;
+    }
+    // Run length per build.  A launch that fits ONE round of waves (fewer than 8 octets per resident wave: one 4K image, a shard
+    // of up to a hundred 1080p images) is cut so that it STAYS one round with the shortest runs that allow it: the smallest L for
+    // which the stretches, each split evenly into ceil(octets / L) runs, make no more runs than the device holds waves of the build
+    // they go to - four workgroups per CU for the low-column build, three for the general one (round 5; rounds 2-4 took the general
+    // build's count for both and let a job's short rest join its last run: one 4K image with a full-frame smooth overlay 3 037 runs
+    // of 8..10 octets on 3 072 slots, now 4 050 runs of 6 on 4 096: 31.0 -> 27.9 us; profiles/r05/small_launches_ab.txt).
+    int64_t octets_of[2] = {0, 0};
+    for(const Stretch &st : stretches) {
+        const int kind = all[st.i].seg.kind;
+        if(kind == kRunConsecutive || kind == kRunGather) octets_of[st.low] += st.total;
+    }
+    const bool    only_low = octets_of[0] == 0 && octets_of[1] > 0; // (mixed plans: the builds run one after the other, the general count for both)
+    const int64_t slots_of[2] = {(int64_t)t.slots, only_low ? (int64_t)t.slots * 4 / 3 : (int64_t)t.slots};
+    int           len_of[2] = {t.run_len, t.run_len};
+    bool          even[2] = {false, false};
+    for(int low = 0; low < 2; ++low) {
+        const int64_t octets = only_low || low == 0 ? octets_of[0] + octets_of[1] : octets_of[1];
+        if(octets == 0 || t.opt.run_octets > 0) continue;
+        len_of[low] = run_length_for(t, octets, slots_of[low]);
+        if(octets >= 8 * slots_of[low]) continue; // several rounds: runs of 8..16, rests join, the tail shrinks (below)
+        even[low] = true;
+        // ... and among those, the L whose fullest CU has the least to do: a CU runs whole workgroups of four waves, so what counts
+        // is ceil(workgroups / CUs) x L (128 images of the 1080p workload: 3 712 runs of 7 would put four workgroups on 160 CUs and
+        // three on the rest, 3 072 runs of 8 put three on every CU and are 3 % faster); ties go to the shorter run, i.e. more waves
+        // per CU to hide each other's latencies (one 4K image: 4 050 runs of 6 against 3 037 of 8: 10 % faster)
+        const int64_t cus = t.slots / (3 * MJX_GROUP_WAVES_HOST) > 0 ? t.slots / (3 * MJX_GROUP_WAVES_HOST) : 1;
+        int           L = 0;
+        int64_t       best = -1;
+        for(int cand = (int)((octets + slots_of[low] - 1) / slots_of[low]) < 2 ? 2 : (int)((octets + slots_of[low] - 1) / slots_of[low]); cand < kMaxRunOctets; ++cand) {
+            // (at least two octets per run: a wave's start costs what an octet does; mjx_compose_host sizes its packet by that)
+            int64_t n = 0;
+            for(const Stretch &st : stretches) {
+                const int kind = all[st.i].seg.kind;
+                if((kind == kRunConsecutive || kind == kRunGather) && (only_low || low == 0 || st.low == low)) n += (st.total + cand - 1) / cand;
+            }
+            if(n > slots_of[low] && best >= 0) continue;
+            const int64_t groups = (n + MJX_GROUP_WAVES_HOST - 1) / MJX_GROUP_WAVES_HOST, cost = (groups + cus - 1) / cus * cand + (n > slots_of[low] ? (1ll << 40) : 0);
+            if(best < 0 || cost < best) {
+                best = cost;
+                L = cand;
+            }
+            if(cand >= run_octets() && n <= slots_of[low]) break; // longer runs only make the fullest CU's share longer
+        }
+        if(L == 0) L = len_of[low];
+        len_of[low] = L;
+    }
+    for(const Stretch &st : stretches) {
+        const size_t i = st.i;
+        const int    total = st.total, kind = all[i].seg.kind, base = all[i].seg.first;
         if(kind == kRunZeroAlpha || kind == kRunDcOnly) {
             // streams for the lean kernel: many short-lived waves (a few octets each), in table order
             const int slots_per_octet = kind == kRunDcOnly ? 2 : 1; // a DC-only octet: 8 tile indices + 8 weights
             for(int f = 0; f < total; f += light_len)
                 t.light.push_back(RunRef{all[i].job, base + f * slots_per_octet, total - f < light_len ? total - f : light_len, kind, all[i].sched});
-            i = e;
             continue;
         }
         size_t    seg = i;       // segment that holds octet f
         int       seg_end = all[i].seg.noctets;
-        for(int f = 0; f < total;) {
-            int len = t.run_len < total - f ? t.run_len : total - f;
-            const int rest = total - f - len;
-            if(rest > 0 && rest * 2 < t.run_len && len + rest <= kMaxRunOctets) len += rest;
+        const int run_len = len_of[st.low];
+        const int nparts = (total + run_len - 1) / run_len; // even[]: ceil(total / L) runs of floor or ceil(total / nparts) octets
+        for(int f = 0, part = 0; f < total; ++part) {
+            int len;
+            if(even[st.low]) {
+                len = total / nparts + (part < total % nparts ? 1 : 0);
+            }
+            else {
+                len = run_len < total - f ? run_len : total - f;
+                const int rest = total - f - len;
+                if(rest > 0 && rest * 2 < run_len && len + rest <= kMaxRunOctets) len += rest;
+            }
             while(f >= seg_end) seg_end += all[++seg].seg.noctets;
             const int first = kind == kRunConsecutive ? base + f * kWaveBlocks : base + f;
-            runs.push_back(Labelled{RunRef{all[i].job, first, len, kind, all[i].sched, (all[i].seg.low & low_mask & 2) ? 1 : 0}, all[seg].seg.cls, (all[i].seg.low & low_mask & 1) ? 1 : 0});
+            runs.push_back(Labelled{RunRef{all[i].job, first, len, kind, all[i].sched, (all[i].seg.low & low_mask & 2) ? 1 : 0}, all[seg].seg.cls, st.low});
             f += len;
         }
-        i = e;
     }
     std::stable_sort(runs.begin(), runs.end(), [](const Labelled &a, const Labelled &b) { return a.cls > b.cls; });
 
@@ -596,6 +660,16 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
     if(t.runs.empty() && t.lowl.empty()) t.run_min = 0;
 }
 
+// octets per run for `octets` octets of blended work on a kernel build of which the device holds `slots` wavefronts at once
+int run_length_for(const Tables &t, int64_t octets, int64_t slots) {
+    if(t.opt.run_octets > 0) return t.opt.run_octets < run_octets() ? t.opt.run_octets : run_octets(); // the caller's choice (mjx_plan_options_t)
+    const int64_t per_slot = (octets + slots - 1) / slots; // octets per resident wave
+    int           run_len = per_slot < 8 ? (int)per_slot : (int)(per_slot / 8);
+    if(per_slot >= 8 && run_len < 8) run_len = 8;
+    if(run_len < 2) run_len = 2;
+    return run_len > run_octets() ? run_octets() : run_len;
+}
+
 int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables, int nq, bool tiles_i16, Tables &t) {
     // the reference divides by quantval (compose.c:327-336): q == 0 is a caller bug there (SIGFPE)
     for(int i = 0; i < nq * 64; ++i) {
@@ -612,13 +686,7 @@ int build_tables(const mjx_rect_job_t *jobs, int njobs, const uint16_t *qtables,
         if(jobs[i].rows > 0 && jobs[i].cols > 0) total_octets += ((int64_t)jobs[i].rows * jobs[i].cols + kWaveBlocks - 1) / kWaveBlocks;
     }
     t.slots = compose_resident_waves(tiles_i16);
-    const int64_t per_slot = (total_octets + t.slots - 1) / t.slots; // octets per resident wave
-    int           run_len = per_slot < 8 ? (int)per_slot : (int)(per_slot / 8);
-    if(per_slot >= 8 && run_len < 8) run_len = 8;
-    if(run_len < 2) run_len = 2;
-    if(run_len > run_octets()) run_len = run_octets();
-    if(t.opt.run_octets > 0) run_len = t.opt.run_octets < run_octets() ? t.opt.run_octets : run_octets(); // the caller's choice (mjx_plan_options_t)
-    t.run_len = run_len;
+    t.run_len = run_length_for(t, total_octets, t.slots);
     // rectangles of >= 2^24 blocks are split by rows so that the kernel's float row/column split
     // of the linear tile index stays exact
     const int64_t kMaxJobBlocks = (1ll << 24) - 1;
