@@ -88,6 +88,9 @@ def parse(argv=None):
     ap.add_argument("--no-low-column-build", action="store_true", help="compose: MJX_PLAN_NO_LOW_COLUMN_BUILD (smooth runs take the general build of the blend kernel)")
     ap.add_argument("--keep-zero-alpha", action="store_true",
                     help="compose: blocks without any weight still stream their tile and alpha blocks (no MJX_PLAN_ALPHA_IS_FINAL)")
+    ap.add_argument("--tiles-not-final", action="store_true",
+                    help="compose: no MJX_PLAN_TILES_ARE_FINAL - opaque blocks of float tiles (single weight 0.25, whole-number tile) read the image's block like the other "
+                         "single-weight blocks")
     ap.add_argument("--also", default="auto", choices=["auto", "none"],
                     help="auto (default): the headline run (default workload, regime, tiles and launch on one GPU) also measures, inside the same JSON line, what "
                          "making its plan costs (`plan_ms`), the same launch planned WITHOUT the promise that alpha is final (`roofline.frac_without_promise`) and, "
@@ -432,17 +435,20 @@ def plan_launch_bytes(plan_stats, blocks, tiles_i16):
     (132 B); the single weight (0,0) -> JCOEF in and out, the tile block and a table entry with the weight (520 B, 392 with
     int16 tiles); float tiles, no weight in a row k >= 4 -> the second 128-byte line of the alpha block stays where it is
     (eight first lines and one second line per octet in the low-column build: 656 B per block; two in the general and lean
-    builds: 672 B)."""
+    builds: 672 B); an opaque block (MJX_PLAN_TILES_ARE_FINAL: that weight is 0.25 and the tile holds whole numbers) -> the tile
+    block in, a table entry, JCOEF out (388 B, 260 with int16 tiles)."""
     per_block = 512 if tiles_i16 else BYTES_PER_BLOCK
     special_dc, special_zero = 8 * plan_stats["dc_only_octets"], 8 * plan_stats["zero_alpha_octets"]
     dc_bytes = 128 + (128 if tiles_i16 else 256) + 8 + 128
+    special_opq = 8 * plan_stats.get("opaque_octets", 0)
+    opq_bytes = (128 if tiles_i16 else 256) + 4 + 128
     lowl_only = plan_stats.get("runs_low_columns") and plan_stats.get("low_column_octets") == plan_stats.get("low_row_octets") and not plan_stats.get("runs_beside")
     skipped = 8 * plan_stats.get("low_row_octets", 0) * (112 if lowl_only else 96) if not tiles_i16 else 0
-    launch_bytes = (blocks - special_dc - special_zero) * per_block - skipped + special_dc * dc_bytes + special_zero * 132
+    launch_bytes = (blocks - special_dc - special_zero - special_opq) * per_block - skipped + special_dc * dc_bytes + special_zero * 132 + special_opq * opq_bytes
     return max(min(launch_bytes, blocks * per_block), 0)
 
 
-def also_compose(batch, batch_cfg, regime_name, steps, nsample, alpha_is_final=True, spinup_ms=150.0):
+def also_compose(batch, batch_cfg, regime_name, steps, nsample, alpha_is_final=True, spinup_ms=150.0, tiles_are_final=None):
     """One more measurement on an existing batch (same images, same rectangles): tiles and alpha of `regime_name` and the planes
     are generated afresh (deterministic: the planes are pristine again), a plan is made, the first pass is compared with the CPU
     oracle on `nsample` images, then `steps` launches are timed between two HIP events.  Returns the entry of the JSON line's
@@ -453,7 +459,7 @@ def also_compose(batch, batch_cfg, regime_name, steps, nsample, alpha_is_final=T
     regime = REGIMES[regime_name]
     batch.regime = regime
     batch.fill_synthetic()
-    batch.build_plan(alpha_is_final=alpha_is_final)
+    batch.build_plan(alpha_is_final=alpha_is_final, tiles_are_final=tiles_are_final)
     st = batch.plan_stats()
     tiles = [batch.tiles_as_float(0, c) for c in range(3)] if regime == 5 else None
     _, expected = cpu_baseline_and_expected(batch_cfg, regime, nsample, batch.image0, timing=False, tiles=tiles)
@@ -557,7 +563,8 @@ def bench_compose(args, rank, world):
     bytes_per_block = 512 if args.tiles == "i16" else BYTES_PER_BLOCK  # int16 tiles: 128 + 128 + 128 read, 128 written
     batch.fill_synthetic()
     batch.build_plan(group_by_density=not args.no_group, alpha_is_final=not args.keep_zero_alpha, side_by_side={"auto": None, "serial": False, "side-by-side": True}[args.launch],
-                     run_octets=args.run_octets, stream_run_octets=args.stream_run_octets, beside_share=args.beside_share, low_column_build=not args.no_low_column_build)
+                     run_octets=args.run_octets, stream_run_octets=args.stream_run_octets, beside_share=args.beside_share, low_column_build=not args.no_low_column_build,
+                     tiles_are_final=False if args.tiles_not_final else None)
     plan_stats = batch.plan_stats()
     blocks_per_step = batch.total_blocks()
     sync = torch.cuda.synchronize
@@ -656,7 +663,7 @@ def bench_compose(args, rank, world):
             "parity": verdicts.pop() if len(verdicts) == 1 else "mixed: see per_rank",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("mjx::compose_lowl_kernel (the blend kernel's build for weights in columns 0..3: four workgroups per CU; weights in rows 0..3 as well: the second line of the alpha blocks is not fetched)" if plan_stats.get("runs_low_columns") == plan_stats.get("runs") else "mjx::compose_kernel") if not plan_stats.get("zero_alpha_octets") and not plan_stats.get("dc_only_octets") else "one step = mjx::compose_kernel (or its lean build) + mjx::compose_light_kernel (+ mjx::compose_light_shared_kernel beside it)",
+                         "kernel": ("mjx::compose_lowl_kernel (the blend kernel's build for weights in columns 0..3: four workgroups per CU; weights in rows 0..3 as well: the second line of the alpha blocks is not fetched)" if plan_stats.get("runs_low_columns") == plan_stats.get("runs") else "mjx::compose_kernel") if not plan_stats.get("zero_alpha_octets") and not plan_stats.get("dc_only_octets") and not plan_stats.get("opaque_octets") else "one step = mjx::compose_kernel (or its lean build) + mjx::compose_light_kernel (+ mjx::compose_light_shared_kernel beside it)",
                          "kernel_ms_mean": mean_kern_ms,
                          "kernel_ms_mean_is": "distance of two HIP events around the K timed launches on the launch stream / K",
                          "kernel_ms_pristine": pristine_ms, "kernel_ms_pristine_min": min(ms) if ms else None,

@@ -166,6 +166,18 @@ int mjx_compose_plan_create(mjx_compose_plan_t **plan, const mjx_rect_job_t *job
  * like the others (three workgroups per CU instead of four; measurements, and the parity tests' way of sending smooth masks
  * through the general build).  Purely a schedule. */
 #define MJX_PLAN_NO_LOW_COLUMN_BUILD 32
+/* MJX_PLAN_TILES_ARE_FINAL (with MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL, float tiles): the caller promises the same
+ * for the image tiles.  The scan then also reads them, and a block whose only weight is (0,0) = 0.25 exactly (what an opaque pixel
+ * of an overlay compiles to: tiles.c / compose.c:139-157, 255/255 * 1/4... the reference's own normalisation) and whose 64 tile
+ * values are whole numbers below 2^23 is an OPAQUE block: the reference's arithmetic for it,
+ *     X = tile - (float)(coef * q);  Y = (X * 2) * 0.5 = X;  coef' = (coef * q + (int)Y) / q        (compose.c:277-336, convolve.c)
+ * is exact in every step (|coef * q| < 2^23 as well), so coef' = (int)tile / q whatever the image held: the block is written from
+ * its tile alone and the image's block is not read (388 bytes per block instead of 520).  With int16 tiles (MJX_PLAN_TILES_I16 /
+ * MJX_JOB_TILES_I16) the tile values are whole numbers by type and MJX_PLAN_ALPHA_IS_FINAL is enough - schedules of
+ * mjx_tile_schedule_create over int16 tiles included (260 bytes per block instead of 392).  Blocks with that weight whose tile
+ * holds anything else (a fraction, 2^23 or more, NaN) stay with the single-weight blocks: the results are the reference's either
+ * way. */
+#define MJX_PLAN_TILES_ARE_FINAL 64
 int mjx_compose_plan_create_ex(mjx_compose_plan_t **plan, const mjx_rect_job_t *jobs, int njobs,
                                const uint16_t *qtables, int nq, int flags);
 /* The same with every choice of the schedule that is the caller's to make.  Zero-initialise the struct (memset / = {0}): a zero
@@ -208,6 +220,8 @@ typedef struct mjx_plan_stats {
      * [3] tables going up (runs, gather table, quantisation rows), [4] the whole call. */
     int32_t build_us[5];
     int32_t reserved;
+    int64_t opaque_octets;  /* octets of opaque blocks (MJX_PLAN_TILES_ARE_FINAL; int16 tiles): written from the tile alone, not
+                               counted in dc_only_octets */
 } mjx_plan_stats_t;
 int mjx_compose_plan_stats(const mjx_compose_plan_t *plan, mjx_plan_stats_t *out);
 void mjx_compose_plan_destroy(mjx_compose_plan_t *plan);

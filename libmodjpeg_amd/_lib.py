@@ -20,6 +20,7 @@ MJX_PLAN_ALPHA_IS_FINAL = 2
 MJX_PLAN_TILES_I16 = 4
 MJX_PLAN_SERIAL = 8         # the two kernels of a step always one after the other
 MJX_PLAN_SIDE_BY_SIDE = 16  # ... always side by side (the default decides by the size of the launch)
+MJX_PLAN_TILES_ARE_FINAL = 64  # float tiles keep their contents too: opaque blocks are written from the tile alone
 MJX_PLAN_NO_LOW_COLUMN_BUILD = 32  # smooth runs take the general build of the blend kernel like the others
 MJX_VERSION = 105  # include/mjx.h; compared with mjx_version() of the library that is loaded
 MJX_JOB_TILES_I16 = 1
@@ -56,7 +57,7 @@ class PlanStats(ctypes.Structure):
                 ("runs", ctypes.c_int64), ("block_terms", ctypes.c_int64), ("union_terms", ctypes.c_int64), ("dc_only_octets", ctypes.c_int64), ("union_terms_consecutive", ctypes.c_int64),
                 ("resident_waves", ctypes.c_int32), ("run_octets_max", ctypes.c_int32), ("run_octets_min", ctypes.c_int32), ("runs_beside", ctypes.c_int32),
                 ("low_column_octets", ctypes.c_int64), ("runs_low_columns", ctypes.c_int64), ("low_row_octets", ctypes.c_int64),
-                ("build_us", ctypes.c_int32 * 5), ("reserved", ctypes.c_int32)]
+                ("build_us", ctypes.c_int32 * 5), ("reserved", ctypes.c_int32), ("opaque_octets", ctypes.c_int64)]
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k not in ("reserved", "build_us")}

@@ -143,15 +143,18 @@ class ComposeBatch:
 
     # ---- launch plan ------------------------------------------------------------------------
     def build_plan(self, group_by_density=True, alpha_is_final=True, side_by_side=None, run_octets=0, stream_run_octets=0, tail_min_octets=0, beside_share=0.0,
-                   low_column_build=True):
+                   low_column_build=True, tiles_are_final=None):
         """group_by_density: octets are formed from blocks that need the same terms where a rectangle
         mixes patterns (mjx_compose_plan_create_ex); a schedule only, same results.  alpha_is_final (with
         it): the alpha tiles will not change any more, so blocks without any weight leave their tile and
         alpha blocks behind (the reference skips every term of theirs, convolve.c:32).  side_by_side: None = the
         library decides by the size of the launch whether the blend kernel and the streams of the blocks that need
         no blend run side by side; True / False force it (MJX_PLAN_SIDE_BY_SIDE / MJX_PLAN_SERIAL).  run_octets, stream_run_octets,
-        tail_min_octets, beside_share: mjx_plan_options_t (0 = the library's choice); low_column_build=False: MJX_PLAN_NO_LOW_COLUMN_BUILD"""
-        from ._lib import MJX_PLAN_NO_LOW_COLUMN_BUILD, MJX_PLAN_SERIAL, MJX_PLAN_SIDE_BY_SIDE, PlanOptions
+        tail_min_octets, beside_share: mjx_plan_options_t (0 = the library's choice); low_column_build=False: MJX_PLAN_NO_LOW_COLUMN_BUILD.
+        tiles_are_final (None: as alpha_is_final): MJX_PLAN_TILES_ARE_FINAL, the image tiles keep their contents too, so opaque blocks
+        (single weight 0.25, whole-number tile) are written from the tile alone"""
+        from ._lib import MJX_PLAN_NO_LOW_COLUMN_BUILD, MJX_PLAN_SERIAL, MJX_PLAN_SIDE_BY_SIDE, MJX_PLAN_TILES_ARE_FINAL, PlanOptions
+        tiles_are_final = alpha_is_final if tiles_are_final is None else (tiles_are_final and alpha_is_final)
         how = 0 if side_by_side is None else (MJX_PLAN_SIDE_BY_SIDE if side_by_side else MJX_PLAN_SERIAL)
         jobs = (RectJob * (3 * self.n))()
         j = 0
@@ -165,7 +168,8 @@ class ComposeBatch:
         qt = np.ascontiguousarray(np.stack(self.quant))
         self.destroy_plan()
         opt = PlanOptions()
-        opt.flags = ((MJX_PLAN_GROUP_BY_DENSITY | (MJX_PLAN_ALPHA_IS_FINAL if alpha_is_final else 0)) if group_by_density else 0) | how | (0 if low_column_build else MJX_PLAN_NO_LOW_COLUMN_BUILD)
+        opt.flags = ((MJX_PLAN_GROUP_BY_DENSITY | (MJX_PLAN_ALPHA_IS_FINAL if alpha_is_final else 0) | (MJX_PLAN_TILES_ARE_FINAL if tiles_are_final else 0)) if group_by_density else 0) | how | \
+            (0 if low_column_build else MJX_PLAN_NO_LOW_COLUMN_BUILD)
         opt.run_octets, opt.stream_run_octets, opt.tail_min_octets, opt.beside_share = run_octets, stream_run_octets, tail_min_octets, beside_share
         check(lib().mjx_compose_plan_create_opts(ctypes.byref(self.plan), jobs, 3 * self.n, qt.ctypes.data_as(ctypes.c_void_p), 3, ctypes.byref(opt)),
               "mjx_compose_plan_create_opts")

@@ -927,83 +927,6 @@ MJX_DEV uint4 global_load16_nt(const void *p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// DEPTH: octets a wave has in flight (registers).  2 for the launch that has the device to itself (8 waves per SIMD hide the
-// rest); the build that runs BESIDE the blend kernel (launch_compose_light(shared)) has one wave per SIMD to do it with - three
-// lean blend waves leave 80 of a SIMD's 512 registers - and so keeps more of its own in flight, over longer runs.
-template <bool I16, int DEPTH>
-MJX_DEV void compose_light_body(const Run *__restrict__ runs, int ridx, const void *__restrict__ qrq) {
-    const int lane = threadIdx.x & 63;
-    const int b = lane >> 3, r = lane & 7;
-    const Run    run = runs[ridx];
-    const int    noct = __builtin_amdgcn_readfirstlane(run.noctets);
-    const bool   dc = __builtin_amdgcn_readfirstlane(run.kind) == kRunDcOnly;
-    const DevJob job = run.job;
-    // this lane's quantisation row: 8 x u16, 8 reciprocals (48 bytes of the 384-byte table)
-    const char  *qbase = reinterpret_cast<const char *>(qrq) + (size_t)(unsigned)job.qidx * kQuantTableBytes + r * (kQuantRowDwords * 4);
-    const uint4  q4 = *reinterpret_cast<const uint4 *>(qbase);
-    const float4 rq_lo = *reinterpret_cast<const float4 *>(qbase + 16), rq_hi = *reinterpret_cast<const float4 *>(qbase + 32);
-    const float  rq[8] = {rq_lo.x, rq_lo.y, rq_lo.z, rq_lo.w, rq_hi.x, rq_hi.y, rq_hi.z, rq_hi.w};
-    // the run's table: zero-alpha octets are 8 tile indices; DC-only octets 8 tile indices followed by the
-    // blocks' 8 weights (0,0) as float bits (read by the schedule from the alpha tiles, which are final)
-    const int    gstride = dc ? 2 * kWaveBlocks : kWaveBlocks;
-    const int   *G = run.gather + (size_t)run.first * kWaveBlocks + b;
-
-    // this lane's operands of one octet: the JCOEF row, and for DC-only runs the tile row and the block's weight
-    struct Octet {
-        unsigned pblk;       // plane block of this lane's row (store_ptr)
-        uint4    c4, t0, t1; // t0 (,t1): the tile row, 8 x int16 or 8 x float
-        unsigned w;          // alpha[0][0]: float bits, or the int16 coefficient in the low half
-    };
-    auto fetch = [&](const int *g) {
-        const int n = g[0];
-        Octet     o;
-        o.pblk = plane_block_of(job, n);
-        o.c4 = global_load16_nt(store_ptr(job, o.pblk, lane));
-        o.t0 = o.t1 = make_uint4(0, 0, 0, 0);
-        o.w = 0;
-        if(dc) {
-            o.w = (unsigned)g[kWaveBlocks];
-            if constexpr(I16) {
-                o.t0 = global_load16_nt(reinterpret_cast<const int16_t *>(job.tile) + (size_t)n * 64 + r * 8);
-            }
-            else {
-                o.t0 = global_load16_nt(job.tile + (size_t)n * 64 + r * 8);
-                o.t1 = global_load16_nt(job.tile + (size_t)n * 64 + r * 8 + 4);
-            }
-        }
-        return o;
-    };
-    auto finish = [&](const Octet &o) {
-        int16_t *cptr = store_ptr(job, o.pblk, lane);
-        if(!dc) {
-            octet_zero_alpha_rq(cptr, q4, rq, o.c4);
-            return;
-        }
-        float t[8];
-        if constexpr(I16) {
-            const unsigned tw[4] = {o.t0.x, o.t0.y, o.t0.z, o.t0.w};
-            static_for<4>([&](auto P) {
-                t[2 * P] = s16_lo_to_f32(tw[P]);
-                t[2 * P + 1] = s16_hi_to_f32(tw[P]);
-            });
-        }
-        else {
-            t[0] = __uint_as_float(o.t0.x); t[1] = __uint_as_float(o.t0.y); t[2] = __uint_as_float(o.t0.z); t[3] = __uint_as_float(o.t0.w);
-            t[4] = __uint_as_float(o.t1.x); t[5] = __uint_as_float(o.t1.y); t[6] = __uint_as_float(o.t1.z); t[7] = __uint_as_float(o.t1.w);
-        }
-        octet_dc_only_rq(cptr, q4, rq, o.c4, t, __uint_as_float(o.w));
-    };
-    // two octets in flight: the next octet's loads are issued before this one is finished and stored
-    Octet cur = fetch(G);
-#pragma unroll 1
-    for(int i = 0; i < noct; ++i) {
-        Octet nxt = cur;
-        if(i + 1 < noct) nxt = fetch(G + (i + 1) * gstride);
-        finish(cur);
-        cur = nxt;
-    }
-}
-
 // The same streams for a wave that has a SIMD's memory pipeline almost to itself: the kernel that runs BESIDE the blend kernel
 // (launch_compose_light(shared)).  Three lean blend waves leave 80 of a SIMD's 512 registers, i.e. one wave of this kernel per
 // SIMD, which has to keep the CU's share of the stream in flight alone: DEPTH octets of its own, over one run after the other
@@ -1018,9 +941,14 @@ MJX_DEV void compose_light_body(const Run *__restrict__ runs, int ridx, const vo
 // 65 535 x 65 535 pixel component is 8 GiB); !WIDE: scalar base + 32-bit byte offset, for the kernel that lives in 80 registers -
 // side_by_side_share() sends a plan there only when every rectangle ends below 4 GiB of its plane.  (A tile array of one job is
 // always below 4 GiB: build_tables cuts rectangles of 2^24 blocks or more.)
-template <bool I16, bool DC, int DEPTH, bool WIDE>
-MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
-    const int    b = lane >> 3, r = lane & 7;
+// KIND: what the run's blocks need (wave-uniform, one instantiation each):
+//   kStreamZa   zero-alpha blocks: the JCOEF row alone travels (5 registers per octet in flight, so many more of them)
+//   kStreamDc   DC-only blocks: JCOEF row, tile row and the block's weight
+//   kStreamOpq  opaque blocks (kRunOpaque): the tile row alone - the image's block is not read at all, see octet_opaque below
+constexpr int kStreamZa = 0, kStreamDc = 1, kStreamOpq = 2;
+template <bool I16, int KIND, int DEPTH, bool WIDE>
+MJX_DEV void light_stream_run(const Run &run, const float *qtab, int lane) {
+    constexpr bool DC = KIND == kStreamDc, OPQ = KIND == kStreamOpq, TILE = DC || OPQ;
     const int    noct = __builtin_amdgcn_readfirstlane(run.noctets);
     const DevJob job = run.job;
     struct Tab { // one octet's table entry, wave-uniform
@@ -1028,9 +956,9 @@ MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
         unsigned w[DC ? kWaveBlocks : 1];
     };
     struct Octet {
-        unsigned pblk;
-        uint4    c4;
-        uint4    t[DC ? (I16 ? 1 : 2) : 0]; // the tile row, 8 x int16 or 8 x float
+        unsigned pblk;           // the block's index in the plane (WIDE) / the byte offset of this lane's row of it (!WIDE)
+        uint4    c4[OPQ ? 0 : 1];
+        uint4    t[TILE ? (I16 ? 1 : 2) : 0]; // the tile row, 8 x int16 or 8 x float
         unsigned w[DC ? 1 : 0];
     };
     constexpr int gstride = DC ? 2 * kWaveBlocks : kWaveBlocks;
@@ -1066,63 +994,100 @@ MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
     };
     auto fetch = [&](const Tab &t) {
         const int n = pick(t.n);
+        // What a lane derives from its number (r * 16, r * 32, its row of the quantisation table, b * 8) is made afresh for every
+        // octet, from a copy of the number the compiler cannot see through: left alone it keeps each of them in a register of its own
+        // for the whole kernel, and in the 80 registers of the kernel beside the blend kernel it SPILLED one (rounds 4 and 5, float
+        // tiles: 20 bytes of scratch) - and a reload is a vector load whose s_waitcnt vmcnt(0) drains every octet the wave has in
+        // flight, once per fetch.
+        const unsigned rr = (unsigned)opaque(lane) & 7u;
+        const int      r = (int)rr;
         Octet o;
         o.pblk = plane_block_of(job, n);
-        if constexpr(WIDE) o.c4 = global_load16_nt(reinterpret_cast<const char *>(job.coef) + ((size_t)o.pblk * 128 + (size_t)r * 16));
-        else o.c4 = global_load16_nt(reinterpret_cast<const char *>(job.coef) + (o.pblk * 128u + (unsigned)r * 16u));
-        if constexpr(DC) {
-            o.w[0] = (unsigned)pick(t.w);
+        if constexpr(!WIDE) o.pblk = o.pblk * 128u + rr * 16u; // (the byte offset of the lane's row: what the load and the store both need)
+        if constexpr(!OPQ) {
+            if constexpr(WIDE) o.c4[0] = global_load16_nt(reinterpret_cast<const char *>(job.coef) + ((size_t)o.pblk * 128 + (size_t)r * 16));
+            else o.c4[0] = global_load16_nt(reinterpret_cast<const char *>(job.coef) + o.pblk);
+        }
+        if constexpr(DC) o.w[0] = (unsigned)pick(t.w);
+        if constexpr(TILE) {
             if constexpr(I16) {
-                o.t[0] = global_load16_nt(reinterpret_cast<const char *>(job.tile) + ((unsigned)n * 128u + (unsigned)r * 16u));
+                o.t[0] = global_load16_nt(reinterpret_cast<const char *>(job.tile) + ((unsigned)n * 128u + rr * 16u));
             }
             else {
-                o.t[0] = global_load16_nt(reinterpret_cast<const char *>(job.tile) + ((unsigned)n * 256u + (unsigned)r * 32u));
-                o.t[1] = global_load16_nt(reinterpret_cast<const char *>(job.tile) + ((unsigned)n * 256u + (unsigned)r * 32u + 16u));
+                o.t[0] = global_load16_nt(reinterpret_cast<const char *>(job.tile) + ((unsigned)n * 256u + rr * 32u));
+                o.t[1] = global_load16_nt(reinterpret_cast<const char *>(job.tile) + ((unsigned)n * 256u + rr * 32u + 16u));
             }
         }
         return o;
     };
     auto finish = [&](const Octet &o) {
+        const int    ln = opaque(lane), b = ln >> 3, r = ln & 7; // (see fetch)
+        const float *qrow = qtab + r * kQuantRowDwords;
+        (void)b;
         int16_t       *cptr = WIDE ? reinterpret_cast<int16_t *>(reinterpret_cast<char *>(job.coef) + ((size_t)o.pblk * 128 + (size_t)r * 16))
-                                   : reinterpret_cast<int16_t *>(reinterpret_cast<char *>(job.coef) + (o.pblk * 128u + (unsigned)r * 16u));
-        // this lane's quantisation row from the wave's LDS copy: 8 x u16 now, the 8 reciprocals when the tail needs them
-        const uint4    q4 = *reinterpret_cast<const uint4 *>(qrow);
-        const unsigned cd[4] = {pk_mul_lo_u16(o.c4.x, q4.x), pk_mul_lo_u16(o.c4.y, q4.y), pk_mul_lo_u16(o.c4.z, q4.z), pk_mul_lo_u16(o.c4.w, q4.w)};
-        if constexpr(!DC) {
-            // (octet_zero_alpha_rq) Y = +0: what is left is coef = (short)((short)(coef * q) / q), the block itself unless coef * q left
-            // int16.  A block that comes out as it went in is not written back: 128 bytes of HBM traffic less for every block
-            // outside the mask (whole blocks only - the eight lanes of a block agree - so that no line is written in part).
-            unsigned out[4];
-            static_for<4>([&](auto P) { // (the reciprocals pair by pair out of LDS: this kernel has 80 registers and eight octets in flight)
-                const float2 rq = *reinterpret_cast<const float2 *>(qrow + 4 + 2 * P);
-                out[P] = pack16((int)(s16_lo_to_f32(cd[P]) * rq.x), (int)(s16_hi_to_f32(cd[P]) * rq.y));
-            });
-            const bool               same = out[0] == o.c4.x && out[1] == o.c4.y && out[2] == o.c4.z && out[3] == o.c4.w;
-            const unsigned long long all = __ballot(same);
-            if(((all >> (b * 8)) & 0xFFull) != 0xFFull) global_store16(cptr, make_uint4(out[0], out[1], out[2], out[3]));
-        }
-        else {
-            float t[8];
+                                   : reinterpret_cast<int16_t *>(reinterpret_cast<char *>(job.coef) + o.pblk);
+        if constexpr(OPQ) {
+            // An opaque block: its only weight is (0,0) = 0.25 and its tile holds integers below 2^23 (the schedule has seen both).
+            // Then X = tile - (float)coef is exact, Y = V_0(H_0(X)) * w = (2X)(2 * 0.25) = X exactly (compose.c:300-312 with
+            // convolve.c:36-45, :567-580), coef + (int)Y = (int)tile whatever coef was, and what is stored is
+            // (short)((short)(int)tile / q) (compose.c:315-336): the image's block is not read.
+            unsigned s[4];
             if constexpr(I16) {
-                const unsigned tw[4] = {o.t[0].x, o.t[0].y, o.t[0].z, o.t[0].w};
-                static_for<4>([&](auto P) {
-                    t[2 * P] = s16_lo_to_f32(tw[P]);
-                    t[2 * P + 1] = s16_hi_to_f32(tw[P]);
-                });
+                s[0] = o.t[0].x; s[1] = o.t[0].y; s[2] = o.t[0].z; s[3] = o.t[0].w; // already (short)(int)tile, two per register
             }
             else {
-                t[0] = __uint_as_float(o.t[0].x); t[1] = __uint_as_float(o.t[0].y); t[2] = __uint_as_float(o.t[0].z); t[3] = __uint_as_float(o.t[0].w);
-                t[4] = __uint_as_float(o.t[1].x); t[5] = __uint_as_float(o.t[1].y); t[6] = __uint_as_float(o.t[1].z); t[7] = __uint_as_float(o.t[1].w);
+                const float tf[8] = {__uint_as_float(o.t[0].x), __uint_as_float(o.t[0].y), __uint_as_float(o.t[0].z), __uint_as_float(o.t[0].w),
+                                     __uint_as_float(o.t[1].x), __uint_as_float(o.t[1].y), __uint_as_float(o.t[1].z), __uint_as_float(o.t[1].w)};
+                static_for<4>([&](auto P) { s[P] = pack16(cvt_i32_sat(tf[2 * P]), cvt_i32_sat(tf[2 * P + 1])); }); // (exact: integers below 2^23; pack16 = the (short) of step A)
             }
-            float x[8], y[8]; // (octet_dc_only_rq)
-            static_for<4>([&](auto P) {
-                x[2 * P] = t[2 * P] - s16_lo_to_f32(cd[P]);
-                x[2 * P + 1] = t[2 * P + 1] - s16_hi_to_f32(cd[P]);
+            unsigned out[4];
+            static_for<4>([&](auto P) { // Q: (short)(s / q) by the exact reciprocal product, the reciprocals pair by pair out of LDS
+                const float2 rq = *reinterpret_cast<const float2 *>(qrow + 4 + 2 * P);
+                out[P] = pack16((int)(s16_lo_to_f32(s[P]) * rq.x), (int)(s16_hi_to_f32(s[P]) * rq.y));
             });
-            static_for<8>([&](auto U) { x[U] = x[U] + x[U]; });
-            static_for<8>([&](auto U) { y[U] = 0.0f; });
-            vstage_first(y, x, __uint_as_float(o.w[0]));
-            octet_tail(cptr, qrow, cd, y);
+            global_store16(cptr, make_uint4(out[0], out[1], out[2], out[3]));
+            return;
+        }
+        else {
+            // this lane's quantisation row from the wave's LDS copy: 8 x u16 now, the 8 reciprocals when the tail needs them
+            const uint4    q4 = *reinterpret_cast<const uint4 *>(qrow);
+            const unsigned cd[4] = {pk_mul_lo_u16(o.c4[0].x, q4.x), pk_mul_lo_u16(o.c4[0].y, q4.y), pk_mul_lo_u16(o.c4[0].z, q4.z), pk_mul_lo_u16(o.c4[0].w, q4.w)};
+            if constexpr(!DC) {
+                // (octet_zero_alpha_rq) Y = +0: what is left is coef = (short)((short)(coef * q) / q), the block itself unless coef * q left
+                // int16.  A block that comes out as it went in is not written back: 128 bytes of HBM traffic less for every block
+                // outside the mask (whole blocks only - the eight lanes of a block agree - so that no line is written in part).
+                unsigned out[4];
+                static_for<4>([&](auto P) { // (the reciprocals pair by pair out of LDS: this kernel has 80 registers and eight octets in flight)
+                    const float2 rq = *reinterpret_cast<const float2 *>(qrow + 4 + 2 * P);
+                    out[P] = pack16((int)(s16_lo_to_f32(cd[P]) * rq.x), (int)(s16_hi_to_f32(cd[P]) * rq.y));
+                });
+                const bool               same = out[0] == o.c4[0].x && out[1] == o.c4[0].y && out[2] == o.c4[0].z && out[3] == o.c4[0].w;
+                const unsigned long long all = __ballot(same);
+                if(((all >> (b * 8)) & 0xFFull) != 0xFFull) global_store16(cptr, make_uint4(out[0], out[1], out[2], out[3]));
+            }
+            else {
+                float t[8];
+                if constexpr(I16) {
+                    const unsigned tw[4] = {o.t[0].x, o.t[0].y, o.t[0].z, o.t[0].w};
+                    static_for<4>([&](auto P) {
+                        t[2 * P] = s16_lo_to_f32(tw[P]);
+                        t[2 * P + 1] = s16_hi_to_f32(tw[P]);
+                    });
+                }
+                else {
+                    t[0] = __uint_as_float(o.t[0].x); t[1] = __uint_as_float(o.t[0].y); t[2] = __uint_as_float(o.t[0].z); t[3] = __uint_as_float(o.t[0].w);
+                    t[4] = __uint_as_float(o.t[1].x); t[5] = __uint_as_float(o.t[1].y); t[6] = __uint_as_float(o.t[1].z); t[7] = __uint_as_float(o.t[1].w);
+                }
+                float x[8], y[8]; // (octet_dc_only_rq)
+                static_for<4>([&](auto P) {
+                    x[2 * P] = t[2 * P] - s16_lo_to_f32(cd[P]);
+                    x[2 * P + 1] = t[2 * P + 1] - s16_hi_to_f32(cd[P]);
+                });
+                static_for<8>([&](auto U) { x[U] = x[U] + x[U]; });
+                static_for<8>([&](auto U) { y[U] = 0.0f; });
+                vstage_first(y, x, __uint_as_float(o.w[0]));
+                octet_tail(cptr, qrow, cd, y);
+            }
         }
     };
 
@@ -1183,7 +1148,16 @@ MJX_DEV void light_stream_run(const Run &run, const float *qrow, int lane) {
 #define MJX_STREAM_DEPTH_DC_F32 2
 #endif
 #endif
+#ifndef MJX_STREAM_DEPTH_OPQ_I16
+#define MJX_STREAM_DEPTH_OPQ_I16 8
+#endif
+#ifndef MJX_STREAM_DEPTH_OPQ_F32
+#define MJX_STREAM_DEPTH_OPQ_F32 5
+#endif
 // ... and in the kernel that has the device to itself (8 waves per SIMD)
+#ifndef MJX_LIGHT_DEPTH_OPQ
+#define MJX_LIGHT_DEPTH_OPQ 3
+#endif
 #ifndef MJX_LIGHT_DEPTH_ZA
 #define MJX_LIGHT_DEPTH_ZA 4
 #endif
@@ -1202,12 +1176,12 @@ MJX_DEV void compose_light_stream(const Run *__restrict__ runs, int nruns, const
         const Run run = runs[ridx];
         const int qidx = __builtin_amdgcn_readfirstlane(run.job.qidx);
         if(qidx != have_q) { // consecutive runs mostly belong to one rectangle
-            if(lane < kQuantTableBytes / 16)
-                reinterpret_cast<uint4 *>(mine)[lane] = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(qrq) + (size_t)(unsigned)qidx * kQuantTableBytes)[lane];
+            const int ln = opaque(lane); // (not kept as addresses across the runs: light_stream_run's fetch)
+            if(ln < kQuantTableBytes / 16)
+                reinterpret_cast<uint4 *>(mine)[ln] = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(qrq) + (size_t)(unsigned)qidx * kQuantTableBytes)[ln];
             wave_sync();
             have_q = qidx;
         }
-        const float *qrow = mine + (lane & 7) * kQuantRowDwords;
         constexpr int kDepthDc = SHARED ? (I16 ? MJX_STREAM_DEPTH_DC_I16 : MJX_STREAM_DEPTH_DC_F32) : MJX_LIGHT_DEPTH_DC;
         constexpr int kDepthZa = SHARED ? MJX_STREAM_DEPTH_ZA : MJX_LIGHT_DEPTH_ZA;
 #ifdef MJX_EXP_NARROW_STREAM_OFFSETS /* experiment only (wrong beyond 4 GiB of a plane): round 4's addressing, to show that the test of it has teeth */
@@ -1215,8 +1189,11 @@ MJX_DEV void compose_light_stream(const Run *__restrict__ runs, int nruns, const
 #else
         constexpr bool kWide = !SHARED;
 #endif
-        if(__builtin_amdgcn_readfirstlane(run.kind) == kRunDcOnly) light_stream_run<I16, true, kDepthDc, kWide>(run, qrow, lane);
-        else light_stream_run<I16, false, kDepthZa, kWide>(run, qrow, lane);
+        constexpr int kDepthOpq = SHARED ? (I16 ? MJX_STREAM_DEPTH_OPQ_I16 : MJX_STREAM_DEPTH_OPQ_F32) : MJX_LIGHT_DEPTH_OPQ;
+        const int     kind = __builtin_amdgcn_readfirstlane(run.kind);
+        if(kind == kRunDcOnly) light_stream_run<I16, kStreamDc, kDepthDc, kWide>(run, mine, lane);
+        else if(kind == kRunOpaque) light_stream_run<I16, kStreamOpq, kDepthOpq, kWide>(run, mine, lane);
+        else light_stream_run<I16, kStreamZa, kDepthZa, kWide>(run, mine, lane);
     }
 }
 
@@ -1228,11 +1205,7 @@ MJX_DEV void compose_light_stream(const Run *__restrict__ runs, int nruns, const
 template <bool I16>
 __global__ __launch_bounds__(256) MJX_LIGHT_ATTR void compose_light_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
     const int ridx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#ifdef MJX_LIGHT_R03
-    if(ridx < nruns) compose_light_body<I16, 2>(runs, ridx, qrq);
-#else
     compose_light_stream<I16, false>(runs, ridx < nruns ? ridx + 1 : 0, qrq, ridx, 1 << 30); // this wave's one run
-#endif
 }
 template <bool I16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MJX_STREAM_VGPR_CAP))) void compose_light_shared_kernel(const Run *__restrict__ runs, int nruns, const void *__restrict__ qrq) {
@@ -1318,8 +1291,12 @@ int compose_resident_waves(bool tiles_i16) {
 // ------------------------------------------------------------------------------------------
 // w00[block] = the block's weight (0,0) as the compose kernels see it (float bits): DC-only runs carry it
 // in their table instead of fetching the head of every alpha block (a 64-byte request for 4 bytes)
+// opaque: 0 = off; 1 = a block whose only weight is (0,0) = 0.25 gets kOpaqueTag in w00 (int16 tiles: their values are integers by
+// type); 2 = ... and whose 64 tile values are integers below 2^23 in magnitude (float tiles: the tile block is read and checked here,
+// under the caller's promise that the tiles keep their contents, MJX_PLAN_TILES_ARE_FINAL).  Such blocks need not read the image
+// (light_stream_run, kStreamOpq).
 template <bool I16>
-__global__ __launch_bounds__(256) void alpha_pattern_kernel(const Run *__restrict__ runs, int nruns, uint64_t *__restrict__ pattern, uint32_t *__restrict__ w00) {
+__global__ __launch_bounds__(256) void alpha_pattern_kernel(const Run *__restrict__ runs, int nruns, uint64_t *__restrict__ pattern, uint32_t *__restrict__ w00, int opaque) {
     const int lane = threadIdx.x & 63, b = lane >> 3, r = lane & 7;
     const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if(ridx >= nruns) return;
@@ -1345,25 +1322,37 @@ __global__ __launch_bounds__(256) void alpha_pattern_kernel(const Run *__restric
             lo32 |= (unsigned)__shfl_xor((int)lo32, d);
             hi32 |= (unsigned)__shfl_xor((int)hi32, d);
         }
+        // the block's weight (0,0) as the compose kernels see it (every lane of the block computes it: a broadcast load)
+        float w;
+        if constexpr(I16) { // dropon.c:548: (float)((float)coef * (0.3535534 * 0.3535534 / 1020.0))
+            const double kdc = 0.3535534 * 0.3535534 / 1020.0;
+            w = (float)((double)(float)(int)*(reinterpret_cast<const int16_t *>(job.alpha) + (size_t)nc * 64) * kdc);
+        }
+        else {
+            w = job.alpha[(size_t)nc * 64];
+        }
+        bool tag = opaque != 0 && lo32 == 1u && hi32 == 0u && w == 0.25f; // (the same in the block's eight lanes)
+        if(opaque == 2) { // float tiles: this lane's row of the tile block (the test is made for every block: the lanes of the others drop out below)
+            bool whole = true;
+            if(tag) {
+                const float4 t0 = *reinterpret_cast<const float4 *>(job.tile + (size_t)nc * 64 + r * 8), t1 = *reinterpret_cast<const float4 *>(job.tile + (size_t)nc * 64 + r * 8 + 4);
+                const float  tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                for(int u = 0; u < 8; ++u) whole = whole && tv[u] == rintf(tv[u]) && fabsf(tv[u]) < 8388608.0f; // (NaN and infinities fail the first test)
+            }
+            const unsigned long long ok = __ballot(whole);
+            tag = tag && ((ok >> (8 * b)) & 0xFFull) == 0xFFull;
+        }
         if(r == 0 && n < job.nblocks) {
             pattern[(size_t)(unsigned)job.nnz_off + n] = ((uint64_t)hi32 << 32) | lo32;
-            float w;
-            if constexpr(I16) { // dropon.c:548: (float)((float)coef * (0.3535534 * 0.3535534 / 1020.0))
-                const double kdc = 0.3535534 * 0.3535534 / 1020.0;
-                w = (float)((double)(float)(int)*(reinterpret_cast<const int16_t *>(job.alpha) + (size_t)nc * 64) * kdc);
-            }
-            else {
-                w = job.alpha[(size_t)nc * 64];
-            }
-            w00[(size_t)(unsigned)job.nnz_off + n] = __float_as_uint(w);
+            w00[(size_t)(unsigned)job.nnz_off + n] = tag ? kOpaqueTag : __float_as_uint(w);
         }
     }
 }
 
-int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, uint32_t *w00, bool tiles_i16, hipStream_t s) {
+int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, uint32_t *w00, bool tiles_i16, int opaque, hipStream_t s) {
     if(nruns <= 0) return MJX_OK;
-    if(tiles_i16) hipLaunchKernelGGL(alpha_pattern_kernel<true>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, runs, nruns, pattern, w00);
-    else hipLaunchKernelGGL(alpha_pattern_kernel<false>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, runs, nruns, pattern, w00);
+    if(tiles_i16) hipLaunchKernelGGL(alpha_pattern_kernel<true>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, runs, nruns, pattern, w00, opaque ? 1 : 0);
+    else hipLaunchKernelGGL(alpha_pattern_kernel<false>, dim3((unsigned)((nruns + 3) / 4)), dim3(256), 0, s, runs, nruns, pattern, w00, opaque);
     return check_hip(hipGetLastError(), "alpha_pattern_kernel launch", MJX_ERR_LAUNCH);
 }
 

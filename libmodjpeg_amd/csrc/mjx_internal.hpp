@@ -31,10 +31,16 @@ enum RunKind : int32_t {
     // the two kinds below are run by compose_light_kernel, not by compose_kernel:
     kRunZeroAlpha = 2,   // gather octets of blocks whose 64 weights are all zero: the reference skips every
                          // term of such a block (convolve.c:32), Y stays +0, only the JCOEF block travels
-    kRunDcOnly = 3       // gather octets of blocks whose ONLY weight is (0,0) - every block an opaque or evenly
+    kRunDcOnly = 3,      // gather octets of blocks whose ONLY weight is (0,0) - every block an opaque or evenly
                          // translucent part of an overlay covers: of the alpha block only its first weight
                          // travels, and the one term left, V_0(H_0(X)) * w = 2X * 2w, needs no transposition
+    kRunOpaque = 4       // (round 5) ... and of those the OPAQUE ones: the weight is exactly 0.25 (alpha 255 all over the block) and the
+                         // tile holds integers below 2^23 - what tile preparation always produces.  Then Y = (2X)(2 * 0.25) = X =
+                         // tile - coef exactly, coef + (int)Y is the tile value whatever coef was, and the block is written as
+                         // (short)((short)tile / q) WITHOUT reading the image's block: 8 tile indices per octet, like zero-alpha runs
 };
+// w00 of a block the scan found to be opaque (a NaN pattern no weight of a DC-only block can have: NaN != 0.25)
+constexpr uint32_t kOpaqueTag = 0xFFFFFFFFu;
 struct Run {
     DevJob         job;
     int32_t        first;
@@ -139,7 +145,8 @@ int launch_compose_light(const Run *runs, int nruns, const void *qrq, bool tiles
 int launch_compose_light_pair(const Run *runs, int nruns, int nbeside, const void *qrq, bool tiles_i16, hipStream_t beside, hipStream_t after);
 // pattern[first block of the job in the plan + n] = bit (8k + l) set when weight (k, l) of tile block n is not zero
 // ... and w00[same index] = its weight (0,0) as float bits
-int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, uint32_t *w00, bool tiles_i16, hipStream_t s);
+// opaque: 0 no tagging, 1 tag blocks whose only weight is (0,0) = 0.25 (int16 tiles), 2 ... and whose float tile holds integers below 2^23
+int launch_alpha_pattern(const Run *runs, int nruns, uint64_t *pattern, uint32_t *w00, bool tiles_i16, int opaque, hipStream_t s);
 int run_octets();
 // wavefronts of compose_kernel the current device holds at once (CUs x resident waves per CU)
 int compose_resident_waves(bool tiles_i16);

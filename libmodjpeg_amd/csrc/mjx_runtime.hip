@@ -159,10 +159,12 @@ struct SchedStats {
     int64_t blocks = 0, octets = 0, gather_octets = 0, zero_octets = 0, dc_octets = 0, block_terms = 0, union_terms = 0, union_consecutive = 0;
     int64_t low_octets = 0; // blended octets whose weights all lie in columns 0..3
     int64_t low_row_octets = 0; // ... and in rows 0..3
+    int64_t opq_octets = 0;     // octets of opaque blocks (kRunOpaque): the image's block is not read
     void add(const SchedStats &o) {
         union_consecutive += o.union_consecutive;
         low_octets += o.low_octets;
         low_row_octets += o.low_row_octets;
+        opq_octets += o.opq_octets;
         blocks += o.blocks; octets += o.octets; gather_octets += o.gather_octets; zero_octets += o.zero_octets; dc_octets += o.dc_octets;
         block_terms += o.block_terms; union_terms += o.union_terms;
     }
@@ -316,7 +318,7 @@ struct Tables {
 // 505 / 2215 at 1 / 10 / 64 terms in 1 / 4 / 8 columns): 121 fixed + 20.6 per column of weights in use
 // (one H stage and its transposition) + 30.1 per term; an octet cannot be faster than its 5 KiB take
 // to stream, which is what an A2 octet (505) needs as well: below that the memory system is the bound.
-constexpr float kCostFixed = 121.0f, kCostColumn = 20.6f, kCostTerm = 30.1f, kCostMemory = 480.0f, kCostZeroAlpha = 170.0f, kCostDcOnly = 340.0f;
+constexpr float kCostFixed = 121.0f, kCostColumn = 20.6f, kCostTerm = 30.1f, kCostMemory = 480.0f, kCostZeroAlpha = 170.0f, kCostDcOnly = 340.0f, kCostOpaque = 250.0f;
 
 inline unsigned pattern_columns(uint64_t p) { // bit l: some weight (k, l) is used
     p |= p >> 32;
@@ -353,7 +355,7 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     }
     // what the blocks cost as they lie
     bool     all_same = true;
-    int      nzero = 0, ndc = 0;
+    int      nzero = 0, ndc = 0, nopq = 0; // (nopq: DC-only blocks the scan tagged as opaque: w00 == kOpaqueTag)
     float    cost_cons = 0.0f;
     int64_t  terms = 0, union_cons = 0;
     uint64_t union_all = 0;
@@ -365,6 +367,7 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
             all_same = all_same && p == pattern[0];
             nzero += p == 0;
             ndc += p == 1;
+            nopq += p == 1 && w00 != nullptr && w00[o * kWaveBlocks + k] == kOpaqueTag;
             terms += __builtin_popcountll(p);
         }
         cost_cons += octet_cost(u);
@@ -375,7 +378,8 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     st.union_consecutive += union_cons;
     // with the caller's promise that alpha is final: blocks without weights travel without tiles, blocks whose
     // only weight is (0,0) with the head of their alpha block only
-    const bool split_zero = skip_zero && nzero >= kWaveBlocks, split_dc = skip_zero && ndc >= kWaveBlocks;
+    const bool split_opq = skip_zero && nopq >= kWaveBlocks;
+    const bool split_zero = skip_zero && nzero >= kWaveBlocks, split_dc = skip_zero && ndc - (split_opq ? nopq : 0) >= kWaveBlocks;
     auto consecutive = [&]() {
         // (like the zero-alpha and DC-only kinds, the low-column build relies on the alpha tiles keeping the zeros they have now:
         // only with the caller's promise, MJX_PLAN_ALPHA_IS_FINAL / a tile schedule)
@@ -386,7 +390,7 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
         st.low_octets += (low & 1) ? noct_all : 0;
         st.low_row_octets += (low & 2) ? noct_all : 0;
     };
-    if(all_same && !(split_zero && pattern[0] == 0) && !(split_dc && pattern[0] == 1)) return consecutive();
+    if(all_same && !(split_zero && pattern[0] == 0) && !((split_dc || split_opq) && pattern[0] == 1)) return consecutive();
 
     // sorted order: densest first; among blocks of similar density those that use the same rows and
     // columns of weights lie together, then equal patterns.  Real masks have few DISTINCT patterns (an
@@ -430,17 +434,19 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
         return a.p < b.p;
     });
     std::vector<Key> keys;
-    std::vector<int> zeros, dconly;
+    std::vector<int> zeros, dconly, opaque;
     keys.reserve((size_t)nblocks);
     for(const Group &g : groups) {
         for(int n = g.head; n >= 0; n = next[(size_t)n]) {
             if(split_zero && g.p == 0) zeros.push_back(n);
+            else if(split_opq && g.p == 1 && w00[n] == kOpaqueTag) opaque.push_back(n);
             else if(split_dc && g.p == 1) dconly.push_back(n);
             else keys.push_back(Key{g.p, n});
         }
     }
     const int noct_sorted = (int)((keys.size() + kWaveBlocks - 1) / kWaveBlocks);
-    float     cost_sorted = kCostZeroAlpha * (float)((zeros.size() + kWaveBlocks - 1) / kWaveBlocks) + kCostDcOnly * (float)((dconly.size() + kWaveBlocks - 1) / kWaveBlocks);
+    float     cost_sorted = kCostZeroAlpha * (float)((zeros.size() + kWaveBlocks - 1) / kWaveBlocks) + kCostDcOnly * (float)((dconly.size() + kWaveBlocks - 1) / kWaveBlocks) +
+                        kCostOpaque * (float)((opaque.size() + kWaveBlocks - 1) / kWaveBlocks);
     std::vector<uint64_t> unions((size_t)noct_sorted);
     for(int o = 0; o < noct_sorted; ++o) {
         uint64_t u = 0;
@@ -483,12 +489,23 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
                 at[k] = dconly[i < dconly.size() ? i : dconly.size() - 1];
                 gather.push_back(at[k]);
             }
-            for(int k = 0; k < kWaveBlocks; ++k) gather.push_back((int32_t)w00[at[k]]);
+            // (a tagged block that stays here - fewer than eight of them, or a rest - has the weight the tag stands for)
+            for(int k = 0; k < kWaveBlocks; ++k) gather.push_back((int32_t)(w00[at[k]] == kOpaqueTag ? 0x3E800000u /* 0.25f */ : w00[at[k]]));
         }
         st.octets += nd;
         st.gather_octets += nd;
         st.dc_octets += nd;
         st.union_terms += nd;
+    }
+    if(!opaque.empty()) { // 8 tile indices per octet; a ragged last octet repeats its last block (same bytes to the same address)
+        base = (int)(gather.size() / kWaveBlocks);
+        const int no = (int)((opaque.size() + kWaveBlocks - 1) / kWaveBlocks);
+        segs.push_back(Segment{kRunOpaque, 0, base, no});
+        for(int i = 0; i < no * kWaveBlocks; ++i) gather.push_back(opaque[(size_t)i < opaque.size() ? (size_t)i : opaque.size() - 1]);
+        st.octets += no;
+        st.gather_octets += no;
+        st.opq_octets += no;
+        st.union_terms += no;
     }
     if(!zeros.empty()) {
         base = (int)(gather.size() / kWaveBlocks);
@@ -597,7 +614,7 @@ void cut_runs(Tables &t, const std::vector<JobSegment> &all) {
     for(const Stretch &st : stretches) {
         const size_t i = st.i;
         const int    total = st.total, kind = all[i].seg.kind, base = all[i].seg.first;
-        if(kind == kRunZeroAlpha || kind == kRunDcOnly) {
+        if(kind == kRunZeroAlpha || kind == kRunDcOnly || kind == kRunOpaque) {
             // streams for the lean kernel: many short-lived waves (a few octets each), in table order
             const int slots_per_octet = kind == kRunDcOnly ? 2 : 1; // a DC-only octet: 8 tile indices + 8 weights
             for(int f = 0; f < total; f += light_len)
@@ -775,7 +792,8 @@ static int32_t us_since(std::chrono::steady_clock::time_point t0) {
 
 // us (optional): [0] the scan on the device, [1] the patterns coming down (large scans only: the small ones are one queue of
 // upload, kernel and download whose parts the host cannot tell apart, counted under [0])
-int scan_patterns(const Tables &t, RawBuf<uint64_t> &pattern, RawBuf<uint32_t> &w00, mjx_stream_t after, int32_t *us = nullptr) {
+// opaque: launch_alpha_pattern's tagging of opaque blocks (0 off, 1 by weight, 2 by weight and tile contents)
+int scan_patterns(const Tables &t, RawBuf<uint64_t> &pattern, RawBuf<uint32_t> &w00, mjx_stream_t after, int opaque, int32_t *us = nullptr) {
     const auto t_start = std::chrono::steady_clock::now();
     std::vector<Run> tmp;
     for(int jid = 0; jid < (int)t.jobs.size(); ++jid) {
@@ -804,7 +822,7 @@ int scan_patterns(const Tables &t, RawBuf<uint64_t> &pattern, RawBuf<uint32_t> &
         err = check_hip(hipMemcpyAsync(arena->dev, arena->pin, tmp.size() * sizeof(Run), hipMemcpyHostToDevice, s), "hipMemcpyAsync(scan runs)", MJX_ERR_LAUNCH);
         if(err == MJX_OK)
             err = launch_alpha_pattern(reinterpret_cast<const Run *>(arena->dev), (int)tmp.size(), reinterpret_cast<uint64_t *>(arena->dev + run_bytes),
-                                       reinterpret_cast<uint32_t *>(arena->dev + run_bytes + pat_bytes), t.tiles_i16, s);
+                                       reinterpret_cast<uint32_t *>(arena->dev + run_bytes + pat_bytes), t.tiles_i16, opaque, s);
         if(err == MJX_OK) err = check_hip(hipMemcpyAsync(arena->pin + run_bytes, arena->dev + run_bytes, pat_bytes + w_bytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(patterns)", MJX_ERR_LAUNCH);
         const int serr = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize", MJX_ERR_LAUNCH);
         if(err == MJX_OK && serr == MJX_OK) {
@@ -823,7 +841,7 @@ int scan_patterns(const Tables &t, RawBuf<uint64_t> &pattern, RawBuf<uint32_t> &
     if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_pat, pat_bytes), "hipMalloc(patterns)", MJX_ERR_MEMORY);
     if(err == MJX_OK) err = check_hip(hipMalloc((void **)&d_w, w_bytes), "hipMalloc(weights)", MJX_ERR_MEMORY);
     if(err == MJX_OK) err = check_hip(hipMemcpy(d_tmp, tmp.data(), tmp.size() * sizeof(Run), hipMemcpyHostToDevice), "hipMemcpy(scan runs)", MJX_ERR_LAUNCH);
-    if(err == MJX_OK) err = launch_alpha_pattern(d_tmp, (int)tmp.size(), d_pat, d_w, t.tiles_i16, nullptr);
+    if(err == MJX_OK) err = launch_alpha_pattern(d_tmp, (int)tmp.size(), d_pat, d_w, t.tiles_i16, opaque, nullptr);
     if(err == MJX_OK && us) { // (only to tell the kernel from the copies in build_us)
         err = check_hip(hipStreamSynchronize(nullptr), "hipStreamSynchronize(scan)", MJX_ERR_LAUNCH);
         us[0] = us_since(t_start);
@@ -878,7 +896,8 @@ int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, i
     double spent = 0.0;
     int    n = 0;
     for(const RunRef &r : t.light) {
-        spent += (double)r.noctets * (r.kind == kRunDcOnly ? (t.tiles_i16 ? 1.15 : 1.5) : 0.5); // (a block outside the mask is read, and written only if it changed)
+        // (a block outside the mask is read, and written only if it changed; an opaque block: its tile in, the block out)
+        spent += (double)r.noctets * (r.kind == kRunDcOnly ? (t.tiles_i16 ? 1.15 : 1.5) : (r.kind == kRunOpaque ? (t.tiles_i16 ? 0.7 : 1.0) : 0.5));
         if(spent > blend_ns) break;
         ++n;
     }
@@ -901,6 +920,7 @@ void fill_stats(mjx_plan_stats_t *out, const SchedStats &st, int64_t runs, int s
     out->run_octets_min = run_min;
     out->low_column_octets = st.low_octets;
     out->low_row_octets = st.low_row_octets;
+    out->opaque_octets = st.opq_octets;
 }
 } // namespace
 
@@ -920,7 +940,7 @@ int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t
     const int flags = opts->flags;
     if(njobs < 0 || nq < 0) return MJX_ERR_BAD_ARG;
     if(njobs > 0 && (jobs == nullptr || qtables == nullptr || nq == 0)) return MJX_ERR_NULL_DATA;
-    if(flags & ~(MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_TILES_I16 | MJX_PLAN_SERIAL | MJX_PLAN_SIDE_BY_SIDE | MJX_PLAN_NO_LOW_COLUMN_BUILD)) return MJX_ERR_BAD_ARG;
+    if(flags & ~(MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL | MJX_PLAN_TILES_I16 | MJX_PLAN_SERIAL | MJX_PLAN_SIDE_BY_SIDE | MJX_PLAN_NO_LOW_COLUMN_BUILD | MJX_PLAN_TILES_ARE_FINAL)) return MJX_ERR_BAD_ARG;
     if((flags & MJX_PLAN_SERIAL) && (flags & MJX_PLAN_SIDE_BY_SIDE)) return MJX_ERR_BAD_ARG;
     if(opts->run_octets < 0 || opts->run_octets > run_octets() || opts->stream_run_octets < 0 || opts->stream_run_octets > 24 || opts->tail_min_octets < -1 ||
        !(opts->beside_share >= 0.0f && opts->beside_share <= 1.0f))
@@ -975,7 +995,9 @@ int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t
             // without weights leave their tiles behind, which is why that needs the caller's promise
             RawBuf<uint64_t> pattern;
             RawBuf<uint32_t> w00;
-            if((err = scan_patterns(t, pattern, w00, nullptr, p->build_us)) != MJX_OK) break; // after the legacy default stream (mjx.h)
+            // opaque blocks (kRunOpaque) under the promise(s): int16 tiles are integers by type, float tiles are looked at by the scan
+            const int opaque = !(flags & MJX_PLAN_ALPHA_IS_FINAL) ? 0 : (t.tiles_i16 ? 1 : ((flags & MJX_PLAN_TILES_ARE_FINAL) ? 2 : 0));
+            if((err = scan_patterns(t, pattern, w00, nullptr, opaque, p->build_us)) != MJX_OK) break; // after the legacy default stream (mjx.h)
             lap("scan + download");
             // The jobs' schedules are independent (each looks at its own blocks' patterns only), and a batch has thousands of them
             // (4096 images x 3 components: 6.3 M patterns, 40-50 ms on one thread): host threads take contiguous shares of the jobs,
@@ -1203,7 +1225,7 @@ int mjx_tile_schedule_create(mjx_tile_schedule_t **sched, const void *alpha, int
     t.blocks = d.nblocks;
     RawBuf<uint64_t> pattern;
     RawBuf<uint32_t> w00;
-    int              err = scan_patterns(t, pattern, w00, after);
+    int              err = scan_patterns(t, pattern, w00, after, t.tiles_i16 ? 1 : 0); // (a schedule has no tile pointer: opaque blocks for int16 tiles only)
     if(err != MJX_OK) return err;
     mjx_tile_schedule *s = new(std::nothrow) mjx_tile_schedule;
     if(s == nullptr) return MJX_ERR_MEMORY;

@@ -44,7 +44,7 @@ def test_plan_options_are_validated_on_the_host(hiplib):
     q = np.ones(64, np.uint16)
     qp = q.ctypes.data_as(ctypes.c_void_p)
     assert L.mjx_compose_plan_create_opts(ctypes.byref(plan), ctypes.pointer(job), 1, qp, 1, None) == hiplib.MJX_ERR_NULL_DATA
-    for field, value in (("run_octets", 17), ("run_octets", -1), ("stream_run_octets", 25), ("tail_min_octets", -2), ("beside_share", 1.5), ("beside_share", -0.1), ("flags", 64)):
+    for field, value in (("run_octets", 17), ("run_octets", -1), ("stream_run_octets", 25), ("tail_min_octets", -2), ("beside_share", 1.5), ("beside_share", -0.1), ("flags", 128)):
         opt = hiplib.PlanOptions()
         setattr(opt, field, value)
         assert L.mjx_compose_plan_create_opts(ctypes.byref(plan), ctypes.pointer(job), 1, qp, 1, ctypes.byref(opt)) == hiplib.MJX_ERR_BAD_ARG, (field, value)
@@ -72,7 +72,7 @@ def test_ctypes_mirrors_have_the_c_layout(hiplib, tmp_path):
     mirrors = {
         "mjx_rect_job_t": (hiplib.RectJob, ["coef", "blocks_per_row", "qtable", "flags"]),
         "mjx_host_rect_t": (hiplib.HostRect, ["rows_ptr", "q", "blocks_per_row", "flags", "schedule", "stream"]),
-        "mjx_plan_stats_t": (hiplib.PlanStats, ["blocks", "runs", "union_terms", "dc_only_octets", "resident_waves", "run_octets_min", "low_row_octets", "build_us", "reserved"]),
+        "mjx_plan_stats_t": (hiplib.PlanStats, ["blocks", "runs", "union_terms", "dc_only_octets", "resident_waves", "run_octets_min", "low_row_octets", "build_us", "reserved", "opaque_octets"]),
         "mjx_plan_options_t": (hiplib.PlanOptions, ["flags", "run_octets", "stream_run_octets", "tail_min_octets", "beside_share", "reserved"]),
         "mjx_dc_job_t": (hiplib.DcJob, ["coef", "value", "q0"]),
         "mjx_tileprep_t": (hiplib.TilePrep, ["image", "crop_w", "off_y", "source", "ncomp", "h_samp", "v_samp", "tile", "alpha_tile", "flags", "stream"]),

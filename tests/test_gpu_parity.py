@@ -558,6 +558,10 @@ def test_tile_schedules_travel_with_resident_tiles_through_the_host_buffer_call(
         if i16:
             tile = rng.integers(-2000, 2000, (n, 64)).astype(np.int16)
             alpha = np.where(mask, rng.integers(1, 2040, (n, 64)), 0).astype(np.int16)
+            # opaque blocks (the single weight 2040 -> 0.25): written from the tile alone, whatever it holds (mjx.h, MJX_PLAN_TILES_ARE_FINAL)
+            opq = (kind == 1) & (rng.random(n) < 0.6)
+            alpha[opq, 0] = 2040
+            tile[opq] = rng.integers(-32768, 32768, (int(opq.sum()), 64)).astype(np.int16)
             tf = tile.astype(np.float32)
             af = (alpha.astype(np.float32).astype(np.float64) * kk).astype(np.float32)
         else:
@@ -570,6 +574,7 @@ def test_tile_schedules_travel_with_resident_tiles_through_the_host_buffer_call(
         st = PlanStats()
         check(lib().mjx_tile_schedule_stats(sc, ctypes.byref(st)), "mjx_tile_schedule_stats")
         assert st.blocks == n and st.block_terms == int(mask.sum())
+        assert st.opaque_octets == ((int(opq.sum()) + 7) // 8 if i16 and opq.sum() >= 8 else 0), "float tiles: a schedule has not seen the tiles"
         if n >= 64:
             assert lib().mjx_tile_schedule_gather_octets(sc) > 0 and st.zero_alpha_octets > 0
             assert st.union_terms < 2 * st.block_terms / 8 + 64 * 8, "octets of like blocks: the unions stay close to the blocks' own patterns"
@@ -646,8 +651,18 @@ def test_rectangles_made_of_blocks_that_need_no_blend(mj, i16):
             st = PlanStats()
             check(lib().mjx_compose_plan_stats(plan, ctypes.byref(st)), "stats")
             # the 35- and 18-block all-zero rectangles: 5 + 3 octets; the mix: 1; the 33- and 19-block DC-only ones: 5 + 3; the mix: 1;
-            # the single all-zero block stays below the 8-block threshold and goes the general way
-            assert st.zero_alpha_octets == 5 + 3 + 1 and st.dc_only_octets == 5 + 3 + 1, (st.zero_alpha_octets, st.dc_only_octets)
+            # the single all-zero block stays below the 8-block threshold and goes the general way.  int16 tiles: the blocks of a
+            # rectangle whose single weight is 2040 (-> 0.25) are opaque blocks and leave for a stream of their own when there are eight
+            want_dc = want_opq = 0
+            for (_, _, alpha), shape in zip(host, shapes):
+                single = (np.count_nonzero(alpha, axis=1) == 1) & (alpha[:, 0] != 0)
+                nopq = int((single & (alpha[:, 0] == 2040)).sum()) if i16 else 0
+                nopq = nopq if nopq >= 8 else 0
+                ndc = int(single.sum()) - nopq
+                want_opq += (nopq + 7) // 8
+                want_dc += (ndc + 7) // 8 if ndc >= 8 else 0
+            assert want_dc + want_opq >= 5 + 3 + 1
+            assert st.zero_alpha_octets == 5 + 3 + 1 and st.dc_only_octets == want_dc and st.opaque_octets == want_opq, (st.zero_alpha_octets, st.dc_only_octets, st.opaque_octets)
         check(lib().mjx_compose_run(plan, None), "run")
         check(lib().mjx_compose_run(plan, None), "run")  # twice: the second pass starts from composed planes
         torch.cuda.synchronize()
@@ -664,6 +679,98 @@ def test_rectangles_made_of_blocks_that_need_no_blend(mj, i16):
             O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 2]), tf, af)
         assert np.array_equal(results[1][j].reshape(-1), want), ("plain plan", j)
         assert np.array_equal(results[0][j].reshape(-1), want), ("lean kernel", j, kind)
+
+
+@pytest.mark.parametrize("i16", [False, True])
+@pytest.mark.parametrize("seed", [404] + _EXTRA_SEEDS)
+def test_opaque_blocks_are_written_from_their_tiles_alone(mj, seed, i16):
+    """MJX_PLAN_TILES_ARE_FINAL (float tiles) / int16 tiles under MJX_PLAN_ALPHA_IS_FINAL: a block whose only weight is (0,0) = 0.25
+    and whose tile holds whole numbers below 2^23 is written as (short)((short)(int)tile / q) without a read of the image
+    (compose.c:277-336 is exact for it).  Here: such blocks with tile values up to +-(2^23 - 1), -0.0, and images that hold
+    +-32767 under quantisers that make coef * q wrap; and every near miss - one tile value with a fraction, +-2^23, NaN, an infinity;
+    the weight one ulp beside 0.25; a second weight elsewhere in the block - which must stay with the single-weight blocks.
+    Plans with and without the promises, kernels side by side and one after the other: all == oracle."""
+    import torch
+    from libmodjpeg_amd._lib import (MJX_JOB_TILES_I16, MJX_PLAN_ALPHA_IS_FINAL, MJX_PLAN_GROUP_BY_DENSITY, MJX_PLAN_SERIAL, MJX_PLAN_SIDE_BY_SIDE, MJX_PLAN_TILES_ARE_FINAL, PlanStats,
+                                     RectJob, check, lib)
+    rng = np.random.default_rng(seed + i16)
+    c0, c1 = 0.3535534, 0.5
+    kk = np.array([(c0 if j // 8 == 0 else c1) * (c0 if j % 8 == 0 else c1) / 1020.0 for j in range(64)], np.float64)
+    shapes = [(30, 40, 2, 3, 21, 33), (12, 9, 0, 0, 12, 9), (5, 70, 1, 4, 3, 61), (6, 6, 2, 2, 2, 3)]  # prow, bpr, row0, col0, rows, cols
+    quants = np.stack([rng.integers(1, 256, 64), rng.integers(1, 65536, 64), np.ones(64)]).astype(np.uint16)
+    host, want_opaque = [], 0
+    for prow, bpr, row0, col0, rows, cols in shapes:
+        n = rows * cols
+        coef = rng.integers(-1024, 1024, (prow, bpr, 64)).astype(np.int16)
+        coef[rng.random((prow, bpr, 64)) < 0.01] = 32767
+        coef[rng.random((prow, bpr, 64)) < 0.01] = -32768
+        kind = rng.choice(np.arange(8), n, p=[0.45, 0.1, 0.05, 0.05, 0.05, 0.1, 0.1, 0.1])  # 0 opaque, 1-4 near misses, 5 no weight, 6 single weight, 7 dense
+        if i16:
+            tile = rng.integers(-32768, 32768, (n, 64)).astype(np.int16)
+            alpha = np.zeros((n, 64), np.int16)
+            alpha[kind <= 4, 0] = 2040
+            alpha[kind == 1, 0] = 2039
+            alpha[kind == 2, 0] = 2041
+            alpha[kind == 3, 63] = 1
+            alpha[kind == 4, rng.integers(1, 64, int((kind == 4).sum()))] = -1
+            alpha[kind == 6, 0] = rng.integers(1, 2040, int((kind == 6).sum()))
+            alpha[kind == 7] = rng.integers(1, 2040, (int((kind == 7).sum()), 64))
+            exact = kind == 0
+        else:
+            big = rng.random(n) < 0.3
+            tile = np.where(big[:, None], rng.integers(-(2**23) + 1, 2**23, (n, 64)), rng.integers(-3000, 3000, (n, 64))).astype(np.float32)
+            tile[rng.random((n, 64)) < 0.01] = np.float32(-0.0)
+            alpha = np.zeros((n, 64), np.float32)
+            alpha[kind <= 4, 0] = 0.25
+            at = rng.integers(0, 64, n)
+            miss = np.array([0.5, 8388608.0, -8388608.0, np.nan, np.inf, -np.inf, 1e-3, 8388607.5], np.float32)
+            for k in np.flatnonzero(kind == 1):  # one value of the tile is not a whole number below 2^23
+                tile[k, at[k]] = miss[rng.integers(0, len(miss))]
+            alpha[kind == 2, 0] = np.nextafter(np.float32(0.25), np.float32(rng.choice([0.0, 1.0])))
+            alpha[kind == 3, 63] = 1e-41
+            alpha[kind == 4, rng.integers(1, 64, int((kind == 4).sum()))] = np.float32("nan")
+            alpha[kind == 6, 0] = (rng.random(int((kind == 6).sum())) * 0.3 + 0.01).astype(np.float32)
+            alpha[kind == 7] = (rng.standard_normal((int((kind == 7).sum()), 64)) * 0.05).astype(np.float32)
+            exact = (kind == 0) | ((kind == 1) & np.array([miss_ok(tile[k]) for k in range(n)]))
+        ne = int(exact.sum())
+        want_opaque += (ne + 7) // 8 if ne >= 8 else 0
+        host.append((coef, np.ascontiguousarray(tile), np.ascontiguousarray(alpha)))
+    jobs = (RectJob * len(shapes))()
+    final = MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_ALPHA_IS_FINAL
+    results, variants = [], (final | MJX_PLAN_TILES_ARE_FINAL, final, 0, final | MJX_PLAN_TILES_ARE_FINAL | MJX_PLAN_SIDE_BY_SIDE, final | MJX_PLAN_TILES_ARE_FINAL | MJX_PLAN_SERIAL,
+                         MJX_PLAN_GROUP_BY_DENSITY | MJX_PLAN_TILES_ARE_FINAL)
+    for flags in variants:
+        dev = [(_t(c), _t(t), _t(a)) for c, t, a in host]
+        for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
+            jobs[j] = RectJob(dev[j][0].data_ptr(), dev[j][1].data_ptr(), dev[j][2].data_ptr(), bpr, prow, row0, col0, rows, cols, j % 3, MJX_JOB_TILES_I16 if i16 else 0)
+        plan = ctypes.c_void_p()
+        check(lib().mjx_compose_plan_create_ex(ctypes.byref(plan), jobs, len(shapes), quants.ctypes.data_as(ctypes.c_void_p), 3, flags), "plan")
+        st = PlanStats()
+        check(lib().mjx_compose_plan_stats(plan, ctypes.byref(st)), "stats")
+        promised = bool(flags & MJX_PLAN_ALPHA_IS_FINAL) and (i16 or bool(flags & MJX_PLAN_TILES_ARE_FINAL))
+        assert st.opaque_octets == (want_opaque if promised else 0), (hex(flags), st.opaque_octets, want_opaque)
+        check(lib().mjx_compose_run(plan, None), "run")
+        check(lib().mjx_compose_run(plan, None), "run")  # twice: an opaque block comes out the same, the others start from composed planes
+        torch.cuda.synchronize()
+        lib().mjx_compose_plan_destroy(plan)
+        results.append([d[0].cpu().numpy() for d in dev])
+    for j, (prow, bpr, row0, col0, rows, cols) in enumerate(shapes):
+        want = host[j][0].reshape(-1).copy()
+        if i16:
+            tf = host[j][1].astype(np.float32).reshape(-1)
+            af = (host[j][2].astype(np.float32).astype(np.float64) * kk).astype(np.float32).reshape(-1)
+        else:
+            tf, af = host[j][1].reshape(-1), host[j][2].reshape(-1)
+        for _ in range(2):
+            O.compose_rect(want, bpr, row0, col0, rows, cols, np.ascontiguousarray(quants[j % 3]), tf, af)
+        for v, flags in enumerate(variants):
+            assert np.array_equal(results[v][j].reshape(-1), want), (hex(flags), j)
+
+
+def miss_ok(row):
+    """all 64 values whole numbers below 2^23 (what the scan of MJX_PLAN_TILES_ARE_FINAL asks of a tile block)"""
+    with np.errstate(invalid="ignore"):
+        return bool(np.all(np.isfinite(row)) and np.all(row == np.rint(row)) and np.all(np.abs(row) < 8388608.0))
 
 
 def test_host_paths_in_place_and_staged_give_the_same_bytes(mj):
