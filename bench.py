@@ -84,6 +84,7 @@ def parse(argv=None):
                          "the other, side by side, or as the library decides (default; side by side when both fill the device)")
     ap.add_argument("--beside-share", type=float, default=0.0, help="compose, side-by-side launches: this share of the stream runs goes beside the blend kernel (mjx_plan_options_t; 0 = the library's estimate)")
     ap.add_argument("--run-octets", type=int, default=0, help="compose: octets per wave of the blend kernel (mjx_plan_options_t.run_octets; 0 = by the size of the launch)")
+    ap.add_argument("--tail-min-octets", type=int, default=0, help="compose: mjx_plan_options_t.tail_min_octets (0 = the library's choice, -1 = runs never shrink towards the end of a launch)")
     ap.add_argument("--stream-run-octets", type=int, default=0, help="compose: octets per run of the stream kernel (mjx_plan_options_t.stream_run_octets; 0 = 4)")
     ap.add_argument("--no-low-column-build", action="store_true", help="compose: MJX_PLAN_NO_LOW_COLUMN_BUILD (smooth runs take the general build of the blend kernel)")
     ap.add_argument("--keep-zero-alpha", action="store_true",
@@ -94,7 +95,7 @@ def parse(argv=None):
     ap.add_argument("--also", default="auto", choices=["auto", "none"],
                     help="auto (default): the headline run (default workload, regime, tiles and launch on one GPU) also measures, inside the same JSON line, what "
                          "making its plan costs (`plan_ms`), the same launch planned WITHOUT the promise that alpha is final (`roofline.frac_without_promise`) and, "
-                         "under `also`, the other regimes of the same batch (A5 real mask, A4 mixed, A3 dense), the 4K full-frame config and the effects batch, each "
+                         "under `also`, the other regimes of the same batch (A5 real mask, A4 mixed, A3 dense, A1 opaque), the 4K full-frame config and the effects batch, each "
                          "with its step time, its parity verdict and its fraction of the HBM peak on the bytes its plan moves; none: the headline only")
     ap.add_argument("--also-steps", type=int, default=20, help="timed steps of every `also` measurement (effects: a quarter of it)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
@@ -563,7 +564,7 @@ def bench_compose(args, rank, world):
     bytes_per_block = 512 if args.tiles == "i16" else BYTES_PER_BLOCK  # int16 tiles: 128 + 128 + 128 read, 128 written
     batch.fill_synthetic()
     batch.build_plan(group_by_density=not args.no_group, alpha_is_final=not args.keep_zero_alpha, side_by_side={"auto": None, "serial": False, "side-by-side": True}[args.launch],
-                     run_octets=args.run_octets, stream_run_octets=args.stream_run_octets, beside_share=args.beside_share, low_column_build=not args.no_low_column_build,
+                     run_octets=args.run_octets, stream_run_octets=args.stream_run_octets, tail_min_octets=args.tail_min_octets, beside_share=args.beside_share, low_column_build=not args.no_low_column_build,
                      tiles_are_final=False if args.tiles_not_final else None)
     plan_stats = batch.plan_stats()
     blocks_per_step = batch.total_blocks()
@@ -694,7 +695,7 @@ def bench_compose(args, rank, world):
             out["roofline"]["frac_without_promise"] = wp["frac_on_bytes_moved"]
             out["roofline"]["kernel_ms_without_promise"] = wp["ms_per_step"]
             out["roofline"]["without_promise"] = wp
-            also = {"compose_1080p_batch:" + r: also_compose(batch, cfg, r, args.also_steps, 8) for r in ("A5", "A4", "A3")}
+            also = {"compose_1080p_batch:" + r: also_compose(batch, cfg, r, args.also_steps, 8) for r in ("A5", "A4", "A3", "A1")}
             del batch
             if pristine is not None:
                 del pristine

@@ -390,7 +390,10 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
         st.low_octets += (low & 1) ? noct_all : 0;
         st.low_row_octets += (low & 2) ? noct_all : 0;
     };
-    if(all_same && !(split_zero && pattern[0] == 0) && !((split_dc || split_opq) && pattern[0] == 1)) return consecutive();
+    // (test build, measurements: MJX_EXP_GATHER=1 sends blocks that all need the same through the gather form - same blocks per octet,
+    // named by the table; =2 also shuffles them, so that an octet's blocks lie anywhere in the rectangle)
+    static const int exp_gather = tuning_env("MJX_EXP_GATHER") ? atoi(tuning_env("MJX_EXP_GATHER")) : 0;
+    if(!exp_gather && all_same && !(split_zero && pattern[0] == 0) && !((split_dc || split_opq) && pattern[0] == 1)) return consecutive();
 
     // sorted order: densest first; among blocks of similar density those that use the same rows and
     // columns of weights lie together, then equal patterns.  Real masks have few DISTINCT patterns (an
@@ -444,6 +447,13 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
             else keys.push_back(Key{g.p, n});
         }
     }
+    if(exp_gather == 2) {
+        uint64_t x = 0x9E3779B97F4A7C15ull ^ (uint64_t)nblocks;
+        for(size_t i = keys.size(); i > 1; --i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            std::swap(keys[i - 1], keys[(size_t)(x % i)]);
+        }
+    }
     const int noct_sorted = (int)((keys.size() + kWaveBlocks - 1) / kWaveBlocks);
     float     cost_sorted = kCostZeroAlpha * (float)((zeros.size() + kWaveBlocks - 1) / kWaveBlocks) + kCostDcOnly * (float)((dconly.size() + kWaveBlocks - 1) / kWaveBlocks) +
                         kCostOpaque * (float)((opaque.size() + kWaveBlocks - 1) / kWaveBlocks);
@@ -455,7 +465,7 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
         cost_sorted += octet_cost(u);
     }
     // a gathered octet fetches its tiles as four 256-byte segments per piece and its table: it has to buy something
-    if(cost_sorted > 0.93f * cost_cons) return consecutive();
+    if(!exp_gather && cost_sorted > 0.93f * cost_cons) return consecutive();
 
     int base = (int)(gather.size() / kWaveBlocks);
     for(int o = 0; o < noct_sorted;) { // stretches of octets of one cost class (and all with, or not all with, their weights in columns 0..3)
@@ -896,8 +906,10 @@ int side_by_side_share(const Tables &t, const mjx_rect_job_t *jobs, int njobs, i
     double spent = 0.0;
     int    n = 0;
     for(const RunRef &r : t.light) {
-        // (a block outside the mask is read, and written only if it changed; an opaque block: its tile in, the block out)
-        spent += (double)r.noctets * (r.kind == kRunDcOnly ? (t.tiles_i16 ? 1.15 : 1.5) : (r.kind == kRunOpaque ? (t.tiles_i16 ? 0.7 : 1.0) : 0.5));
+        // (a block outside the mask is read, and written only if it changed; an opaque block: its tile in, the block out - float
+        // tiles 1.12: the sweep of profiles/r05/beside_share_after_opaque_blocks.txt has its best step at 0.7-0.8 of A5's stream runs
+        // and 0.8-0.9 of A4's)
+        spent += (double)r.noctets * (r.kind == kRunDcOnly ? (t.tiles_i16 ? 1.15 : 1.5) : (r.kind == kRunOpaque ? (t.tiles_i16 ? 0.7 : 1.12) : 0.5));
         if(spent > blend_ns) break;
         ++n;
     }

@@ -22,7 +22,7 @@ prof write_A2 --pmc WRITE_SIZE -- $H
 prof stats_A2nopromise --kernel-trace --stats -- $H --keep-zero-alpha
 prof fetch_A2nopromise --pmc FETCH_SIZE -- $H --keep-zero-alpha
 prof write_A2nopromise --pmc WRITE_SIZE -- $H --keep-zero-alpha
-for RG in A5 A4 A3; do
+for RG in A1 A5 A4 A3; do
   prof stats_$RG --kernel-trace --stats -- $H --regime $RG
   prof fetch_$RG --pmc FETCH_SIZE -- $H --regime $RG
   prof write_$RG --pmc WRITE_SIZE -- $H --regime $RG
