@@ -297,9 +297,10 @@ int mjx_compose_rect_host(int16_t *plane, int blocks_per_row, int plane_rows, in
  * (off_x, off_y) inside a canvas of whole MCUs, becomes one contiguous array of prepared float
  * tiles per component for image and alpha, identical to the ones the linked libjpeg (IJG 9d) would
  * have produced.  Supported: 3 components; target YCbCr from an RGB or YCbCr overlay, target RGB
- * from an RGB overlay; every component at full resolution or subsampled 2:1 in either direction
- * (4:4:4, 4:2:2, 4:4:0, 4:2:0) or 4:1 horizontally (4:1:1, 4:1:0: libjpeg's h2v1 box filter in front of a 16-wide
- * transform); 1 component, target grayscale from an RGB or YCbCr overlay.  Anything else returns
+ * from an RGB overlay; every component at full resolution or subsampled by a whole number up to 4 in either
+ * direction (4:4:4, 4:2:2, 4:4:0, 4:2:0; 4:1:1, 4:1:0, 1x4 or 3x1 luma ...: libjpeg's box filters - h2v1, h2v2, int_downsample -
+ * in front of the transform that folds one halving of an even ratio); 1 component, target grayscale from an RGB or YCbCr
+ * overlay.  Anything else (fractional ratios, which libjpeg does not compress either; four components) returns
  * MJX_ERR_BAD_ARG before touching the device, and the caller prepares the tiles with libjpeg.
  * Block counts: canvas = crop + offset rounded up to whole MCUs; component c has
  * canvas_w / (8 * hmax / h_samp[c]) columns and canvas_h / (8 * vmax / v_samp[c]) rows. */

@@ -22,9 +22,12 @@
 // Supported: three components, target YCbCr (overlay RGB: converted; overlay YCbCr: as is) or RGB
 // (overlay RGB), every component at full resolution or subsampled 2:1 in either direction (4:4:4,
 // 4:2:2, 4:4:0, 4:2:0); one component, target grayscale (overlay RGB: libjpeg's Y; overlay YCbCr: its
-// first component); a component subsampled 4:1 horizontally (4:1:1, 4:1:0): libjpeg folds only ONE halving
-// into the transform and makes the other with its h2v1 box filter, reproduced in prep_block.  Everything
-// else (vertical ratios above 2, CMYK ...) returns MJX_ERR_BAD_ARG and the caller prepares the tiles with
+// first component); and every other whole-number ratio a component can have (3 and 4 in either direction: 4:1:1, 4:1:0,
+// 1x4 luma ...).  libjpeg 9 folds ONE halving per direction into the transform (jcmaster.c: DCT_h/v_scaled_size 16 when
+// the ratio is even) and makes what is left of the ratio - 2 of a ratio 4, the whole of a ratio 3 - with jcsample.c's
+// downsamplers on the colour-converted samples: h2v1 (bias 0, 1, 0, 1 ...), h2v2 (bias 1, 2, 1, 2 ...), and its general box
+// filter int_downsample for every other pair ((sum + n / 2) / n), all reproduced in prep_block.  Everything
+// else (fractional ratios, CMYK ...) returns MJX_ERR_BAD_ARG and the caller prepares the tiles with
 // libjpeg as before.
 //
 // One wavefront per output block: the C x R samples go to LDS (colour conversion on the way),
@@ -43,7 +46,7 @@ struct PrepComp {
     int32_t rows, cols;     // blocks
     int32_t nx, ny;         // samples per block: 8 or 16 in each direction
     int32_t first;          // index of this component's first block in the launch
-    int32_t pre;            // 2: the samples are first averaged in horizontal pairs (a 4:1 ratio: see prep_block), else 1
+    int32_t pre_x, pre_y;   // the samples are first averaged over pre_x x pre_y pixels (what the transform does not fold: see prep_block)
 };
 
 struct PrepJob {
@@ -85,7 +88,7 @@ MJX_FDCT(16, 16);
 MJX_FDCT(16, 8);
 MJX_FDCT(8, 16);
 
-template <int C, int R> __device__ __forceinline__ void prep_block(const PrepJob &job, int c, int kind, int brow, int bcol, float *out, int lane, int (*s)[16], int (*d1)[8], int pre) {
+template <int C, int R> __device__ __forceinline__ void prep_block(const PrepJob &job, int c, int kind, int brow, int bcol, float *out, int lane, int (*s)[16], int (*d1)[8], int pre_x, int pre_y) {
     using T = Fdct<C, R>;
     const int *M1 = T::M1(), *M2 = T::M2(), *B1 = T::B1(), *S1 = T::S1(), *B2 = T::B2(), *S2 = T::S2();
     const unsigned char *pix = kind == 0 ? job.image : job.alpha;
@@ -102,15 +105,21 @@ template <int C, int R> __device__ __forceinline__ void prep_block(const PrepJob
     };
     for(int i = lane; i < C * R; i += 64) {
         const int sy = i / C, sx = i - sy * C;
-        if(pre == 2) {
-            // a component subsampled 4:1 horizontally (4:1:1, 4:1:0): IJG 9 folds ONE halving into the transform
-            // (16 samples per row) and makes the other with jcsample.c h2v1_downsample on the colour-converted
-            // samples: (a + b + bias) >> 1, bias alternating 0, 1 along the output row from 0
-            const int ox = bcol * C + sx;
-            s[sy][sx] = (sample(2 * ox, brow * R + sy) + sample(2 * ox + 1, brow * R + sy) + (ox & 1)) >> 1;
+        const int ox = bcol * C + sx, oy = brow * R + sy; // the sample's place in the component as the transform sees it
+        if(pre_x == 1 && pre_y == 1) {
+            s[sy][sx] = sample(ox, oy);
         }
         else {
-            s[sy][sx] = sample(bcol * C + sx, brow * R + sy);
+            // what IJG 9 does not fold into the transform it makes with jcsample.c on the colour-converted samples:
+            //   2 x 1  h2v1_downsample: (a + b + bias) >> 1, bias 0, 1, 0, 1 ... along the output row          (4:1:1, 4:1:0)
+            //   2 x 2  h2v2_downsample: (a + b + c + d + bias) >> 2, bias 1, 2, 1, 2 ...
+            //   else   int_downsample:  (sum + n / 2) / n over the pre_x x pre_y box                           (ratios 3; 1 x 2 of a vertical ratio 4)
+            int sum = 0;
+            for(int j = 0; j < pre_y; ++j)
+                for(int i = 0; i < pre_x; ++i) sum += sample(ox * pre_x + i, oy * pre_y + j);
+            if(pre_x == 2 && pre_y == 1) s[sy][sx] = (sum + (ox & 1)) >> 1;
+            else if(pre_x == 2 && pre_y == 2) s[sy][sx] = (sum + 1 + (ox & 1)) >> 2;
+            else s[sy][sx] = (sum + (pre_x * pre_y) / 2) / (pre_x * pre_y);
         }
     }
     __syncthreads();
@@ -155,10 +164,10 @@ __global__ __launch_bounds__(64) void tileprep_kernel(PrepJob job) {
     const PrepComp pc = job.comp[c];
     const int      blk = id - pc.first, brow = blk / pc.cols, bcol = blk - brow * pc.cols;
     float         *out = (kind == 0 ? pc.tile : pc.alpha) + (size_t)blk * (job.i16 ? 32 : 64); // an int16 block is 32 floats long
-    if(pc.nx == 8 && pc.ny == 8) prep_block<8, 8>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre);
-    else if(pc.nx == 16 && pc.ny == 16) prep_block<16, 16>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre);
-    else if(pc.nx == 16) prep_block<16, 8>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre);
-    else prep_block<8, 16>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre);
+    if(pc.nx == 8 && pc.ny == 8) prep_block<8, 8>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre_x, pc.pre_y);
+    else if(pc.nx == 16 && pc.ny == 16) prep_block<16, 16>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre_x, pc.pre_y);
+    else if(pc.nx == 16) prep_block<16, 8>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre_x, pc.pre_y);
+    else prep_block<8, 16>(job, c, kind, brow, bcol, out, lane, s, d1, pc.pre_x, pc.pre_y);
 }
 
 } // namespace mjx
@@ -199,14 +208,17 @@ extern "C" int mjx_tiles_prepare(const mjx_tileprep_t *p) {
     for(int c = 0; c < ncomp; ++c) {
         if(hmax % p->h_samp[c] != 0 || vmax % p->v_samp[c] != 0) return MJX_ERR_BAD_ARG;
         const int fx = hmax / p->h_samp[c], fy = vmax / p->v_samp[c];
-        // 8x8, 16x16, 16x8, 8x16 transforms; a horizontal ratio of 4 = h2v1 box filter + a 16-wide transform
-        if((fx != 1 && fx != 2 && fx != 4) || (fy != 1 && fy != 2)) return MJX_ERR_BAD_ARG;
+        // 8x8, 16x16, 16x8, 8x16 transforms (an even ratio folds one halving into the transform: jcmaster.c, DCT_h/v_scaled_size;
+        // never more than a factor 2 between the two sizes, which ratios up to 4 cannot exceed); the rest of the ratio is a box filter
+        if(fx < 1 || fx > 4 || fy < 1 || fy > 4) return MJX_ERR_BAD_ARG;
+        const int fold_x = fx % 2 == 0 ? 2 : 1, fold_y = fy % 2 == 0 ? 2 : 1;
         if(p->tile[c] == nullptr || p->alpha_tile[c] == nullptr) return MJX_ERR_NULL_DATA;
         job.comp[c].tile = p->tile[c];
         job.comp[c].alpha = p->alpha_tile[c];
-        job.comp[c].nx = fx == 1 ? 8 : 16;
-        job.comp[c].ny = 8 * fy;
-        job.comp[c].pre = fx == 4 ? 2 : 1;
+        job.comp[c].nx = 8 * fold_x;
+        job.comp[c].ny = 8 * fold_y;
+        job.comp[c].pre_x = fx / fold_x;
+        job.comp[c].pre_y = fy / fold_y;
         job.comp[c].cols = (int32_t)(W / (8 * fx));
         job.comp[c].rows = (int32_t)(H / (8 * fy));
         job.comp[c].first = (int32_t)total;

@@ -351,7 +351,7 @@ static int device_prep_enabled(void) {
 /* the tiles of a miss prepared on the device (mjx_tiles_prepare: forward DCT, colour conversion and
  * DCT-scaled chroma of the linked libjpeg as exact integer forms), nothing but the overlay's visible
  * pixels crossing PCIe.  MJX_ERR_BAD_ARG: this overlay / target combination is libjpeg's (gray,
- * CMYK, 4:1:1 ...), the caller takes the host path.  want_i16: the tiles stay the int16 coefficients. */
+ * CMYK, fractional sampling ratios ...), the caller takes the host path.  want_i16: the tiles stay the int16 coefficients. */
 static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_sampling_t *s, int bx, int by, int cx, int cy, int cw,
                                 int ch, int want_i16) {
     mjx_tileprep_t p;
@@ -364,7 +364,7 @@ static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COL
     for(c = 0; c < ncomp; c++) { /* formats the device does not reproduce are declined before anything is allocated or copied */
         const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
         if(hs < 1 || vs < 1 || s->max_h_samp_factor % hs != 0 || s->max_v_samp_factor % vs != 0) return MJX_ERR_BAD_ARG;
-        if((s->max_h_samp_factor / hs > 2 && s->max_h_samp_factor / hs != 4) || s->max_v_samp_factor / vs > 2) return MJX_ERR_BAD_ARG;
+        if(s->max_h_samp_factor / hs > 4 || s->max_v_samp_factor / vs > 4) return MJX_ERR_BAD_ARG;
     }
     /* the entry's copy of the window first: when it is pinned it is also the upload source */
     if((e = window_copy(t, d, cx, cy, cw, ch)) != MJX_OK) return e;
@@ -419,7 +419,8 @@ static int contents_fill_device(struct mjh_tiles *t, const mj_dropon_t *d, J_COL
     return MJX_OK;
 }
 
-/* the combinations mjx_tiles_prepare reproduces (the others are libjpeg's: CMYK, gray overlays, 4:1:1 ...) */
+/* the combinations mjx_tiles_prepare reproduces: every whole-number sampling ratio up to 4 (the others are libjpeg's: CMYK, gray overlays,
+ * fractional ratios - which libjpeg itself refuses to compress) */
 static int device_prep_covers(const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_sampling_t *s) {
     const int ncomp = cs == JCS_GRAYSCALE ? 1 : 3;
     int       c;
@@ -430,7 +431,7 @@ static int device_prep_covers(const mj_dropon_t *d, J_COLOR_SPACE cs, const mj_s
     for(c = 0; c < ncomp; c++) {
         const int hs = s->samp_factor[c].h_samp_factor, vs = s->samp_factor[c].v_samp_factor;
         if(hs < 1 || vs < 1 || s->max_h_samp_factor % hs != 0 || s->max_v_samp_factor % vs != 0) return 0;
-        if((s->max_h_samp_factor / hs > 2 && s->max_h_samp_factor / hs != 4) || s->max_v_samp_factor / vs > 2) return 0;
+        if(s->max_h_samp_factor / hs > 4 || s->max_v_samp_factor / vs > 4) return 0;
     }
     return 1;
 }

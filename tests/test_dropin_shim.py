@@ -169,14 +169,18 @@ def test_gpu_tile_preparation_matches_reference(shim, golden_dir, tmp_path, case
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sampling,expect", [("420", "gpu"), ("444", "gpu"), ("422", "gpu"), ("440", "gpu"), ("rgb", "gpu"), ("gray", "gpu"), ("411", "gpu"), ("410", "gpu")])
+@pytest.mark.parametrize("sampling,expect", [("420", "gpu"), ("444", "gpu"), ("422", "gpu"), ("440", "gpu"), ("rgb", "gpu"), ("gray", "gpu"), ("411", "gpu"), ("410", "gpu"),
+                                             # round 5: every whole-number ratio libjpeg compresses (<= 10 blocks per MCU): vertical 4 (8x16 transform + its 1x2 box filter),
+                                             # 3 in either direction (box filter alone), luma BELOW the chroma resolution, and 4 in both directions (h2v2 + 16x16)
+                                             ("1x4,1x1,1x1", "gpu"), ("2x4,1x1,1x1", "gpu"), ("3x1,1x1,1x1", "gpu"), ("3x2,1x1,1x1", "gpu"), ("1x3,1x1,1x1", "gpu"),
+                                             ("2x3,1x1,1x1", "gpu"), ("2x2,2x1,1x2", "gpu"), ("4x1,1x4,1x1", "gpu"), ("1x1,2x2,2x2", "gpu")])
 def test_gpu_tile_preparation_equals_libjpeg_on_random_overlays(shim, tmp_path, sampling, expect):
     """device-prepared tiles == libjpeg-prepared tiles (the drop-in's host path, itself pinned to the
     reference) on random overlays: RGB / RGBA / YCC / YCCA pixels, odd sizes, every kind of in-MCU
     offset and crop, noise / smooth / saturated contents, translucent blends; 4:2:0, 4:4:4, 4:2:2 and
     4:4:0 targets (libjpeg's 8x8, 16x16, 16x8 and 8x16 transforms), grayscale targets and 4:1:1 / 4:1:0 targets
     (its h2v1 box filter in front of a 16-wide transform) are all prepared on the device"""
-    rng = np.random.default_rng(int(sampling) if sampling.isdigit() else (7 if sampling == "rgb" else 9))
+    rng = np.random.default_rng(int(sampling) if sampling.isdigit() else (7 if sampling == "rgb" else (9 if sampling == "gray" else sum(map(ord, sampling)))))
     target = str(tmp_path / "target.jpg")
     _make_input(target, ("200", "120"), sampling)
     probe = os.path.join(TOOLS, "mjhost_probe")
@@ -196,7 +200,7 @@ def test_gpu_tile_preparation_equals_libjpeg_on_random_overlays(shim, tmp_path, 
         pix.tofile(raw)
         cx, cy = int(rng.integers(0, w)), int(rng.integers(0, h))
         cw, ch = int(rng.integers(1, w - cx + 1)), int(rng.integers(1, h - cy + 1))
-        bx, by = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+        bx, by = int(rng.integers(0, 32)), int(rng.integers(0, 32))  # (MCUs are up to 32 pixels wide / high with the round-5 samplings; a larger offset only pads more, in both paths)
         blend = [255, 128, 1][trial % 3]
         args = [target, str(raw), str(w), str(h), str(cs), str(blend), str(bx), str(by), str(cx), str(cy), str(cw), str(ch)]
         a, b = tmp_path / f"host{trial}.bin", tmp_path / f"gpu{trial}.bin"

@@ -48,7 +48,7 @@ static unsigned char *make_jpeg(int w, int h, uint32_t seed, unsigned long *len)
     c.in_color_space = JCS_RGB;
     jpeg_set_defaults(&c);
     jpeg_set_quality(&c, 85, TRUE);
-    { /* BENCH_SAMPLING = 420 (default) | 422 | 444 | 440 | 411 | 410 | gray | rgb (an RGB-colourspace JPEG, 1x1 sampling) */
+    { /* BENCH_SAMPLING = 420 (default) | 422 | 444 | 440 | 411 | 410 | HxV,HxV,HxV | gray | rgb (an RGB-colourspace JPEG, 1x1 sampling) */
         const char *sm = getenv("BENCH_SAMPLING");
         if(sm != NULL && strcmp(sm, "gray") == 0) jpeg_set_colorspace(&c, JCS_GRAYSCALE);
         else if(sm != NULL && strcmp(sm, "rgb") == 0) jpeg_set_colorspace(&c, JCS_RGB);
@@ -57,6 +57,14 @@ static unsigned char *make_jpeg(int w, int h, uint32_t seed, unsigned long *len)
         else if(sm != NULL && strcmp(sm, "440") == 0) c.comp_info[0].h_samp_factor = 1;
         else if(sm != NULL && strcmp(sm, "411") == 0) { c.comp_info[0].h_samp_factor = 4; c.comp_info[0].v_samp_factor = 1; }
         else if(sm != NULL && strcmp(sm, "410") == 0) { c.comp_info[0].h_samp_factor = 4; c.comp_info[0].v_samp_factor = 2; }
+        else if(sm != NULL && strchr(sm, 'x') != NULL) { /* "HxV,HxV,HxV": any sampling libjpeg compresses (at most 10 blocks per MCU) */
+            int hv[6], i;
+            if(sscanf(sm, "%dx%d,%dx%d,%dx%d", &hv[0], &hv[1], &hv[2], &hv[3], &hv[4], &hv[5]) != 6) return NULL;
+            for(i = 0; i < 3; i++) {
+                c.comp_info[i].h_samp_factor = hv[2 * i];
+                c.comp_info[i].v_samp_factor = hv[2 * i + 1];
+            }
+        }
     }
     { /* BENCH_QUALITY, BENCH_RESTART (MCUs per restart segment), BENCH_OPTIMIZE (per-image Huffman tables) */
         const char *q = getenv("BENCH_QUALITY"), *r = getenv("BENCH_RESTART"), *o = getenv("BENCH_OPTIMIZE");
