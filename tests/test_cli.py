@@ -53,6 +53,27 @@ def test_same_argv_same_bytes(cli, tmp_path, script):
     assert len(outs[0]) > 1000 and outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("sampling", ["1x4,1x1,1x1", "2x4,1x1,1x1", "3x1,1x1,1x1", "1x3,1x1,1x1", "3x2,1x1,1x1", "2x2,2x1,1x2", "4x1,1x4,1x1", "1x1,2x2,2x2"])
+def test_unusual_samplings_same_bytes(cli, tmp_path, sampling):
+    """targets whose components are subsampled 3:1 or 4:1, vertically too, or whose luma lies BELOW the chroma resolution: the overlay's
+    tiles are prepared on the device (libjpeg's box filters in front of its scaled transforms, mjx_tileprep.hip), composed, written:
+    the same bytes as the reference CLI, which prepares them through libjpeg (dropon.c:325-428)"""
+    src = tmp_path / "in.jpg"
+    env = dict(os.environ, BENCH_SAMPLING=sampling, BENCH_DUMP_INPUT=str(src), MJ_AMD="no-gpu-decode,no-gpu-encode")
+    subprocess.check_output([os.path.join(TOOLS, "bench_dropin"), os.path.join(HOST, "libmodjpeg.so.1"), "403", "299", "16", "16", "1"], env=env)
+    for script in (["-p", "cc", "-m", "5,-3", "-d", PNG, "-y", "12"], ["-p", "br", "-m", "-7,-9", "-d", JPG, "-b", "-8", "-O"]):
+        outs = []
+        for exe, name in ((REF_CLI, "ref.jpg"), (cli, "new.jpg")):
+            out = tmp_path / name
+            res = subprocess.run([exe, "-i", str(src)] + script + ["-o", str(out)], capture_output=True, text=True, env=dict(os.environ, MJ_AMD="debug-tiles"))
+            assert res.returncode == 0, (exe, res.stderr[-400:])
+            outs.append(out.read_bytes())
+            if exe == cli:  # the tile cache's trace says where the tiles were made
+                misses = [l for l in res.stderr.splitlines() if l.startswith("tilecache: miss")]
+                assert misses and all(", device," in l for l in misses), res.stderr[-600:]
+        assert len(outs[0]) > 1000 and outs[0] == outs[1], (sampling, script)
+
+
 def test_error_exit_codes(cli, tmp_path):
     for exe in (REF_CLI, cli):
         assert subprocess.run([exe, "-i", "/nonexistent.jpg"], capture_output=True).returncode == 1
