@@ -1344,7 +1344,10 @@ __global__ __launch_bounds__(256) void alpha_pattern_kernel(const Run *__restric
         }
         if(r == 0 && n < job.nblocks) {
             pattern[(size_t)(unsigned)job.nnz_off + n] = ((uint64_t)hi32 << 32) | lo32;
-            w00[(size_t)(unsigned)job.nnz_off + n] = tag ? kOpaqueTag : __float_as_uint(w);
+            // (kOpaqueTag is the bit pattern of a NaN: a block whose weight really is that NaN gets another one - any NaN weight gives
+            // the same coefficients, and the host must not take it for a tag)
+            const unsigned bits = __float_as_uint(w);
+            w00[(size_t)(unsigned)job.nnz_off + n] = tag ? kOpaqueTag : (bits == kOpaqueTag ? 0x7FC00000u : bits);
         }
     }
 }

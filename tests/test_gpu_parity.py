@@ -704,7 +704,7 @@ def test_opaque_blocks_are_written_from_their_tiles_alone(mj, seed, i16):
         coef = rng.integers(-1024, 1024, (prow, bpr, 64)).astype(np.int16)
         coef[rng.random((prow, bpr, 64)) < 0.01] = 32767
         coef[rng.random((prow, bpr, 64)) < 0.01] = -32768
-        kind = rng.choice(np.arange(8), n, p=[0.45, 0.1, 0.05, 0.05, 0.05, 0.1, 0.1, 0.1])  # 0 opaque, 1-4 near misses, 5 no weight, 6 single weight, 7 dense
+        kind = rng.choice(np.arange(8), n, p=[0.4, 0.1, 0.1, 0.05, 0.05, 0.1, 0.1, 0.1])  # 0 opaque, 1-4 near misses, 5 no weight, 6 single weight, 7 dense
         if i16:
             tile = rng.integers(-32768, 32768, (n, 64)).astype(np.int16)
             alpha = np.zeros((n, 64), np.int16)
@@ -727,6 +727,8 @@ def test_opaque_blocks_are_written_from_their_tiles_alone(mj, seed, i16):
             for k in np.flatnonzero(kind == 1):  # one value of the tile is not a whole number below 2^23
                 tile[k, at[k]] = miss[rng.integers(0, len(miss))]
             alpha[kind == 2, 0] = np.nextafter(np.float32(0.25), np.float32(rng.choice([0.0, 1.0])))
+            # (the NaN whose bit pattern is the scan's tag for an opaque block: a weight like any other NaN)
+            alpha[kind == 2, 0] = np.where(rng.random(int((kind == 2).sum())) < 0.5, np.array([0xFFFFFFFF], np.uint32).view(np.float32)[0], alpha[kind == 2, 0])
             alpha[kind == 3, 63] = 1e-41
             alpha[kind == 4, rng.integers(1, 64, int((kind == 4).sum()))] = np.float32("nan")
             alpha[kind == 6, 0] = (rng.random(int((kind == 6).sum())) * 0.3 + 0.01).astype(np.float32)
