@@ -79,9 +79,24 @@ struct DecChunk {
     int                flags;      // 1: first chunk of its segment, 2: last
 };
 
+// The passes after the synchronisation rounds are seven launches (block offsets: two for the prefix scan; the store pass; the DC
+// differences collected from the planes; their prefix scan: two; the DC values).  Round 5 built the fold VERDICT r04 asked for - the
+// store pass writes the differences itself (MJX_DEC_STORE_DIFF=1: no gather kernel), each scan is ONE launch whose last workgroup
+// makes the totals (MJX_DEC_FUSED_SCAN=1) - four launches, same coefficient arrays (the whole decoder suite passes in every
+// combination), and measured it on one box, alternating (profiles/r05/decoder_fold_halves.txt, 150 reads each): 1080p quality 85
+// 0.576-0.580 ms as it was, 0.577-0.585 / 0.581 / 0.584-0.585 with the first, the second, both; 4K 1.39 / 1.32-1.36 / 1.34-1.39 /
+// 1.40-1.45.  Three launches fewer are worth nothing a read can show: the chain is not what a read waits for (the
+// rounds, the pageable download).  Both stay off; the switches stay for the measurement.
+#ifndef MJX_DEC_STORE_DIFF
+#define MJX_DEC_STORE_DIFF 0
+#endif
+#ifndef MJX_DEC_FUSED_SCAN
+#define MJX_DEC_FUSED_SCAN 0
+#endif
 constexpr int kWaveSlots = 6; // wave-per-chunk walk: tables 0, 1 are the AC tables, 2..5 the DC tables
 constexpr int kMaxRounds = 192, kMoreRounds = 12;
-constexpr int kFlagInts = kMaxRounds + 2; // per image: [0] error, [1 + r] round r changed something
+constexpr int kFlagInts = kMaxRounds + 4; // per image: [0] error, [1 + r] round r changed something, [kScanTicket + which] workgroups of a prefix scan that are done
+constexpr int kScanTicket = kMaxRounds + 2;
 constexpr int kMaxBatch = 32;
 
 // one image of a batch, as the kernels see it (device copies live in the leader's arena)
@@ -159,7 +174,7 @@ __device__ __forceinline__ void stage_shared(unsigned *lds, const DecScan &S, co
 template <bool STORE>
 __device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack, unsigned long long acpack, unsigned long long base_bit, unsigned long long &p,
                                      unsigned long long p_end, int &slot, int wrap, int &k, unsigned &nblocks, long long &t, long long t_stop, int &err,
-                                     unsigned long long *sub_state = nullptr, unsigned *sub_nb = nullptr) {
+                                     unsigned long long *sub_state = nullptr, unsigned *sub_nb = nullptr, unsigned *diff = nullptr) {
     const unsigned *cw = L.words + threadIdx.x;
     // bit window: two consecutive words {hi, lo} of which the first `sh` (< 32) bits of hi are used
     // up, and the word after them fetched ahead; the next 32 bits of the stream are one funnel shift
@@ -214,6 +229,12 @@ __device__ __forceinline__ void walk(const DecLds &L, unsigned long long dcpack,
                 const int      at = k + kinc - 1; // DC: 0 (the difference; the DC pass integrates); AC: k + run
                 if(at > 63) err = 1;
                 else blk[kDecZigzag[at]] = (int16_t)value;
+                if(MJX_DEC_STORE_DIFF && k == 0) {
+                    // the difference also goes where the DC pass sums it up, the blocks of one component in the order of their MCUs
+                    // (MJX_DEC_STORE_DIFF: instead of the gather kernel; the array starts from zero like the planes)
+                    const DecComp &c = S.c[S.slot_comp[slot]];
+                    diff[c.jbase + ((long long)mcu_row * S.mcus_x + mcu_col) * c.nslots + (S.slot_y[slot] * c.hs + S.slot_x[slot])] = (unsigned)(int)(int16_t)value;
+                }
             }
         }
         rel += total;
@@ -575,7 +596,7 @@ __global__ __launch_bounds__(kDecThreads) void huffdec_store_kernel(const DecJob
     if(t < seg_t0 || t > t_stop || slot != (int)((t % S.bpm) % S.period) || p < mine.start) err = 1;
     slot = (int)(t % S.bpm);
     if(err == 0) {
-        if(p < mine.end) walk<true>(L, S.dcpack, S.acpack, (mine.start >> 5) << 5, p, mine.end, slot, S.bpm, k, nb, t, t_stop, err);
+        if(p < mine.end) walk<true>(L, S.dcpack, S.acpack, (mine.start >> 5) << 5, p, mine.end, slot, S.bpm, k, nb, t, t_stop, err, nullptr, nullptr, J.diff);
         if((ck.flags & 2) && mine.end == ck.end) { // the lane that reaches the end of the segment
             if(t != t_stop || k != 0 || p > ck.end) err = 1; // segment ended inside a block / blocks missing
         }
@@ -586,13 +607,13 @@ __global__ __launch_bounds__(kDecThreads) void huffdec_store_kernel(const DecJob
 // ---- the planes start from zero (a block's coefficients after its last symbol are never written).  hipMemsetAsync drops
 // to ~8 GB/s somewhere between 17 and 66 MB (measured on the 8K planes: 12.6 ms for 100 MB), a plain store loop does not.
 struct ZeroPlanes {
-    uint4 *p[5]; // the planes, and the image's counters (totals) when it is being staged
-    size_t n16[5]; // 16-byte units (plane sizes are multiples of 128 bytes)
+    uint4 *p[6]; // the planes, the image's counters (totals) when it is being staged, and the array of its DC differences
+    size_t n16[6]; // 16-byte units (plane sizes are multiples of 128 bytes)
 };
 __global__ __launch_bounds__(256) void huffdec_zero_kernel(ZeroPlanes z) {
     const uint4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for(int c = 0; c < 5; ++c)
+    for(int c = 0; c < 6; ++c)
         for(size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < z.n16[c]; q += (size_t)gridDim.x * 256) z.p[c][q] = zero;
 }
 
@@ -608,6 +629,28 @@ __global__ __launch_bounds__(kScanThreads) void huffdec_scan_totals_kernel(const
     const DecJob &J = jobs[blockIdx.y];
     if(which == 0) scan_totals_body(J.ctot, J.chunk_groups, J.totals + 0);
     else scan_totals_body(J.dtot, J.dc_groups, J.totals + 1);
+}
+
+// (MJX_DEC_FUSED_SCAN) One launch per scan: every workgroup scans its group, and the one that finishes LAST - it takes the last
+// ticket of the image's counter - turns the group totals into prefixes.  Every wave makes its stores visible to the device before its
+// workgroup takes a ticket (agent-scope fence: the XCDs' L2s are not coherent among themselves), the last workgroup fences again
+// before it reads the totals, and leaves the counter at zero for the next scan of the image (a batch that goes round again).
+__global__ __launch_bounds__(kScanThreads) void huffdec_scan_kernel(const DecJob *__restrict__ jobs, int which) {
+    const DecJob &J = jobs[blockIdx.y];
+    const int     ngroups = which == 0 ? J.chunk_groups : J.dc_groups;
+    if((int)blockIdx.x >= ngroups) return;
+    if(which == 0) scan_groups_body(J.nblk, J.cpre, J.ctot, J.nchunks, blockIdx.x);
+    else scan_groups_body(J.diff, J.dpre, J.dtot, J.ndc, blockIdx.x);
+    __shared__ int last;
+    __threadfence();
+    __syncthreads();
+    if(threadIdx.x == 0) last = __hip_atomic_fetch_add(&J.flags[kScanTicket + which], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1;
+    __syncthreads();
+    if(!last) return; // (workgroup-uniform)
+    __threadfence();
+    if(which == 0) scan_totals_body(J.ctot, ngroups, J.totals + 0);
+    else scan_totals_body(J.dtot, ngroups, J.totals + 1);
+    if(threadIdx.x == 0) __hip_atomic_store(&J.flags[kScanTicket + which], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- DC integration ---------------------------------------------------------------------
@@ -931,6 +974,7 @@ struct Request {
     size_t   lds_bytes;
     char    *plane_ptr[4]; // device
     size_t   plane_len[4];
+    size_t   diff_bytes;   // of job.diff, which starts from zero like the planes
     unsigned chunk_wgs, dc_wgs;
     int      first_rounds; // rounds queued before the flags are first looked at
     size_t   o_batch, pin_batch; // where a leader keeps the batch's descriptors and flags in this request's arena
@@ -955,13 +999,16 @@ int max_leaders() {
     return n;
 }
 
-bool zero_planes(char *const *ptr, const size_t *len, int ncomp, hipStream_t s, void *totals = nullptr) {
+bool zero_planes(char *const *ptr, const size_t *len, int ncomp, hipStream_t s, void *diff, size_t diff_bytes, void *totals = nullptr) {
     ZeroPlanes z = {};
     size_t     most = 0;
+    z.p[5] = reinterpret_cast<uint4 *>(diff); // (256-byte aligned, a multiple of 256 bytes long)
+    z.n16[5] = diff_bytes / 16;
+    most = z.n16[5];
     if(totals != nullptr) { // 256 bytes, 256-byte aligned
         z.p[4] = reinterpret_cast<uint4 *>(totals);
         z.n16[4] = 16;
-        most = 16;
+        most = most > 16 ? most : 16;
     }
     for(int c = 0; c < ncomp; ++c) {
         if((reinterpret_cast<uintptr_t>(ptr[c]) & 15u) != 0 || (len[c] & 15u) != 0) { // a caller's plane at an odd address: the library call
@@ -1076,12 +1123,22 @@ void run_batch(Request *lead, Request **batch, int n) {
             else hipLaunchKernelGGL(huffdec_sync_kernel, dim3(cbx, m), dim3(kDecThreads), lds, s, d_jobs, round);
         }
         // 2.-4. block offsets, coefficients, DC values (wasted for an image whose rounds had not settled: rare)
+#if MJX_DEC_FUSED_SCAN
+        hipLaunchKernelGGL(huffdec_scan_kernel, dim3(gcx, m), dim3(kScanThreads), 0, s, d_jobs, 0);
+#else
         hipLaunchKernelGGL(huffdec_scan_groups_kernel, dim3(gcx, m), dim3(kScanThreads), 0, s, d_jobs, 0);
         hipLaunchKernelGGL(huffdec_scan_totals_kernel, dim3(1, m), dim3(kScanThreads), 0, s, d_jobs, 0);
+#endif
         hipLaunchKernelGGL(huffdec_store_kernel, dim3((most_chunks * (unsigned)per + kDecThreads - 1) / kDecThreads, m), dim3(kDecThreads), lds, s, d_jobs);
+#if !MJX_DEC_STORE_DIFF
         hipLaunchKernelGGL(huffdec_dc_gather_kernel, dim3(dbx, m), dim3(256), 0, s, d_jobs);
+#endif
+#if MJX_DEC_FUSED_SCAN
+        hipLaunchKernelGGL(huffdec_scan_kernel, dim3(gdx, m), dim3(kScanThreads), 0, s, d_jobs, 1);
+#else
         hipLaunchKernelGGL(huffdec_scan_groups_kernel, dim3(gdx, m), dim3(kScanThreads), 0, s, d_jobs, 1);
         hipLaunchKernelGGL(huffdec_scan_totals_kernel, dim3(1, m), dim3(kScanThreads), 0, s, d_jobs, 1);
+#endif
         hipLaunchKernelGGL(huffdec_dc_finish_kernel, dim3(dbx, m), dim3(256), 0, s, d_jobs);
         if(hipGetLastError() != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
         if(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * (size_t)kFlagInts * (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
@@ -1107,7 +1164,7 @@ void run_batch(Request *lead, Request **batch, int n) {
                 r->result = MJX_ERR_BAD_ARG; // does not settle: leave it to the sequential decoder
             }
             else { // the store pass ran on unsettled states: wipe what it wrote and go round again
-                if(!zero_planes(r->plane_ptr, r->plane_len, r->job.S.ncomp, s)) return fail_all(MJX_ERR_LAUNCH);
+                if(!zero_planes(r->plane_ptr, r->plane_len, r->job.S.ncomp, s, r->job.diff, r->diff_bytes)) return fail_all(MJX_ERR_LAUNCH);
                 if(hipMemsetAsync(r->job.flags, 0, sizeof(int), s) != hipSuccess) return fail_all(MJX_ERR_LAUNCH);
                 pending[keep++] = pending[k];
             }
@@ -1355,7 +1412,8 @@ extern "C" int mjx_huff_decode_host(const mjx_huff_dscan_t *scan) {
             }
             req.plane_len[c] = plane_bytes[c];
         }
-        if(!zero_planes(req.plane_ptr, req.plane_len, S.ncomp, s, base + o_totals)) return MJX_ERR_LAUNCH;
+        req.diff_bytes = up256((size_t)ndc * 4);
+        if(!zero_planes(req.plane_ptr, req.plane_len, S.ncomp, s, base + o_diff, req.diff_bytes, base + o_totals)) return MJX_ERR_LAUNCH;
     }
     MJX_HIP(hipEventRecord(arena->staged, s), MJX_ERR_LAUNCH);
     DecJob &J = req.job;
