@@ -89,13 +89,16 @@ def parse(argv=None):
     ap.add_argument("--no-low-column-build", action="store_true", help="compose: MJX_PLAN_NO_LOW_COLUMN_BUILD (smooth runs take the general build of the blend kernel)")
     ap.add_argument("--keep-zero-alpha", action="store_true",
                     help="compose: blocks without any weight still stream their tile and alpha blocks (no MJX_PLAN_ALPHA_IS_FINAL)")
+    ap.add_argument("--shared-dropon", action="store_true",
+                    help="compose: ONE set of tiles for every image of the batch (the reference's own use: one overlay, many images; SURVEY 8d's secondary variant - "
+                         "256 B of JCOEF per block cross HBM, the tiles are read from cache)")
     ap.add_argument("--tiles-not-final", action="store_true",
                     help="compose: no MJX_PLAN_TILES_ARE_FINAL - opaque blocks of float tiles (single weight 0.25, whole-number tile) read the image's block like the other "
                          "single-weight blocks")
     ap.add_argument("--also", default="auto", choices=["auto", "none"],
                     help="auto (default): the headline run (default workload, regime, tiles and launch on one GPU) also measures, inside the same JSON line, what "
                          "making its plan costs (`plan_ms`), the same launch planned WITHOUT the promise that alpha is final (`roofline.frac_without_promise`) and, "
-                         "under `also`, the other regimes of the same batch (A5 real mask, A4 mixed, A3 dense, A1 opaque), the 4K full-frame config and the effects batch, each "
+                         "under `also`, the other regimes of the same batch (A5 real mask, A4 mixed, A3 dense, A1 opaque; A2 and A5 with ONE overlay shared by every image), the 4K full-frame config and the effects batch, each "
                          "with its step time, its parity verdict and its fraction of the HBM peak on the bytes its plan moves; none: the headline only")
     ap.add_argument("--also-steps", type=int, default=20, help="timed steps of every `also` measurement (effects: a quarter of it)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
@@ -429,7 +432,7 @@ def traffic_scaled(path, key_prefix, blocks):
     return None, None
 
 
-def plan_launch_bytes(plan_stats, blocks, tiles_i16):
+def plan_launch_bytes(plan_stats, blocks, tiles_i16, shared_dropon=False):
     """Bytes one launch of a plan asks the memory system for (the counters agree: profiles/traffic.json).
     SURVEY 8d prices a composed block at 768 B (512 with int16 tiles); a plan made with the promise that alpha is final moves
     less for four kinds of block: no weight at all -> the JCOEF block in + its table entry, written back only if it changed
@@ -438,6 +441,9 @@ def plan_launch_bytes(plan_stats, blocks, tiles_i16):
     (eight first lines and one second line per octet in the low-column build: 656 B per block; two in the general and lean
     builds: 672 B); an opaque block (MJX_PLAN_TILES_ARE_FINAL: that weight is 0.25 and the tile holds whole numbers) -> the tile
     block in, a table entry, JCOEF out (388 B, 260 with int16 tiles)."""
+    if shared_dropon:  # one tile set for the whole batch (a megabyte, read from cache): what crosses HBM is JCOEF in and out, and the tables
+        special_dc, special_zero, special_opq = 8 * plan_stats["dc_only_octets"], 8 * plan_stats["zero_alpha_octets"], 8 * plan_stats.get("opaque_octets", 0)
+        return (blocks - special_dc - special_zero - special_opq) * 256 + special_dc * (256 + 8) + special_zero * 132 + special_opq * 132
     per_block = 512 if tiles_i16 else BYTES_PER_BLOCK
     special_dc, special_zero = 8 * plan_stats["dc_only_octets"], 8 * plan_stats["zero_alpha_octets"]
     dc_bytes = 128 + (128 if tiles_i16 else 256) + 8 + 128
@@ -462,7 +468,7 @@ def also_compose(batch, batch_cfg, regime_name, steps, nsample, alpha_is_final=T
     batch.fill_synthetic()
     batch.build_plan(alpha_is_final=alpha_is_final, tiles_are_final=tiles_are_final)
     st = batch.plan_stats()
-    tiles = [batch.tiles_as_float(0, c) for c in range(3)] if regime == 5 else None
+    tiles = [batch.tiles_as_float(0, c) for c in range(3)] if regime == 5 or batch.shared_dropon else None
     _, expected = cpu_baseline_and_expected(batch_cfg, regime, nsample, batch.image0, timing=False, tiles=tiles)
     batch.run()
     torch.cuda.synchronize()
@@ -476,8 +482,8 @@ def also_compose(batch, batch_cfg, regime_name, steps, nsample, alpha_is_final=T
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / steps
     blocks = batch.total_blocks()
-    moved = plan_launch_bytes(st, blocks, False)
-    return {"alpha_regime": regime_name, "images": batch.n, "blocks_per_step": blocks, "steps": steps, "ms_per_step": ms, "blocks_per_s": blocks / (ms * 1e-3),
+    moved = plan_launch_bytes(st, blocks, False, batch.shared_dropon)
+    return {"alpha_regime": regime_name, "shared_dropon": batch.shared_dropon, "images": batch.n, "blocks_per_step": blocks, "steps": steps, "ms_per_step": ms, "blocks_per_s": blocks / (ms * 1e-3),
             "parity": "bit-exact" if bad == 0 else f"MISMATCH in {bad} of {3 * nsample} rectangles", "parity_sample_images": nsample,
             "alpha_is_final": alpha_is_final, "bytes_moved_per_block": moved / blocks, "achieved_on_bytes_moved": moved / (ms * 1e-3) / 1e9,
             "frac_on_bytes_moved": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_at_nominal_bytes_per_block": blocks * BYTES_PER_BLOCK / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -560,7 +566,7 @@ def bench_compose(args, rank, world):
     regime = REGIMES[args.regime]
     image0, images = shard_of(total_images, rank, world, args.scaling)
     assert images > 0, f"rank {rank}: empty shard ({total_images} images over {world} ranks)"
-    batch = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, regime, image0=image0, tiles_i16=(args.tiles == "i16"))
+    batch = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, regime, image0=image0, tiles_i16=(args.tiles == "i16"), shared_dropon=args.shared_dropon)
     bytes_per_block = 512 if args.tiles == "i16" else BYTES_PER_BLOCK  # int16 tiles: 128 + 128 + 128 read, 128 written
     batch.fill_synthetic()
     batch.build_plan(group_by_density=not args.no_group, alpha_is_final=not args.keep_zero_alpha, side_by_side={"auto": None, "serial": False, "side-by-side": True}[args.launch],
@@ -583,7 +589,7 @@ def bench_compose(args, rank, world):
     if nsample > 0:
         # the sample: the first images of this rank's shard
         tiles = None
-        if regime == 5:  # the oracle gets the device-prepared tiles as its input (their own parity: tests/test_dropin_shim.py)
+        if regime == 5 or args.shared_dropon:  # the oracle gets the device-prepared tiles as its input (their own parity: tests/test_dropin_shim.py)
             tiles = [batch.tiles_as_float(0, c) for c in range(3)]
         info, expected = cpu_baseline_and_expected((width, height, dw, dh, mcu_x, mcu_y), regime, nsample, image0, timing=(world == 1), tiles=tiles)
         cpu_info = info if world == 1 else None
@@ -635,15 +641,15 @@ def bench_compose(args, rank, world):
         # with the promise that alpha is final moves less for two kinds of block: no weight at all -> the
         # JCOEF block in + its table entry; the single weight (0,0) -> JCOEF in and out, the tile block and
         # a table entry with the weight (520 B, 392 with int16 tiles).  The headline regime A2 has neither kind.
-        launch_bytes = plan_launch_bytes(plan_stats, blocks_per_step, args.tiles == "i16")
+        launch_bytes = plan_launch_bytes(plan_stats, blocks_per_step, args.tiles == "i16", args.shared_dropon)
         achieved = launch_bytes / (mean_kern_ms * 1e-3) / 1e9
         achieved_nominal = blocks_per_step * bytes_per_block / (mean_kern_ms * 1e-3) / 1e9
         moved_bytes, achieved_moved = launch_bytes, achieved  # (the same figures under the names the round-4 profiles use)
         # every rank's own launch against the peak of its own GPU: the figures above describe rank 0's shard
         rank_gbs = [r["blocks_per_step"] * (launch_bytes / blocks_per_step) / (r["kernel_ms_mean"] * 1e-3) / 1e9 for r in per_rank]
         key = f"{args.workload}:{args.regime}:"
-        traffic, traffic_src = traffic_from_profiles(args.traffic_json, f"{args.workload}:{args.regime}:{images}" + (":i16" if args.tiles == "i16" else ""))
-        if traffic is None and args.tiles == "f32":
+        traffic, traffic_src = traffic_from_profiles(args.traffic_json, f"{args.workload}:{args.regime}:{images}" + (":i16" if args.tiles == "i16" else "") + (":shared_dropon" if args.shared_dropon else ""))
+        if traffic is None and args.tiles == "f32" and not args.shared_dropon:
             traffic, traffic_src = traffic_scaled(args.traffic_json, key, blocks_per_step)
         verdicts = {r["parity"] for r in per_rank}
         out = {
@@ -655,7 +661,7 @@ def bench_compose(args, rank, world):
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "s16 JCOEF, f32/f64 blend (reference typing)", "data": "synthetic",
             "config": {"workload": args.workload, "images_total": tot_blocks // batch.blocks_per_image, "images_per_gpu": images, "image": f"{width}x{height} 4:2:0",
-                       "dropon": f"{dw}x{dh} alpha-masked, per-image tiles, MCU ({mcu_x},{mcu_y})",
+                       "dropon": f"{dw}x{dh} alpha-masked, " + ("ONE tile set shared by every image (read from cache)" if args.shared_dropon else "per-image tiles") + f", MCU ({mcu_x},{mcu_y})",
                        "alpha_regime": args.regime, "tiles": "float (768 B per block)" if args.tiles == "f32" else "int16 coefficients, converted in the kernel (512 B per block)",
                        "density_grouping": (not args.no_group), "gather_octets_per_gpu": int(batch.gather_octets), "plan": plan_stats,
                        "launch": ("side by side: %d light runs streamed beside the lean blend kernel, the rest after it" % plan_stats["runs_beside"]) if plan_stats.get("runs_beside") else "one kernel after the other",
@@ -686,7 +692,7 @@ def bench_compose(args, rank, world):
                               "its results coming down, the host's schedule (patterns -> octets -> runs), tables going up; once per plan, not inside the timed region; "
                               "in steps of the headline launch: %.1f" % (plan_stats["build_ms"]["total"] / mean_kern_ms))
         headline = (args.workload == "compose_1080p_batch" and args.regime == "A2" and args.tiles == "f32" and args.launch == "auto" and not args.no_group
-                    and not args.keep_zero_alpha and not args.images and world == 1 and not (args.beside_share or args.run_octets or args.stream_run_octets or args.no_low_column_build))
+                    and not args.keep_zero_alpha and not args.images and world == 1 and not (args.beside_share or args.run_octets or args.stream_run_octets or args.no_low_column_build or args.shared_dropon or args.tiles_not_final or args.tail_min_octets))
         if args.also == "auto" and headline:
             cfg = (width, height, dw, dh, mcu_x, mcu_y)
             t_also = time.perf_counter()
@@ -697,6 +703,11 @@ def bench_compose(args, rank, world):
             out["roofline"]["without_promise"] = wp
             also = {"compose_1080p_batch:" + r: also_compose(batch, cfg, r, args.also_steps, 8) for r in ("A5", "A4", "A3", "A1")}
             del batch
+            # SURVEY 8d's secondary variant, and what the reference's callers do: ONE overlay for the whole batch (smooth mask; the real disc mask)
+            sb = ComposeBatch(images, width, height, dw, dh, mcu_x, mcu_y, REGIMES["A2"], image0=image0, shared_dropon=True)
+            for r in ("A2", "A5"):
+                also["compose_1080p_batch:%s:shared_dropon" % r] = also_compose(sb, cfg, r, args.also_steps, 8)
+            del sb
             if pristine is not None:
                 del pristine
             torch.cuda.empty_cache()

@@ -78,11 +78,15 @@ class ComposeBatch:
     """`n` images (global indices image0 .. image0+n-1) of one geometry, one dropon rectangle per
     image at MCU (mcu_x, mcu_y) of dropon_w x dropon_h pixels (multiples of 16), per-image tiles."""
 
-    def __init__(self, n, width, height, dropon_w, dropon_h, mcu_x, mcu_y, regime, image0=0, quality=85, device=None, tiles_i16=False):
+    def __init__(self, n, width, height, dropon_w, dropon_h, mcu_x, mcu_y, regime, image0=0, quality=85, device=None, tiles_i16=False, shared_dropon=False):
         """tiles_i16: the prepared tiles are kept as the int16 coefficients they are made from
-        (MJX_JOB_TILES_I16: 512 instead of 768 bytes per block, the kernel converts) instead of floats"""
+        (MJX_JOB_TILES_I16: 512 instead of 768 bytes per block, the kernel converts) instead of floats.
+        shared_dropon: ONE set of tiles (those of image `image0`) for every image of the batch - the reference's own use, one overlay
+        composed onto many images (secondary variant: 256 B of JCOEF per block cross HBM, the tiles stay in cache)"""
         assert dropon_w % 16 == 0 and dropon_h % 16 == 0
         self.n, self.image0, self.regime, self.tiles_i16 = n, image0, regime, bool(tiles_i16)
+        self.shared_dropon = bool(shared_dropon)
+        nt = 1 if self.shared_dropon else n  # tile sets
         self.geo = Geometry420(width, height)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.quant = [quant_table(False, quality), quant_table(True, quality), quant_table(True, quality)]
@@ -94,8 +98,8 @@ class ComposeBatch:
             assert row0 + rows <= prow and col0 + cols <= bpr, "dropon rectangle outside the image"
         self.coef = [torch.empty((n, prow, bpr, 64), dtype=torch.int16, device=self.device) for bpr, prow in self.geo.array_dims]
         tdt = torch.int16 if self.tiles_i16 else torch.float32
-        self.tile = [torch.empty((n, rows * cols, 64), dtype=tdt, device=self.device) for (_, _, rows, cols) in self.rect]
-        self.alpha = [torch.empty((n, rows * cols, 64), dtype=tdt, device=self.device) for (_, _, rows, cols) in self.rect]
+        self.tile = [torch.empty((nt, rows * cols, 64), dtype=tdt, device=self.device) for (_, _, rows, cols) in self.rect]
+        self.alpha = [torch.empty((nt, rows * cols, 64), dtype=tdt, device=self.device) for (_, _, rows, cols) in self.rect]
         self.plan = ctypes.c_void_p()
         self.blocks_per_image = sum(r[2] * r[3] for r in self.rect)
 
@@ -110,13 +114,14 @@ class ComposeBatch:
             pblocks = bpr * prow
             tblocks = self.rect[c][2] * self.rect[c][3]
             qp = self.quant[c].ctypes.data_as(vp)
+            nt = self.tile[c].shape[0]  # tile sets: one per image, or one for all (shared_dropon)
             check(L.mjx_synth_coef_batch(vp(self.coef[c].data_ptr()), pblocks, self.image0, self.n, c, 0, pblocks, qp, s), "mjx_synth_coef_batch")
             if self.regime != REGIME_DISC and self.tiles_i16:
-                check(L.mjx_synth_tiles_i16_batch(vp(self.tile[c].data_ptr()), 0, tblocks, self.image0, self.n, c, 0, tblocks, 0, s), "mjx_synth_tiles_i16_batch")
-                check(L.mjx_synth_tiles_i16_batch(vp(self.alpha[c].data_ptr()), 1, tblocks, self.image0, self.n, c, 0, tblocks, self.regime, s), "mjx_synth_tiles_i16_batch")
+                check(L.mjx_synth_tiles_i16_batch(vp(self.tile[c].data_ptr()), 0, tblocks, self.image0, nt, c, 0, tblocks, 0, s), "mjx_synth_tiles_i16_batch")
+                check(L.mjx_synth_tiles_i16_batch(vp(self.alpha[c].data_ptr()), 1, tblocks, self.image0, nt, c, 0, tblocks, self.regime, s), "mjx_synth_tiles_i16_batch")
             elif self.regime != REGIME_DISC:
-                check(L.mjx_synth_tile_batch(vp(self.tile[c].data_ptr()), tblocks, self.image0, self.n, c, 0, tblocks, s), "mjx_synth_tile_batch")
-                check(L.mjx_synth_alpha_batch(vp(self.alpha[c].data_ptr()), tblocks, self.image0, self.n, c, 0, tblocks, self.regime, s), "mjx_synth_alpha_batch")
+                check(L.mjx_synth_tile_batch(vp(self.tile[c].data_ptr()), tblocks, self.image0, nt, c, 0, tblocks, s), "mjx_synth_tile_batch")
+                check(L.mjx_synth_alpha_batch(vp(self.alpha[c].data_ptr()), tblocks, self.image0, nt, c, 0, tblocks, self.regime, s), "mjx_synth_alpha_batch")
         if self.regime == REGIME_DISC:
             self._fill_disc_tiles()
         torch.cuda.current_stream().synchronize()
@@ -162,7 +167,8 @@ class ComposeBatch:
             for c in range(3):
                 bpr, prow = self.geo.array_dims[c]
                 row0, col0, rows, cols = self.rect[c]
-                jobs[j] = RectJob(self.coef[c][i].data_ptr(), self.tile[c][i].data_ptr(), self.alpha[c][i].data_ptr(),
+                ti = 0 if self.shared_dropon else i
+                jobs[j] = RectJob(self.coef[c][i].data_ptr(), self.tile[c][ti].data_ptr(), self.alpha[c][ti].data_ptr(),
                                   bpr, prow, row0, col0, rows, cols, c, MJX_JOB_TILES_I16 if self.tiles_i16 else 0)
                 j += 1
         qt = np.ascontiguousarray(np.stack(self.quant))
@@ -209,6 +215,7 @@ class ComposeBatch:
         """(tile, alpha) of image i, component c as the float arrays the reference's mj_compileddropon_t
         would hold (for the oracle): the arrays themselves, or converted from the int16 form exactly as the
         reference converts its JCOEFs (dropon.c:476-485, :548-566)"""
+        i = 0 if self.shared_dropon else i
         t, a = self.tile[c][i].cpu().numpy().reshape(-1), self.alpha[c][i].cpu().numpy().reshape(-1)
         if not self.tiles_i16:
             return np.ascontiguousarray(t), np.ascontiguousarray(a)

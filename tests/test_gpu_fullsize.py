@@ -227,6 +227,36 @@ def test_real_mask_regime_a5(torch_mod):
             assert np.array_equal(out[0][c][i].cpu().numpy().reshape(-1), want), (i, c)
 
 
+@pytest.mark.parametrize("regime,i16", [(2, False), (5, False), (4, True)])
+def test_one_overlay_shared_by_every_image(torch_mod, regime, i16):
+    """SURVEY 8d's secondary variant and the reference's own use (one dropon, many images: compose.c:155-177): every rectangle of
+    the plan points at the SAME tile arrays.  Smooth masks, the real disc mask (opaque blocks written from the shared tile, rim
+    blocks gathered from it), the mixed regime with int16 tiles; == the oracle fed with that one tile set, image by image"""
+    torch = torch_mod
+    from libmodjpeg_amd.batch import ComposeBatch
+    n = 96
+    b = ComposeBatch(n, 1920, 1080, 256, 256, 52, 26, regime, tiles_i16=i16, shared_dropon=True)
+    b.fill_synthetic()
+    assert b.tile[0].shape[0] == 1
+    b.build_plan()
+    st = b.plan_stats()
+    if regime != 2:
+        assert st["opaque_octets"] > 0 and st["zero_alpha_octets"] > 0
+    b.run()
+    torch.cuda.synchronize()
+    tiles = [b.tiles_as_float(0, c) for c in range(3)]
+    for i in (0, 1, n // 2, n - 1):
+        for c in range(3):
+            bpr, _ = b.geo.array_dims[c]
+            row0, col0, rows, cols = b.rect[c]
+            want = np.empty((rows, cols * 64), np.int16)
+            for l in range(rows):
+                want[l] = O.synth_coef(i, c, (row0 + l) * bpr + col0, cols, b.quant[c])
+            want = want.reshape(-1)
+            O.compose_rect(want, cols, 0, 0, rows, cols, b.quant[c], tiles[c][0], tiles[c][1])
+            assert np.array_equal(b.rect_numpy(i, c).reshape(-1), want), (i, c)
+
+
 def test_4k_fullframe_vs_oracle(torch_mod):
     """BASELINE configs[1]: one 3840x2160 4:2:0 image, full-frame alpha-masked dropon (194 400 blocks)"""
     torch = torch_mod
