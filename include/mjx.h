@@ -281,7 +281,8 @@ int64_t mjx_tile_schedule_gather_octets(const mjx_tile_schedule_t *sched);
 int     mjx_tile_schedule_stats(const mjx_tile_schedule_t *sched, mjx_plan_stats_t *out);
 /* The host-buffer calls borrow a staging arena (grow-only device buffer, pinned descriptor buffer,
  * stream) from a small process-wide pool, so that a steady stream of per-image calls from any
- * number of threads allocates nothing.  mjx_release_thread_cache() frees the idle arenas. */
+ * number of threads allocates nothing.  mjx_release_thread_cache() frees the idle arenas (and the spare host buffers the
+ * plan builder keeps between plans: at most 160 MB). */
 int mjx_release_thread_cache(void);
 /* pinned (page-locked) host memory: plane rows gathered into it upload at full PCIe rate */
 int mjx_malloc_host(void **host, size_t bytes);

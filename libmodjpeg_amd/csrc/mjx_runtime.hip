@@ -14,6 +14,7 @@
 #include <atomic>
 #include <chrono>
 #include <new>
+#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
@@ -130,15 +131,82 @@ using namespace mjx;
 // ------------------------------------------------------------------------------------------
 namespace {
 // storage that is filled by a copy from the device: not zeroed first (a vector's resize would pass over tens of megabytes twice)
+// One spare block of this storage is kept between plans (at most kSpareBytes; mjx_release_thread_cache() frees it): the 75 MB a
+// plan of the headline batch brings down cost 4 ms of first-touch page faults and 5-6 ms of unmapping every time (round 5,
+// MJX_PLAN_DEBUG laps: more than the scan, the schedule and the uploads together).
+constexpr size_t kSpareBytes = (size_t)160 << 20;
+pthread_mutex_t  g_spare_lock = PTHREAD_MUTEX_INITIALIZER;
+void            *g_spare[2] = {nullptr, nullptr};
+size_t           g_spare_bytes[2] = {0, 0};
+inline void *spare_take(size_t bytes, size_t *got) {
+    void *q = nullptr;
+    pthread_mutex_lock(&g_spare_lock);
+    int at = -1; // the smaller of the blocks that are large enough
+    for(int i = 0; i < 2; ++i)
+        if(g_spare[i] != nullptr && g_spare_bytes[i] >= bytes && (at < 0 || g_spare_bytes[i] < g_spare_bytes[at])) at = i;
+    if(at >= 0) {
+        q = g_spare[at];
+        *got = g_spare_bytes[at];
+        g_spare[at] = nullptr;
+        g_spare_bytes[at] = 0;
+    }
+    pthread_mutex_unlock(&g_spare_lock);
+    return q;
+}
+inline void spare_give(void *q, size_t bytes) { // keeps it, or frees it (and a smaller one it replaces)
+    void *drop = q;
+    if(q != nullptr && bytes <= kSpareBytes) {
+        pthread_mutex_lock(&g_spare_lock);
+        int at = g_spare[0] == nullptr ? 0 : (g_spare[1] == nullptr ? 1 : (g_spare_bytes[0] <= g_spare_bytes[1] ? 0 : 1));
+        if(g_spare[at] == nullptr || g_spare_bytes[at] < bytes) {
+            drop = g_spare[at];
+            g_spare[at] = q;
+            g_spare_bytes[at] = bytes;
+        }
+        pthread_mutex_unlock(&g_spare_lock);
+    }
+    free(drop);
+}
+inline void spare_release() {
+    pthread_mutex_lock(&g_spare_lock);
+    for(int i = 0; i < 2; ++i) {
+        free(g_spare[i]);
+        g_spare[i] = nullptr;
+        g_spare_bytes[i] = 0;
+    }
+    pthread_mutex_unlock(&g_spare_lock);
+}
 template <class T> struct RawBuf {
-    T *p = nullptr;
-    ~RawBuf() { free(p); }
+    T     *p = nullptr;
+    size_t cap = 0; // bytes
+    ~RawBuf() { spare_give(p, cap); }
     RawBuf() = default;
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
     bool     resize(size_t n) {
-        free(p);
-        p = static_cast<T *>(malloc((n ? n : 1) * sizeof(T)));
+        spare_give(p, cap);
+        p = nullptr;
+        cap = 0;
+        const size_t bytes = (n ? n : 1) * sizeof(T);
+        if(void *q = spare_take(bytes, &cap)) {
+            p = static_cast<T *>(q);
+            return true;
+        }
+        cap = bytes;
+        // tens of megabytes that are written once (by the copy) and read once: on 4 KiB pages the first touch and the unmapping
+        // were 10 of the 15 ms a plan of the headline batch takes (18 000 page faults each way); huge pages where the kernel grants them
+        constexpr size_t kHuge = (size_t)2 << 20;
+        if(bytes >= 4 * kHuge) {
+            void *q = nullptr;
+            if(posix_memalign(&q, kHuge, (bytes + kHuge - 1) & ~(kHuge - 1)) == 0) {
+                (void)madvise(q, (bytes + kHuge - 1) & ~(kHuge - 1), MADV_HUGEPAGE);
+                p = static_cast<T *>(q);
+                cap = (bytes + kHuge - 1) & ~(kHuge - 1);
+                return true;
+            }
+        }
+        p = static_cast<T *>(malloc(bytes));
+        if(p == nullptr) cap = 0;
         return p != nullptr;
     }
     T       *data() { return p; }
@@ -356,7 +424,7 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     // what the blocks cost as they lie
     bool     all_same = true;
     int      nzero = 0, ndc = 0, nopq = 0; // (nopq: DC-only blocks the scan tagged as opaque: w00 == kOpaqueTag)
-    float    cost_cons = 0.0f;
+    float    cost_cons = 0.0f, cost_floor = 0.0f; // (cost_floor: no octet costs less than the mean of its blocks' own patterns)
     int64_t  terms = 0, union_cons = 0;
     uint64_t union_all = 0;
     for(int o = 0; o < noct_all; ++o) {
@@ -369,6 +437,7 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
             ndc += p == 1;
             nopq += p == 1 && w00 != nullptr && w00[o * kWaveBlocks + k] == kOpaqueTag;
             terms += __builtin_popcountll(p);
+            cost_floor += octet_cost(p);
         }
         cost_cons += octet_cost(u);
         union_cons += __builtin_popcountll(u);
@@ -394,6 +463,10 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     // named by the table; =2 also shuffles them, so that an octet's blocks lie anywhere in the rectangle)
     static const int exp_gather = tuning_env("MJX_EXP_GATHER") ? atoi(tuning_env("MJX_EXP_GATHER")) : 0;
     if(!exp_gather && all_same && !(split_zero && pattern[0] == 0) && !((split_dc || split_opq) && pattern[0] == 1)) return consecutive();
+    // The same verdict as the comparison of the sorted order's cost below, without the sort: an octet costs what the UNION of its
+    // blocks' patterns costs, which is at least the mean of what the blocks cost alone, so no order is cheaper than cost_floor / 8.
+    // (The headline batch: blocks that all have the smooth pattern or a subset of it - 16 of the 33 ms a plan took went here.)
+    if(!exp_gather && !split_zero && !split_dc && !split_opq && cost_floor / (float)kWaveBlocks > 0.93f * cost_cons) return consecutive();
 
     // sorted order: densest first; among blocks of similar density those that use the same rows and
     // columns of weights lie together, then equal patterns.  Real masks have few DISTINCT patterns (an
@@ -1081,9 +1154,11 @@ int mjx_compose_plan_create_opts(mjx_compose_plan_t **plan, const mjx_rect_job_t
             plain_runs(t);
             lap("plain_runs");
         }
+        lap("the scan's buffers freed");
         // side by side, the lean build of the blend kernel takes every blended run (the low-column build would fill the registers
         // the stream kernel needs)
         p->nbeside = side_by_side_share(t, jobs, njobs, flags);
+        lap("share");
         // The low-column build (four workgroups per CU) is worth 3-11 % on launches of a few rounds of waves - one 4K image, the
         // 512-image shard of the 8-GPU split - where ramp and tail count, nothing on the 4096-image batch and -1..-4 % on launches
         // of a hundred rounds (256 x 4K: profiles/r04/lowl_kernel_4k_workloads.txt): above a million octets the general build
@@ -1426,6 +1501,7 @@ namespace {
 } // namespace
 
 int mjx_release_thread_cache(void) {
+    spare_release();
     pthread_mutex_lock(&g_pool_lock);
     for(int i = 0; i < kMaxArenas; ++i) {
         if(!g_busy[i]) g_pool[i].release();
