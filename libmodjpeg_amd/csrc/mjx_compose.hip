@@ -944,7 +944,7 @@ MJX_DEV uint4 global_load16_nt(const void *p) {
 // KIND: what the run's blocks need (wave-uniform, one instantiation each):
 //   kStreamZa   zero-alpha blocks: the JCOEF row alone travels (5 registers per octet in flight, so many more of them)
 //   kStreamDc   DC-only blocks: JCOEF row, tile row and the block's weight
-//   kStreamOpq  opaque blocks (kRunOpaque): the tile row alone - the image's block is not read at all, see octet_opaque below
+//   kStreamOpq  opaque blocks (kRunOpaque): the tile row alone - the image's block is not read at all (the OPQ branch of `finish` below)
 constexpr int kStreamZa = 0, kStreamDc = 1, kStreamOpq = 2;
 template <bool I16, int KIND, int DEPTH, bool WIDE>
 MJX_DEV void light_stream_run(const Run &run, const float *qtab, int lane) {

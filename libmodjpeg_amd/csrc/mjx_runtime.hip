@@ -465,7 +465,7 @@ void schedule_tiles(const uint64_t *pattern, const uint32_t *w00, int nblocks, b
     if(!exp_gather && all_same && !(split_zero && pattern[0] == 0) && !((split_dc || split_opq) && pattern[0] == 1)) return consecutive();
     // The same verdict as the comparison of the sorted order's cost below, without the sort: an octet costs what the UNION of its
     // blocks' patterns costs, which is at least the mean of what the blocks cost alone, so no order is cheaper than cost_floor / 8.
-    // (The headline batch: blocks that all have the smooth pattern or a subset of it - 16 of the 33 ms a plan took went here.)
+    // (The headline batch: blocks that all have the smooth pattern or a subset of it.)
     if(!exp_gather && !split_zero && !split_dc && !split_opq && cost_floor / (float)kWaveBlocks > 0.93f * cost_cons) return consecutive();
 
     // sorted order: densest first; among blocks of similar density those that use the same rows and
